@@ -1,0 +1,177 @@
+/*
+ * meatmodeler.h — C ABI of libmeatmodeler_hip.so (MI355X / gfx950 only).
+ *
+ * The drop-in boundary for the structure-from-motion hot path of skyepurchase/MeatModeler.
+ * The reference has no FFI of its own (it is pure Python calling cv2 / scipy); each entry point below
+ * names the reference call site it replaces (paths relative to the reference checkout) — the Python
+ * façade in meatmodeler_amd/{processor,bundleAdjuster,track}.py binds them with ctypes
+ * (see INTEGRATION.md for the stub a maintainer would add).
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes; no torch / C++ types.
+ *  - Pointers marked [dev] are HIP device pointers on the context's device; [host] are host pointers.
+ *  - Every call is asynchronous on the context's stream unless marked (sync); no call allocates or
+ *    frees device memory: the caller passes workspaces sized by the *_workspace_bytes functions.
+ *  - Return value: 0 = ok, negative = error (text via mm_last_error).  Nothing throws across the ABI.
+ */
+#ifndef MEATMODELER_H
+#define MEATMODELER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MM_OK 0
+#define MM_ERR_ARG (-1)
+#define MM_ERR_HIP (-2)
+#define MM_ERR_WORKSPACE (-3)
+#define MM_ERR_NUMERIC (-4)
+
+typedef struct mm_ctx mm_ctx;
+
+/* ---- context ------------------------------------------------------------------------------- */
+int mm_abi_version(void);
+/* hip_stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or NULL for the default stream. */
+int mm_ctx_create(int device, void *hip_stream, mm_ctx **out);
+void mm_ctx_destroy(mm_ctx *ctx);
+const char *mm_last_error(mm_ctx *ctx);
+int mm_ctx_sync(mm_ctx *ctx); /* (sync) hipStreamSynchronize on the context stream */
+/* HIP-event timing on the context stream (bench.py's roofline leg). */
+int mm_timer_create(mm_ctx *ctx, void **timer_out);
+int mm_timer_start(mm_ctx *ctx, void *timer);
+int mm_timer_stop(mm_ctx *ctx, void *timer);
+int mm_timer_elapsed_ms(mm_ctx *ctx, void *timer, float *ms_out); /* (sync) */
+void mm_timer_destroy(mm_ctx *ctx, void *timer);
+/* Per-launch profiling: while enabled every kernel launched through this context is bracketed by two HIP events on
+ * the context's stream.  mm_profile_report (sync) writes one line per kernel name, "name launches total_ms\n", and
+ * returns the number of lines.  Enabling clears earlier records. */
+int mm_profile_enable(mm_ctx *ctx, int on);
+int mm_profile_report(mm_ctx *ctx, char *buf, size_t buf_len);
+
+/* ---- a-2: brute-force Hamming 2-NN + ratio test ----------------------------------------------
+ * Replaces cv2.FlannBasedMatcher(...).knnMatch(prev_desc, new_desc, k=2) and the Lowe filter,
+ * processor.py:132-137 (exact form of the approximate FLANN search; ties -> lowest train index).
+ *
+ * Batched form: pair p matches query set  q + p*q_set_stride  (nq[p] rows, or nq_cap if nq == NULL)
+ * against train set t + p*t_set_stride.  Descriptors are 32 bytes, rows contiguous, 16-byte aligned.
+ *   idx  [n_pairs, nq_cap, 2] int32 : train index of the nearest / second nearest (-1 if absent)
+ *   dist [n_pairs, nq_cap, 2] int32 : their Hamming distances (-1 if absent)
+ * Rows >= nq[p] are left untouched.
+ */
+size_t mm_bf_workspace_bytes(int n_pairs, int nq_cap, int nt_cap);
+int mm_bf_knn2_batched(mm_ctx *ctx, const uint8_t *q /*dev*/, const int32_t *nq /*dev|NULL*/, int nq_cap,
+                       size_t q_set_stride, const uint8_t *t /*dev*/, const int32_t *nt /*dev|NULL*/, int nt_cap,
+                       size_t t_set_stride, int n_pairs, int32_t *idx /*dev*/, int32_t *dist /*dev*/,
+                       void *ws /*dev*/, size_t ws_bytes);
+int mm_bf_knn2_hamming(mm_ctx *ctx, const uint8_t *q /*dev*/, int nq, const uint8_t *t /*dev*/, int nt,
+                       int32_t *idx /*dev [nq,2]*/, int32_t *dist /*dev [nq,2]*/, void *ws, size_t ws_bytes);
+/* Lowe ratio test, order preserving: keeps query i iff it has two neighbours and
+ * (double)d0 < threshold * (double)d1  (processor.py:136-137).  pairs[p, j] = (queryIdx, trainIdx) of the
+ * j-th kept match in query order; m_out[p] = number kept. */
+int mm_ratio_filter_batched(mm_ctx *ctx, const int32_t *idx /*dev*/, const int32_t *dist /*dev*/,
+                            const int32_t *nq /*dev|NULL*/, int nq_cap, int n_pairs, double threshold,
+                            int32_t *pairs /*dev [n_pairs,nq_cap,2]*/, int32_t *m_out /*dev [n_pairs]*/);
+
+/* ---- a-1: ORB detect + describe ----------------------------------------------------------------
+ * Replaces orb.detectAndCompute(img, None), processor.py:129,328 with cv2.ORB_create(nfeatures=...) defaults
+ * (processor.py:308): 8 levels x1.2, FAST-9/16 t=20 + 3x3 NMS, border 31, 2n by FAST score then n by Harris,
+ * intensity-centroid orientation, 7x7 sigma=2 blur, 256-bit steered BRIEF.  Integer-exact definition in DESIGN.md.
+ */
+typedef struct mm_orb_params {
+    int32_t nfeatures;      /* processor.py:308 uses 20000; BASELINE configs 2000 / 4000 / 8000 */
+    int32_t nlevels;        /* 8  */
+    int32_t edge_threshold; /* 31 */
+    int32_t fast_threshold; /* 20 */
+    float scale_factor;     /* 1.2f */
+    int32_t reserved;
+} mm_orb_params;
+size_t mm_orb_workspace_bytes(int batch, int height, int width, const mm_orb_params *prm);
+/* imgs [batch, height, stride] u8 grey.  Outputs are per frame with capacity cap = nfeatures:
+ *   kp_xy   [batch, cap, 2] f32 : level-0 coordinates (cv2.KeyPoint.pt)
+ *   kp_meta [batch, cap, 4] i32 : level, x_level, y_level, harris25 (low 32 bits; debugging / parity)
+ *   kp_resp [batch, cap]    f32 : Harris response (cv2.KeyPoint.response)
+ *   kp_mom  [batch, cap, 2] i32 : intensity-centroid moments m10, m01 (angle = atan2(m01, m10))
+ *   desc    [batch, cap, 32] u8
+ *   n_out   [batch] i32
+ * pattern [256*4] int8 (x0,y0,x1,y1 per bit) device pointer — the rBRIEF sampling pattern. */
+int mm_orb_detect_compute(mm_ctx *ctx, const uint8_t *imgs /*dev*/, int batch, int height, int width, int stride,
+                          const mm_orb_params *prm, const int8_t *pattern /*dev*/, void *ws /*dev*/, size_t ws_bytes,
+                          float *kp_xy, int32_t *kp_meta, float *kp_resp, int32_t *kp_mom, uint8_t *desc,
+                          int32_t *n_out);
+/* Level geometry shared with the host side (and the oracle checks it): widths/heights of the nlevels levels. */
+int mm_orb_level_sizes(int height, int width, const mm_orb_params *prm, int32_t *lvl_w /*host[nlevels]*/,
+                       int32_t *lvl_h /*host*/, int32_t *lvl_n /*host: features per level*/,
+                       float *lvl_scale /*host*/);
+
+/* ---- a-3 / a-5: track linking and flattening (host logic, exact coordinate-equality semantics) -----
+ * Replaces processor.pointTracking (processor.py:190-243) run over a whole clip plus
+ * `popped_tracks += tracks` (processor.py:418) and managePoints (processor.py:264-291).
+ * All pointers are HOST pointers.  kp_xy [n_frames, cap, 2] f32, matches [n_frames-1, mcap, 2] (queryIdx, trainIdx).
+ * Output: CSR over tracks in the reference's final order; obs_frame / obs_kp give each observation.
+ * Returns the number of tracks (>= 0) or a negative error; *n_obs_out receives the observation count.
+ * If the output capacity is too small returns MM_ERR_WORKSPACE with the required sizes in *n_obs_out / return. */
+int64_t mm_link_tracks_clip(int n_frames, int cap, const int32_t *kp_count, const float *kp_xy, int mcap,
+                            const int32_t *match_count, const int32_t *matches, int64_t max_tracks,
+                            int64_t max_obs, int64_t *track_ptr /*[max_tracks+1]*/, int32_t *obs_frame,
+                            int32_t *obs_kp, int64_t *n_obs_out);
+/* Host index build for BA: CSR of observations by point and by camera (stable). */
+int mm_ba_build_index(int F, int P, int64_t O, const int32_t *fi, const int32_t *pi, int32_t *pt_ptr /*[P+1]*/,
+                      int32_t *pt_obs /*[O]*/, int32_t *cam_ptr /*[F+1]*/, int32_t *cam_obs /*[O]*/);
+
+/* ---- a-4: two-view DLT triangulation ------------------------------------------------------------
+ * Replaces the per-track cv2.triangulatePoints + dehomogenise loop, processor.py:254-261.
+ * proj [F,3,4] f64; track i uses views f0[i], f1[i] with pixels x0[i], x1[i]; X [n,3]. */
+int mm_triangulate_dlt(mm_ctx *ctx, const double *proj /*dev*/, const int32_t *f0 /*dev*/, const int32_t *f1 /*dev*/,
+                       const double *x0 /*dev [n,2]*/, const double *x1 /*dev [n,2]*/, int64_t n,
+                       double *X /*dev [n,3]*/);
+
+/* ---- a-7..a-9: bundle adjustment sweeps -----------------------------------------------------------
+ * Cost model of bundleAdjuster.py:7-52,81-102 (Rodrigues rotate, translate, full 3x3 K, divide, minus obs),
+ * f64 throughout.  The LM/trust-region driver (the reference's scipy least_squares TRF loop,
+ * bundleAdjuster.py:180-192) lives in meatmodeler_amd/bundleAdjuster.py and calls these sweeps. */
+typedef struct mm_ba_problem {
+    int32_t F, P;
+    int64_t O;
+    const double *K;         /* dev [9] row-major 3x3 */
+    const int32_t *fi, *pi;  /* dev [O] camera / point index of each observation */
+    const double *obs;       /* dev [O,2] */
+    const int32_t *pt_ptr, *pt_obs;   /* dev CSR by point  (mm_ba_build_index) */
+    const int32_t *cam_ptr, *cam_obs; /* dev CSR by camera */
+} mm_ba_problem;
+
+/* res [O,2] (may be NULL) ; cost2 [1] receives sum of squared residuals (caller halves it). */
+int mm_ba_residual(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams /*dev [F,6]*/,
+                   const double *pts /*dev [P,3]*/, double *res /*dev|NULL*/, double *cost2 /*dev [1]*/,
+                   void *ws, size_t ws_bytes);
+/* Analytic Jacobian blocks per observation: Jc [O,2,6], Jp [O,2,3] (parity / debugging surface). */
+int mm_ba_jacobian(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, const double *pts, double *Jc,
+                   double *Jp);
+/* Block normal equations: B [F,6,6] = sum Jc^T Jc, gc [F,6] = sum Jc^T r, C [P,6] = upper triangle of sum Jp^T Jp
+ * (xx,xy,xz,yy,yz,zz), gp [P,3] = sum Jp^T r.  Deterministic (segmented, atomic-free).  gc/B may be NULL when
+ * cameras are fixed; C/gp may be NULL when points are fixed (pose-only, bundleAdjuster.py:206-243). */
+int mm_ba_normal_eq(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, const double *pts, double *B,
+                    double *gc, double *C, double *gp);
+/* out [O,2] = Jc * wc[fi] + Jp * wp[pi]  (either w may be NULL = zero). */
+int mm_ba_jvp(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, const double *pts, const double *wc,
+              const double *wp, double *out);
+/* Reduced camera system.  Cd [P,6] = damped point blocks (C + reg*diag), Bd [F,6,6] damped camera blocks.
+ * S [6F,6F] (full symmetric, row-major) = blockdiag(Bd) - sum_p E_p Cd_p^-1 E_p^T ;  v [6F] = gc - E Cd^-1 gp.
+ * Cinv [P,6] receives Cd^-1 (upper triangle).  S and v are overwritten. */
+int mm_ba_schur(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, const double *pts, const double *Bd,
+                const double *Cd, const double *gc, const double *gp, double *S, double *v, double *Cinv);
+/* dp [P,3] = Cinv (gp - E^T dc). */
+int mm_ba_backsub(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, const double *pts, const double *Cinv,
+                  const double *gp, const double *dc /*dev [F,6]*/, double *dp);
+/* Dense SPD solve A x = b by blocked Cholesky (f64 MFMA trailing updates).  A [n,n] row-major, lower triangle is
+ * overwritten by L; b is overwritten by x.  info [1] dev int32: 0 ok, k>0 = non-positive pivot at column k. */
+size_t mm_chol_workspace_bytes(int n);
+int mm_chol_solve(mm_ctx *ctx, double *A /*dev*/, int n, double *b /*dev*/, int nrhs, int32_t *info /*dev*/,
+                  void *ws, size_t ws_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MEATMODELER_H */

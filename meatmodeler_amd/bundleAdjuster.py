@@ -1,0 +1,434 @@
+"""Drop-in for the reference's ``bundleAdjuster.py`` — same public names, argument and return conventions.
+
+The reference hands its cost function to ``scipy.optimize.least_squares`` (TRF, ``jac_sparsity``,
+``x_scale='jac'``, ``ftol=1e-4``; bundleAdjuster.py:180-192).  SciPy then differentiates numerically and solves
+each damped Gauss-Newton system with LSMR (scipy/optimize/_lsq/trf.py:401-560).  Here the same trust-region
+iteration (`trf_no_bounds`: Jacobian column scaling with running max, Cauchy-derived regulariser, 2-D subspace
+trust-region step, ratio test, ftol/xtol/gtol termination) runs with
+
+  * the analytic Jacobian (never materialised) and block normal equations computed by HIP sweeps,
+  * the regularised Gauss-Newton system  (J^T J + reg D^-2) q = J^T f  solved EXACTLY through the Schur complement
+    onto the cameras (point blocks eliminated, dense 6F x 6F Cholesky on f64 MFMA) instead of iteratively by LSMR.
+
+So the iterates follow SciPy's to within LSMR's own 1e-6 tolerance and the finite-difference error of the reference's
+Jacobian; see DESIGN.md §BA for what "parity" means on this gauge-free problem.
+
+Host Python only sequences launches and does the 2x2 / scalar algebra of the trust region; torch is used for
+device buffers and a handful of axpy / dot reductions on the parameter vector.
+"""
+import numpy as np
+import torch
+from numpy.linalg import norm as _norm
+from scipy.linalg import cho_factor, cho_solve, LinAlgError
+from scipy.sparse import csr_matrix
+
+from . import ops
+from ._lib import default_context, MMError
+
+EPS = np.finfo(float).eps
+
+
+# ----------------------------------------------------------------------------------------------- small helpers
+
+def _rodrigues_matrix(rvec):
+    """Axis-angle -> R, the closed form cv2.Rodrigues evaluates at bundleAdjuster.py:153,201."""
+    r = np.asarray(rvec, float).reshape(3)
+    th2 = float(r @ r)
+    th = np.sqrt(th2)
+    Kx = np.array([[0.0, -r[2], r[1]], [r[2], 0.0, -r[0]], [-r[1], r[0], 0.0]])
+    if th < 1e-8:
+        a, b = 1.0 - th2 / 6.0, 0.5 - th2 / 24.0
+    else:
+        a, b = np.sin(th) / th, (1.0 - np.cos(th)) / th2
+    return np.eye(3) + a * Kx + b * (Kx @ Kx)
+
+
+def frameParameters(frame_extrinsic_matrices):
+    """[F,3|4,4] -> [6F] rows (rvec, tvec) (bundleAdjuster.py:105-134): theta = arccos((tr R - 1)/2) without
+    clipping, axis = skew part / (2 sin theta) with 0/0 -> 0, r = axis * theta.  O(F) host glue."""
+    E = np.asarray(frame_extrinsic_matrices, float)
+    R = E[:, :3, :3]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        theta = np.arccos((np.trace(R, axis1=1, axis2=2) - 1.0) * 0.5)
+        two_s = 2.0 * np.sin(theta)
+        axis = np.stack([R[:, 2, 1] - R[:, 1, 2], R[:, 0, 2] - R[:, 2, 0], R[:, 1, 0] - R[:, 0, 1]], 1) / two_s[:, None]
+        rvec = np.nan_to_num(axis) * theta[:, None]
+    return np.concatenate([rvec, E[:, :3, 3]], axis=1).reshape(-1)
+
+
+def pointAdjustmentSparsity(n_frames, n_points, frame_indices, point_indices):
+    """Jacobian sparsity structure (bundleAdjuster.py:55-78) as CSR: observation i owns rows 2i, 2i+1 with ones in its
+    camera's 6 and its point's 3 columns.  The HIP path never needs it (the block layout is implicit); provided for
+    callers that used it."""
+    fi = np.asarray(frame_indices).astype(np.int64)
+    pi = np.asarray(point_indices).astype(np.int64)
+    O = fi.size
+    cols = np.empty((O, 2, 9), np.int64)
+    cols[:, :, :6] = (6 * fi)[:, None, None] + np.arange(6)
+    cols[:, :, 6:] = (6 * n_frames + 3 * pi)[:, None, None] + np.arange(3)
+    return csr_matrix((np.ones(18 * O, dtype=int), cols.reshape(-1), np.arange(0, 18 * O + 1, 9)),
+                      shape=(2 * O, 6 * n_frames + 3 * n_points))
+
+
+def _dev(x, device):
+    return torch.as_tensor(np.ascontiguousarray(x, np.float64)).to(device)
+
+
+def project(points, frame_params, camera_matrix):
+    """points [n,3], frame_params [n,6] -> pixels [n,2] on the device (bundleAdjuster.py:31-52): the residual sweep
+    with zero observations and identity index maps."""
+    ctx = default_context()
+    n = len(points)
+    ar = np.arange(n, dtype=np.int32)
+    pb = ops.BADevice(camera_matrix, ar, ar, np.zeros((n, 2)), n, n, ctx.device, ctx)
+    _, res = pb.residual(_dev(np.asarray(frame_params, float)[:, :6], ctx.device), _dev(points, ctx.device), True)
+    return res.cpu().numpy()
+
+
+def rotate(points, rot_vecs):
+    """Rodrigues rotation of points by per-row axis-angle vectors (bundleAdjuster.py:7-28).  Not on the hot path (the
+    sweeps fuse it); evaluated through `project` with K = I after translating by +t0 to keep z away from zero is NOT
+    possible in general, so this helper uses device tensor algebra."""
+    ctx = default_context()
+    X = _dev(points, ctx.device)
+    r = _dev(rot_vecs, ctx.device)
+    th = r.norm(dim=1, keepdim=True)
+    k = torch.where(th > 0, r / torch.where(th > 0, th, torch.ones_like(th)), torch.zeros_like(r))
+    c, s = torch.cos(th), torch.sin(th)
+    out = c * X + s * torch.cross(k, X, dim=1) + (k * X).sum(1, keepdim=True) * (1 - c) * k
+    return out.cpu().numpy()
+
+
+def pointFun(parameters, camera_matrix, n_frames, n_points, frame_indices, point_indices, points_2D):
+    """Residual vector [2*O] (bundleAdjuster.py:81-102) from the HIP residual sweep."""
+    ctx = default_context()
+    parameters = np.asarray(parameters, float)
+    pb = ops.BADevice(camera_matrix, frame_indices, point_indices, points_2D, n_frames, n_points, ctx.device, ctx)
+    cams = _dev(parameters[:6 * n_frames].reshape(n_frames, 6), ctx.device)
+    pts = _dev(parameters[6 * n_frames:].reshape(n_points, 3), ctx.device)
+    return pb.residual(cams, pts, True)[1].cpu().numpy().ravel()
+
+
+def poseFun(parameters, camera_intrinsic_matrix, n_frames, frame_indices, point_indices, points_3D, points_2D):
+    """Pose-only residuals (bundleAdjuster.py:206-211)."""
+    ctx = default_context()
+    pb = ops.BADevice(camera_intrinsic_matrix, frame_indices, point_indices, points_2D, n_frames, len(points_3D),
+                      ctx.device, ctx)
+    cams = _dev(np.asarray(parameters, float).reshape(n_frames, 6), ctx.device)
+    return pb.residual(cams, _dev(points_3D, ctx.device), True)[1].cpu().numpy().ravel()
+
+
+# ----------------------------------------------------------------------------------------------- trust region (host scalars)
+
+def _solve_trust_region_2d(B, g, Delta):
+    """2-D trust-region subproblem exactly as scipy/optimize/_lsq/common.py:171-219 solves it."""
+    try:
+        R, lower = cho_factor(B)
+        p = -cho_solve((R, lower), g)
+        if np.dot(p, p) <= Delta ** 2:
+            return p, True
+    except (LinAlgError, ValueError):
+        pass
+    a = B[0, 0] * Delta ** 2
+    b = B[0, 1] * Delta ** 2
+    c = B[1, 1] * Delta ** 2
+    d = g[0] * Delta
+    f = g[1] * Delta
+    coeffs = np.array([-b + d, 2 * (a - c + f), 6 * b, 2 * (-a + c + f), -b - d])
+    t = np.roots(coeffs)
+    t = np.real(t[np.isreal(t)])
+    p = Delta * np.vstack((2 * t / (1 + t ** 2), (1 - t ** 2) / (1 + t ** 2)))
+    value = 0.5 * np.sum(p * B.dot(p), axis=0) + np.dot(g, p)
+    return p[:, np.argmin(value)], False
+
+
+def _update_tr_radius(Delta, actual, predicted, step_norm, bound_hit):
+    if predicted > 0:
+        ratio = actual / predicted
+    elif predicted == actual == 0:
+        ratio = 1
+    else:
+        ratio = 0
+    if ratio < 0.25:
+        Delta = 0.25 * step_norm
+    elif ratio > 0.75 and bound_hit:
+        Delta *= 2.0
+    return Delta, ratio
+
+
+def _check_termination(dF, F, dx_norm, x_norm, ratio, ftol, xtol):
+    ftol_ok = dF < ftol * F and ratio > 0.25
+    xtol_ok = dx_norm < xtol * (xtol + x_norm)
+    if ftol_ok and xtol_ok:
+        return 4
+    if ftol_ok:
+        return 2
+    if xtol_ok:
+        return 3
+    return None
+
+
+_MESSAGES = {-1: "Improper input parameters status returned from `leastsq`",
+             0: "The maximum number of function evaluations is exceeded.",
+             1: "`gtol` termination condition is satisfied.", 2: "`ftol` termination condition is satisfied.",
+             3: "`xtol` termination condition is satisfied.",
+             4: "Both `ftol` and `xtol` termination conditions are satisfied."}
+
+
+def _print_header():
+    print("{:^15}{:^15}{:^15}{:^15}{:^15}{:^15}".format("Iteration", "Total nfev", "Cost", "Cost reduction",
+                                                          "Step norm", "Optimality"))
+
+
+def _print_iteration(it, nfev, cost, red, step, opt):
+    red = " " * 15 if red is None else f"{red:^15.2e}"
+    step = " " * 15 if step is None else f"{step:^15.2e}"
+    print(f"{it:^15}{nfev:^15}{cost:^15.4e}{red}{step}{opt:^15.2e}")
+
+
+class BAResult:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class SchurTRF:
+    """SciPy's trf_no_bounds (tr_solver='lsmr', x_scale='jac', linear loss) with the Gauss-Newton system solved by
+    the Schur complement.  `allreduce` (optional) sums partial block quantities across ranks for the sharded path
+    (points partitioned over GPUs, cameras replicated): it is called on every tensor that is a sum over
+    observations."""
+
+    def __init__(self, pb, allreduce=None, timers=None):
+        self.pb = pb
+        self.allreduce = allreduce
+        self.timers = timers
+
+    # -- reductions that need the cross-rank sum when sharded --
+    def _ar(self, *tensors):
+        if self.allreduce is not None:
+            for t in tensors:
+                self.allreduce(t)
+
+    def _cost(self, cams, pts):
+        c2, _ = self.pb.residual(cams, pts)
+        self._ar(c2)
+        return 0.5 * float(c2.item())
+
+    def _normal(self, cams, pts):
+        B, gc, C, gp = self.pb.normal_eq(cams, pts)
+        self._ar(B, gc)          # camera blocks are sums over all observations; point blocks are local
+        return B, gc, C, gp
+
+    def solve(self, cams0, pts0, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None, verbose=0, local_points_norm=None):
+        pb = self.pb
+        dev = pb.device
+        cams = cams0.clone()
+        pts = pts0.clone()
+        n = cams.numel() + pts.numel()
+
+        def vdot(ac, ap, bc, bp):
+            """<a, b> over the full parameter vector (camera part replicated, point part sharded)."""
+            s = torch.stack([(ac * bc).sum(), (ap * bp).sum()])
+            if self.allreduce is not None:
+                t = s[1:2].clone()
+                self.allreduce(t)
+                s = torch.stack([s[0], t[0]])
+            return s
+
+        cost = self._cost(cams, pts)
+        if not np.isfinite(cost):
+            raise ValueError("Residuals are not finite in the initial point.")
+        nfev, njev = 1, 1
+        B, gc, C, gp = self._normal(cams, pts)
+        diag_idx = torch.tensor([0, 3, 5], device=dev)
+        sic = torch.sqrt(torch.diagonal(B, dim1=1, dim2=2)).clone()
+        sip = torch.sqrt(C[:, diag_idx])
+        sic[sic == 0] = 1.0
+        sip[sip == 0] = 1.0
+        Delta = float(torch.sqrt(vdot(cams * sic, pts * sip, cams * sic, pts * sip).sum()).item())
+        if Delta == 0:
+            Delta = 1.0
+        if max_nfev is None:
+            max_nfev = n * 100
+        alpha = 0.0
+        termination = None
+        iteration = 0
+        step_norm = None
+        actual = None
+        if verbose == 2:
+            _print_header()
+        while True:
+            gmax = torch.stack([gc.abs().max() if gc.numel() else torch.zeros((), dtype=torch.float64, device=dev),
+                                gp.abs().max() if gp.numel() else torch.zeros((), dtype=torch.float64, device=dev)])
+            if self.allreduce is not None:
+                self.allreduce(gmax, op="max")
+            g_norm = float(gmax.max().item())
+            if g_norm < gtol:
+                termination = 1
+            if verbose == 2:
+                _print_iteration(iteration, nfev, cost, actual, step_norm, g_norm)
+            if termination is not None or nfev == max_nfev:
+                break
+            # scaled gradient g_h = d * g, d = 1 / scale_inv
+            ghc, ghp = gc / sic, gp / sip
+            gh_norm = float(torch.sqrt(vdot(ghc, ghp, ghc, ghp).sum()).item())
+            # Cauchy-derived regulariser (trf.py:473-477): a = 0.5 |J_h g_h|^2, b = -|g_h|^2
+            u1 = pb.jvp(cams, pts, ghc / sic, ghp / sip)
+            d11 = (u1 * u1).sum().reshape(1)
+            self._ar(d11)
+            a_q = 0.5 * float(d11.item())
+            b_q = -gh_norm ** 2
+            to_tr = Delta / gh_norm
+            ts = [0.0, to_tr]
+            if a_q != 0:
+                ext = -0.5 * b_q / a_q
+                if 0.0 < ext < to_tr:
+                    ts.append(ext)
+            ts = np.asarray(ts)
+            ag_value = float(np.min(ts * (a_q * ts + b_q)))
+            reg = -ag_value / Delta ** 2
+            # damped blocks: J^T J + reg * D^-2  (D^-2 = scale_inv^2)
+            Bd = B.clone()
+            Bd.diagonal(dim1=1, dim2=2).add_(reg * sic * sic)
+            Cd = C.clone()
+            Cd[:, diag_idx] += reg * sip * sip
+            S, v, Cinv = pb.schur(cams, pts, Bd, Cd, gc, gp)
+            if self.allreduce is not None:
+                # every rank added the full blockdiag(Bd) and gc: remove the duplicates after the sum
+                ws = self.allreduce.world_size
+                self.allreduce(S)
+                self.allreduce(v)
+                if ws > 1:
+                    idx = torch.arange(6 * pb.F, device=dev).reshape(pb.F, 6)
+                    blk = S.reshape(pb.F, 6, pb.F, 6)
+                    f = torch.arange(pb.F, device=dev)
+                    blk[f, :, f, :] -= (ws - 1) * Bd
+                    v -= (ws - 1) * gc.reshape(-1)
+            info = ops.chol_solve(S, v, pb.ctx)
+            dc = v.reshape(pb.F, 6)
+            dp = pb.backsub(cams, pts, Cinv, gp, dc)
+            if int(info.item()) != 0:
+                raise MMError(f"reduced camera system is not positive definite (pivot {int(info.item())})")
+            gnc, gnp = dc * sic, dp * sip          # gn_h = q * scale_inv
+            # orthonormal basis of span{g_h, gn_h} (trf.py:481-482)
+            q1c, q1p = ghc / gh_norm, ghp / gh_norm
+            sc = vdot(q1c, q1p, gnc, gnp).sum()
+            wc, wp = gnc - sc * q1c, gnp - sc * q1p
+            wn = float(torch.sqrt(vdot(wc, wp, wc, wp).sum()).item())
+            gn_norm = float(torch.sqrt(vdot(gnc, gnp, gnc, gnp).sum()).item())
+            if wn <= 1e-14 * max(gn_norm, 1e-300):
+                q2c, q2p = torch.zeros_like(q1c), torch.zeros_like(q1p)
+                degenerate = True
+            else:
+                q2c, q2p = wc / wn, wp / wn
+                degenerate = False
+            # J_h q1 = u1 / |g_h| ;  J_h q2 = J (q2 / scale_inv)
+            s1c, s1p = q1c / sic, q1p / sip        # unscaled basis steps d * q
+            s2c, s2p = q2c / sic, q2p / sip
+            Jq1 = u1 / gh_norm
+            Jq2 = pb.jvp(cams, pts, s2c, s2p)
+            bs = torch.stack([(Jq1 * Jq1).sum(), (Jq1 * Jq2).sum(), (Jq2 * Jq2).sum()])
+            self._ar(bs)
+            nn = torch.stack([vdot(s1c, s1p, s1c, s1p).sum(), vdot(s1c, s1p, s2c, s2p).sum(),
+                              vdot(s2c, s2p, s2c, s2p).sum(), vdot(q2c, q2p, ghc, ghp).sum(),
+                              vdot(cams, pts, cams, pts).sum()])
+            b11, b12, b22 = bs.tolist()
+            n11, n12, n22, g2, xx = nn.tolist()
+            if degenerate:
+                b22 = 1.0
+            B_S = np.array([[b11, b12], [b12, b22]])
+            g_S = np.array([gh_norm, g2])
+            x_norm = np.sqrt(xx)
+            actual = -1.0
+            while actual <= 0 and nfev < max_nfev:
+                p_S, _ = _solve_trust_region_2d(B_S, g_S, Delta)
+                predicted = -(0.5 * p_S @ B_S @ p_S + g_S @ p_S)
+                cams_new = cams + p_S[0] * s1c + p_S[1] * s2c
+                pts_new = pts + p_S[0] * s1p + p_S[1] * s2p
+                cost_new = self._cost(cams_new, pts_new)
+                nfev += 1
+                step_h_norm = float(_norm(p_S))
+                if not np.isfinite(cost_new):
+                    Delta = 0.25 * step_h_norm
+                    continue
+                actual = cost - cost_new
+                Delta_new, ratio = _update_tr_radius(Delta, actual, predicted, step_h_norm, step_h_norm > 0.95 * Delta)
+                step_norm = float(np.sqrt(max(p_S[0] ** 2 * n11 + 2 * p_S[0] * p_S[1] * n12 + p_S[1] ** 2 * n22, 0.0)))
+                termination = _check_termination(actual, cost, step_norm, x_norm, ratio, ftol, xtol)
+                if termination is not None:
+                    break
+                alpha *= Delta / Delta_new
+                Delta = Delta_new
+            if actual > 0:
+                cams, pts, cost = cams_new, pts_new, cost_new
+                B, gc, C, gp = self._normal(cams, pts)
+                njev += 1
+                sic = torch.maximum(torch.sqrt(torch.diagonal(B, dim1=1, dim2=2)), sic)
+                sip = torch.maximum(torch.sqrt(C[:, diag_idx]), sip)
+            else:
+                step_norm = 0
+                actual = 0
+            iteration += 1
+        if termination is None:
+            termination = 0
+        return BAResult(cams=cams, pts=pts, cost=cost, optimality=g_norm, nfev=nfev, njev=njev, status=termination,
+                        message=_MESSAGES[termination], success=termination > 0)
+
+
+def _finish_verbose(res, cost0, verbose):
+    if verbose >= 1:
+        print(res.message)
+        print(f"Function evaluations {res.nfev}, initial cost {cost0:.4e}, final cost {res.cost:.4e}, "
+              f"first-order optimality {res.optimality:.2e}.")
+
+
+def reformatPointResult(result, n_frames, n_points):
+    """x -> (points [P,3], list of F 4x4 extrinsics) (bundleAdjuster.py:137-157)."""
+    x = np.asarray(result.x, float)
+    points = x[n_frames * 6:].reshape((n_points, 3))
+    frames = x[:n_frames * 6].reshape((n_frames, 6))
+    extrinsics = []
+    for rvec, tvec in zip(frames[:, :3], frames[:, 3:]):
+        E = np.eye(4)
+        E[:3, :3] = _rodrigues_matrix(rvec)
+        E[:3, 3] = tvec
+        extrinsics.append(E)
+    return points, extrinsics
+
+
+def reformatPoseResult(result, n_frames):
+    """x -> list of F 3x4 extrinsics (bundleAdjuster.py:197-203)."""
+    fp = np.asarray(result.x, float).reshape((n_frames, 6))
+    return [np.hstack((_rodrigues_matrix(r), t.reshape(3, 1))) for r, t in zip(fp[:, :3], fp[:, 3:6])]
+
+
+def solvePoints(frame_extrinsic_matrices, camera_intrinsic_matrix, points_3D, points_2D, frame_indices, point_indices,
+                ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None, verbose=2):
+    """adjustPoints with the optimiser settings exposed; returns the full result object (x, cost, nfev, ...)."""
+    ctx = default_context()
+    dev = ctx.device
+    ext = np.asarray(frame_extrinsic_matrices, float)
+    F = len(ext)
+    pts0 = np.asarray(points_3D, float).reshape(-1, 3)
+    P = len(pts0)
+    with np.errstate(all="ignore"):
+        cams0 = frameParameters(ext).reshape(F, 6)
+    pb = ops.BADevice(camera_intrinsic_matrix, frame_indices, point_indices, points_2D, F, P, dev, ctx)
+    solver = SchurTRF(pb)
+    cams_d, pts_d = _dev(cams0, dev), _dev(pts0, dev)
+    cost0 = None
+    if verbose >= 1:
+        cost0 = solver._cost(cams_d, pts_d)
+    res = solver.solve(cams_d, pts_d, ftol=ftol, xtol=xtol, gtol=gtol, max_nfev=max_nfev, verbose=verbose)
+    res.x = np.concatenate([res.cams.cpu().numpy().reshape(-1), res.pts.cpu().numpy().reshape(-1)])
+    if verbose >= 1:
+        _finish_verbose(res, cost0, verbose)
+    return res
+
+
+def adjustPoints(frame_extrinsic_matrices, camera_intrinsic_matrix, points_3D, points_2D, frame_indices, point_indices):
+    """Full bundle adjustment over all cameras and points (bundleAdjuster.py:160-194) with the reference's settings
+    (x_scale='jac', ftol=1e-4, verbose=2 progress table).  -> (points [P,3], list of F 4x4 extrinsics)."""
+    res = solvePoints(frame_extrinsic_matrices, camera_intrinsic_matrix, points_3D, points_2D, frame_indices,
+                      point_indices, ftol=1e-4, verbose=2)
+    F = len(frame_extrinsic_matrices)
+    return reformatPointResult(res, F, len(np.asarray(points_3D).reshape(-1, 3)))

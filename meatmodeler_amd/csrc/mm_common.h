@@ -1,0 +1,78 @@
+// Internal helpers shared by the translation units of libmeatmodeler_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include "../../include/meatmodeler.h"
+
+struct mm_prof_rec {
+    const char *name;
+    hipEvent_t a, b;
+};
+
+struct mm_ctx {
+    int device;
+    hipStream_t stream;
+    char err[512];
+    // optional per-launch HIP-event profiling (mm_profile_*): bench.py's live roofline measurement
+    bool prof = false;
+    std::vector<mm_prof_rec> recs;
+    std::vector<hipEvent_t> pool;
+};
+
+static inline hipEvent_t mm_prof_event(mm_ctx *c) {
+    hipEvent_t e = nullptr;
+    if (!c->pool.empty()) {
+        e = c->pool.back();
+        c->pool.pop_back();
+    } else {
+        (void)hipEventCreate(&e);
+    }
+    return e;
+}
+
+// Launch on the context's stream; when profiling is on, bracket the launch with two events on that stream.
+#define MM_LAUNCH(ctx, name, kernel, grid, block, shmem, ...)                                          \
+    do {                                                                                               \
+        hipEvent_t ea_ = nullptr, eb_ = nullptr;                                                       \
+        if ((ctx)->prof) {                                                                             \
+            ea_ = mm_prof_event(ctx);                                                                  \
+            eb_ = mm_prof_event(ctx);                                                                  \
+            (void)hipEventRecord(ea_, (ctx)->stream);                                                  \
+        }                                                                                              \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, __VA_ARGS__);                    \
+        if ((ctx)->prof) {                                                                             \
+            (void)hipEventRecord(eb_, (ctx)->stream);                                                  \
+            (ctx)->recs.push_back(mm_prof_rec{name, ea_, eb_});                                        \
+        }                                                                                              \
+        MM_LAUNCH_CHECK(ctx, name);                                                                    \
+    } while (0)
+
+static inline int mm_fail(mm_ctx *ctx, int code, const char *fmt, ...) {
+    if (ctx) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+#define MM_HIP(ctx, call)                                                                              \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return mm_fail(ctx, MM_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),    \
+                           __FILE__, __LINE__);                                                        \
+    } while (0)
+
+#define MM_LAUNCH_CHECK(ctx, name)                                                                     \
+    do {                                                                                               \
+        hipError_t e_ = hipGetLastError();                                                             \
+        if (e_ != hipSuccess)                                                                          \
+            return mm_fail(ctx, MM_ERR_HIP, "launch of %s failed: %s", name, hipGetErrorString(e_));   \
+    } while (0)
+
+static inline size_t mm_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

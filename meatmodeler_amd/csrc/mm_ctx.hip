@@ -1,0 +1,126 @@
+// Context, error text and HIP-event timers of the C ABI (include/meatmodeler.h).
+#include "mm_common.h"
+
+extern "C" {
+
+int mm_abi_version(void) { return 1; }
+
+int mm_ctx_create(int device, void *hip_stream, mm_ctx **out) {
+    if (!out) return MM_ERR_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return MM_ERR_HIP;
+    mm_ctx *c = new mm_ctx();
+    c->device = device;
+    c->stream = (hipStream_t)hip_stream;
+    c->err[0] = 0;
+    if (hipSetDevice(device) != hipSuccess) {
+        delete c;
+        return MM_ERR_HIP;
+    }
+    *out = c;
+    return MM_OK;
+}
+
+void mm_ctx_destroy(mm_ctx *ctx) {
+    if (!ctx) return;
+    for (auto &r : ctx->recs) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    for (auto e : ctx->pool) (void)hipEventDestroy(e);
+    delete ctx;
+}
+
+// ---- per-launch profiling ---------------------------------------------------------------------------------------------
+int mm_profile_enable(mm_ctx *ctx, int on) {
+    if (!ctx) return MM_ERR_ARG;
+    if (on) {
+        for (auto &r : ctx->recs) {
+            ctx->pool.push_back(r.a);
+            ctx->pool.push_back(r.b);
+        }
+        ctx->recs.clear();
+    }
+    ctx->prof = on != 0;
+    return MM_OK;
+}
+
+int mm_profile_report(mm_ctx *ctx, char *buf, size_t buf_len) {
+    if (!ctx || !buf || buf_len < 64) return MM_ERR_ARG;
+    MM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    struct Agg {
+        const char *name;
+        long n;
+        double ms;
+    };
+    std::vector<Agg> agg;
+    for (auto &r : ctx->recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+        bool found = false;
+        for (auto &a : agg)
+            if (strcmp(a.name, r.name) == 0) {
+                a.n++;
+                a.ms += ms;
+                found = true;
+                break;
+            }
+        if (!found) agg.push_back(Agg{r.name, 1, (double)ms});
+    }
+    size_t off = 0;
+    buf[0] = 0;
+    for (auto &a : agg) {
+        int w = snprintf(buf + off, buf_len - off, "%s %ld %.6f\n", a.name, a.n, a.ms);
+        if (w < 0 || (size_t)w >= buf_len - off) return mm_fail(ctx, MM_ERR_WORKSPACE, "mm_profile_report: buffer too small");
+        off += (size_t)w;
+    }
+    return (int)agg.size();
+}
+
+const char *mm_last_error(mm_ctx *ctx) { return ctx ? ctx->err : "null context"; }
+
+int mm_ctx_sync(mm_ctx *ctx) {
+    if (!ctx) return MM_ERR_ARG;
+    MM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MM_OK;
+}
+
+struct mm_timer {
+    hipEvent_t a, b;
+};
+
+int mm_timer_create(mm_ctx *ctx, void **timer_out) {
+    if (!ctx || !timer_out) return MM_ERR_ARG;
+    mm_timer *t = new mm_timer();
+    MM_HIP(ctx, hipEventCreate(&t->a));
+    MM_HIP(ctx, hipEventCreate(&t->b));
+    *timer_out = t;
+    return MM_OK;
+}
+int mm_timer_start(mm_ctx *ctx, void *timer) {
+    if (!ctx || !timer) return MM_ERR_ARG;
+    MM_HIP(ctx, hipEventRecord(((mm_timer *)timer)->a, ctx->stream));
+    return MM_OK;
+}
+int mm_timer_stop(mm_ctx *ctx, void *timer) {
+    if (!ctx || !timer) return MM_ERR_ARG;
+    MM_HIP(ctx, hipEventRecord(((mm_timer *)timer)->b, ctx->stream));
+    return MM_OK;
+}
+int mm_timer_elapsed_ms(mm_ctx *ctx, void *timer, float *ms_out) {
+    if (!ctx || !timer || !ms_out) return MM_ERR_ARG;
+    mm_timer *t = (mm_timer *)timer;
+    MM_HIP(ctx, hipEventSynchronize(t->b));
+    MM_HIP(ctx, hipEventElapsedTime(ms_out, t->a, t->b));
+    return MM_OK;
+}
+void mm_timer_destroy(mm_ctx *ctx, void *timer) {
+    (void)ctx;
+    if (!timer) return;
+    mm_timer *t = (mm_timer *)timer;
+    (void)hipEventDestroy(t->a);
+    (void)hipEventDestroy(t->b);
+    delete t;
+}
+
+}  // extern "C"

@@ -1,0 +1,612 @@
+// ORB detect + describe for batches of grey frames (gfx950).  Integer-exact definition: DESIGN.md §"mm-ORB".
+//
+// Replaces orb.detectAndCompute(img, None) (reference processor.py:129,328; cv2.ORB_create(nfeatures) defaults,
+// processor.py:308): 8-level x1.2 pyramid, FAST-9/16 (t=20) + strict 3x3 NMS, 31-px border, per level keep 2n by FAST
+// score then n by Harris (7x7, k=0.04), intensity-centroid orientation (radius 15), 7x7 sigma=2 blur, 256 steered
+// intensity comparisons.  OpenCV itself is absent offline, so its two implementation-defined points are fixed here:
+// selection order is (response desc, y asc, x asc) instead of std::nth_element's, and the rBRIEF pair table is a
+// seeded table supplied by the caller (OpenCV's learned bit_pattern_31_ cannot be regenerated).
+//
+// Kernels (all batched over frames; image-sized passes are HBM/L2-bound streaming stencils):
+//   orb_tables      resize coordinate/weight tables (11-bit fixed point)
+//   orb_resize      level l-1 -> l, bilinear, 4 pixels / thread
+//   orb_fast        LDS tile (72x24 px) -> FAST score tile (66x18) -> NMS -> candidate keys + score histogram
+//   orb_select      exact radix select of the 2n smallest 32-bit keys (255-score | y | x) per (frame, level)
+//   orb_harris      compaction of the selected candidates + exact integer Harris measure 25(ab-c^2)-(a+b)^2
+//   orb_rank        rank by (Harris desc, y, x) (counting rank, O(m^2), m <= 2n), keep n, scatter in order
+//   orb_describe    one wave per keypoint: 39x39 patch -> LDS, moments, separable integer blur, 256 tests
+#include "mm_common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int MAXL = 8;
+constexpr int HALF_PATCH = 15;
+constexpr int EDGE = 31;
+
+struct OrbGeom {
+    int nlevels, batch, H, W, stride0;
+    int w[MAXL], h[MAXL], pitch[MAXL];
+    int nfeat[MAXL];
+    float scale[MAXL];
+    size_t pyr_off[MAXL];    // byte offset of level l (l>=1) for frame 0 inside the workspace
+    size_t pyr_bytes[MAXL];  // bytes per frame of level l
+    int tile_start[MAXL + 1];  // FAST tiles: cumulative count per level
+    int tiles_x[MAXL];
+    int cand_cap[MAXL];
+    size_t cand_off[MAXL];  // byte offset of the candidate key array of level l, frame 0
+    size_t tab_off[MAXL];   // resize tables of level l: x0[w], wx[w], y0[h], wy[h] (int32)
+    int kcap;               // kept capacity per segment (>= 2 * nfeat[0])
+    size_t cnt_off, hist_off, thr_off, kcnt_off, kkey_off, kh_off;
+    int cap_out;  // nfeatures
+};
+
+__device__ __forceinline__ const uint8_t *level_ptr(const OrbGeom &g, const uint8_t *imgs, const uint8_t *ws, int l,
+                                                    int b, int &pitch) {
+    if (l == 0) {
+        pitch = g.stride0;
+        return imgs + (size_t)b * g.H * g.stride0;
+    }
+    pitch = g.pitch[l];
+    return ws + g.pyr_off[l] + (size_t)b * g.pyr_bytes[l];
+}
+
+// ---- resize tables ------------------------------------------------------------------------------------------------------
+__global__ void orb_tables_kernel(OrbGeom g, uint8_t *ws) {
+    const int l = blockIdx.x + 1;
+    if (l >= g.nlevels) return;
+    int32_t *tab = reinterpret_cast<int32_t *>(ws + g.tab_off[l]);
+    const int wd = g.w[l], hd = g.h[l], wsrc = g.w[l - 1], hsrc = g.h[l - 1];
+    for (int i = threadIdx.x; i < wd + hd; i += blockDim.x) {
+        const bool isx = i < wd;
+        const long long d = isx ? i : i - wd;
+        const long long nd = isx ? wd : hd, ns = isx ? wsrc : hsrc;
+        long long num = (2 * d + 1) * ns - nd;  // (d + 0.5) * ns/nd - 0.5, times 2 nd
+        if (num < 0) num = 0;
+        long long i0 = num / (2 * nd);
+        long long rem = num - i0 * 2 * nd;
+        long long wgt = (rem * 2048 + nd) / (2 * nd);
+        if (i0 >= ns - 1) {
+            i0 = ns - 1;
+            wgt = 0;
+        }
+        if (isx) {
+            tab[d] = (int32_t)i0;
+            tab[wd + d] = (int32_t)wgt;
+        } else {
+            tab[2 * wd + d] = (int32_t)i0;
+            tab[2 * wd + hd + d] = (int32_t)wgt;
+        }
+    }
+}
+
+// ---- pyramid level l-1 -> l ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void orb_resize_kernel(OrbGeom g, const uint8_t *__restrict__ imgs,
+                                                         uint8_t *__restrict__ ws, int l) {
+    const int b = blockIdx.z;
+    const int xq = blockIdx.x * 64 + (threadIdx.x & 63);  // group of 4 output pixels
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int wd = g.w[l], hd = g.h[l], pd = g.pitch[l];
+    if (y >= hd || xq * 4 >= pd) return;
+    int ps;
+    const uint8_t *src = level_ptr(g, imgs, ws, l - 1, b, ps);
+    uint8_t *dst = ws + g.pyr_off[l] + (size_t)b * g.pyr_bytes[l];
+    const int32_t *tab = reinterpret_cast<const int32_t *>(ws + g.tab_off[l]);
+    const int ws_ = g.w[l - 1], hs_ = g.h[l - 1];
+    const int y0 = tab[2 * wd + y], wy = tab[2 * wd + hd + y];
+    const int y1 = min(y0 + 1, hs_ - 1);
+    const uint8_t *r0 = src + (size_t)y0 * ps, *r1 = src + (size_t)y1 * ps;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int x = xq * 4 + k;
+        uint32_t v = 0;
+        if (x < wd) {
+            const int x0 = tab[x], wx = tab[wd + x];
+            const int x1 = min(x0 + 1, ws_ - 1);
+            const int top = r0[x0] * (2048 - wx) + r0[x1] * wx;
+            const int bot = r1[x0] * (2048 - wx) + r1[x1] * wx;
+            v = (uint32_t)(top * (2048 - wy) + bot * wy + (1 << 21)) >> 22;
+        }
+        packed |= v << (8 * k);
+    }
+    *reinterpret_cast<uint32_t *>(dst + (size_t)y * pd + xq * 4) = packed;
+}
+
+// ---- FAST-9/16 + NMS ----------------------------------------------------------------------------------------------------
+constexpr int FT_W = 64, FT_H = 16;        // keypoint tile
+constexpr int FP_W = 80, FP_H = FT_H + 8;  // pixel tile in LDS (80 = 72 needed + alignment slack)
+constexpr int FS_W = FT_W + 2, FS_H = FT_H + 2;
+
+__device__ __forceinline__ int fast_score(const uint8_t (*P)[FP_W], int r, int c, int t) {
+    const int p = P[r][c];
+    int v[16];
+    v[0] = P[r + 3][c];      v[1] = P[r + 3][c + 1];  v[2] = P[r + 2][c + 2];  v[3] = P[r + 1][c + 3];
+    v[4] = P[r][c + 3];      v[5] = P[r - 1][c + 3];  v[6] = P[r - 2][c + 2];  v[7] = P[r - 3][c + 1];
+    v[8] = P[r - 3][c];      v[9] = P[r - 3][c - 1];  v[10] = P[r - 2][c - 2]; v[11] = P[r - 1][c - 3];
+    v[12] = P[r][c - 3];     v[13] = P[r + 1][c - 3]; v[14] = P[r + 2][c - 2]; v[15] = P[r + 3][c - 1];
+    uint32_t mb = 0, md = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        mb |= (uint32_t)(v[i] > p + t) << i;
+        md |= (uint32_t)(v[i] < p - t) << i;
+    }
+    auto has9 = [](uint32_t m) {
+        m |= m << 16;
+        uint32_t x = m & (m >> 1);
+        x &= x >> 2;
+        x &= x >> 4;
+        x &= m >> 8;
+        return (x & 0xFFFFu) != 0;
+    };
+    const bool cb = has9(mb), cd = has9(md);
+    if (!cb && !cd) return 0;
+    int best = 0;
+#pragma unroll
+    for (int pol = 0; pol < 2; ++pol) {
+        if (pol == 0 ? !cb : !cd) continue;
+        int d[16], m1[16], m2[16], m4[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) d[i] = pol == 0 ? v[i] - p : p - v[i];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) m1[i] = min(d[i], d[(i + 1) & 15]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) m2[i] = min(m1[i], m1[(i + 2) & 15]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) m4[i] = min(m2[i], m2[(i + 4) & 15]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) best = max(best, min(m4[i], d[(i + 8) & 15]));
+    }
+    return best - 1;  // largest threshold for which the pixel is still a corner (>= t)
+}
+
+__global__ __launch_bounds__(256) void orb_fast_kernel(OrbGeom g, const uint8_t *__restrict__ imgs,
+                                                       uint8_t *__restrict__ ws, int fast_t) {
+    __shared__ __attribute__((aligned(16))) uint8_t P[FP_H][FP_W];
+    __shared__ uint8_t Sc[FS_H][FS_W + 2];
+    const int b = blockIdx.y;
+    int l = 0;
+    while (l + 1 < g.nlevels && (int)blockIdx.x >= g.tile_start[l + 1]) ++l;
+    const int tl = blockIdx.x - g.tile_start[l];
+    const int tx = tl % g.tiles_x[l], ty = tl / g.tiles_x[l];
+    const int ox = EDGE + tx * FT_W, oy = EDGE + ty * FT_H;
+    const int w = g.w[l], h = g.h[l];
+    int pitch;
+    const uint8_t *img = level_ptr(g, imgs, ws, l, b, pitch);
+    // pixel tile: rows oy-4 .. oy+19, columns ox-7 .. ox+72 (ox-7 is a multiple of 4)
+    const int bx = ox - 7, by = oy - 4;
+    for (int e = threadIdx.x; e < FP_H * (FP_W / 4); e += 256) {
+        const int r = e / (FP_W / 4), c4 = (e % (FP_W / 4)) * 4;
+        const int y = by + r, x = bx + c4;
+        uint32_t v = 0;
+        if (y < h && x + 3 < pitch) v = *reinterpret_cast<const uint32_t *>(img + (size_t)y * pitch + x);
+        *reinterpret_cast<uint32_t *>(&P[r][c4]) = v;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < FS_H * FS_W; e += 256) {
+        const int sr = e / FS_W, sc = e % FS_W;
+        // score position: image (ox-1+sc, oy-1+sr) -> P[r = sr+3][c = sc+6]
+        const int x = ox - 1 + sc, y = oy - 1 + sr;
+        int s = 0;
+        if (x < w - 3 && y < h - 3) s = fast_score(P, sr + 3, sc + 6, fast_t);
+        Sc[sr][sc] = (uint8_t)s;
+    }
+    __syncthreads();
+    const int seg = b * g.nlevels + l;
+    int32_t *cnt = reinterpret_cast<int32_t *>(ws + g.cnt_off) + seg;
+    int32_t *hist = reinterpret_cast<int32_t *>(ws + g.hist_off) + (size_t)seg * 256;
+    uint32_t *cand = reinterpret_cast<uint32_t *>(ws + g.cand_off[l]) + (size_t)b * g.cand_cap[l];
+    for (int e = threadIdx.x; e < FT_H * FT_W; e += 256) {
+        const int r = e / FT_W, c = e % FT_W;
+        const int x = ox + c, y = oy + r;
+        if (x >= w - EDGE || y >= h - EDGE) continue;
+        const int s = Sc[r + 1][c + 1];
+        if (s == 0) continue;
+        const bool keep = s > Sc[r][c] && s > Sc[r][c + 1] && s > Sc[r][c + 2] && s > Sc[r + 1][c] &&
+                          s > Sc[r + 1][c + 2] && s > Sc[r + 2][c] && s > Sc[r + 2][c + 1] && s > Sc[r + 2][c + 2];
+        if (!keep) continue;
+        const int slot = atomicAdd(cnt, 1);
+        if (slot < g.cand_cap[l]) cand[slot] = ((uint32_t)(255 - s) << 24) | ((uint32_t)y << 12) | (uint32_t)x;
+        atomicAdd(&hist[255 - s], 1);
+    }
+}
+
+// ---- exact selection of the 2n smallest keys per (frame, level) ----------------------------------------------------------
+__global__ __launch_bounds__(256) void orb_select_kernel(OrbGeom g, uint8_t *__restrict__ ws) {
+    __shared__ int hist[256];
+    __shared__ uint32_t s_prefix;
+    __shared__ int s_k;
+    const int seg = blockIdx.x;
+    const int b = seg / g.nlevels, l = seg % g.nlevels;
+    const int C = min(reinterpret_cast<int32_t *>(ws + g.cnt_off)[seg], g.cand_cap[l]);
+    uint32_t *thr = reinterpret_cast<uint32_t *>(ws + g.thr_off) + seg;
+    const int k = 2 * g.nfeat[l];
+    if (C <= k) {
+        if (threadIdx.x == 0) *thr = (k == 0) ? 0u : 0xFFFFFFFFu;
+        return;
+    }
+    const uint32_t *cand = reinterpret_cast<const uint32_t *>(ws + g.cand_off[l]) + (size_t)b * g.cand_cap[l];
+    const int32_t *hist0 = reinterpret_cast<const int32_t *>(ws + g.hist_off) + (size_t)seg * 256;
+    hist[threadIdx.x] = hist0[threadIdx.x];
+    if (threadIdx.x == 0) {
+        s_prefix = 0;
+        s_k = k;
+    }
+    __syncthreads();
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (pass > 0) {
+            hist[threadIdx.x] = 0;
+            __syncthreads();
+            const uint32_t pre = s_prefix;
+            for (int i = threadIdx.x; i < C; i += 256) {
+                const uint32_t key = cand[i];
+                if ((key >> (shift + 8)) == pre) atomicAdd(&hist[(key >> shift) & 255], 1);
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            int kk = s_k, d = 0, cum = 0;
+            for (; d < 256; ++d) {
+                if (cum + hist[d] >= kk) break;
+                cum += hist[d];
+            }
+            s_k = kk - cum;
+            s_prefix = (s_prefix << 8) | (uint32_t)d;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *thr = s_prefix;  // the k-th smallest key; keys are unique
+}
+
+// ---- compaction + Harris ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ long long harris25(const uint8_t *img, int pitch, int x, int y) {
+    long long a = 0, bb = 0, c = 0;
+    for (int dy = -3; dy <= 3; ++dy) {
+        const uint8_t *rm = img + (size_t)(y + dy - 1) * pitch + x;
+        const uint8_t *r0 = rm + pitch, *rp = r0 + pitch;
+        for (int dx = -3; dx <= 3; ++dx) {
+            const int ix = 2 * ((int)r0[dx + 1] - (int)r0[dx - 1]) + ((int)rm[dx + 1] - (int)rm[dx - 1]) +
+                           ((int)rp[dx + 1] - (int)rp[dx - 1]);
+            const int iy = 2 * ((int)rp[dx] - (int)rm[dx]) + ((int)rp[dx - 1] - (int)rm[dx - 1]) +
+                           ((int)rp[dx + 1] - (int)rm[dx + 1]);
+            a += ix * ix;
+            bb += iy * iy;
+            c += ix * iy;
+        }
+    }
+    return 25 * (a * bb - c * c) - (a + bb) * (a + bb);
+}
+
+__global__ __launch_bounds__(256) void orb_harris_kernel(OrbGeom g, const uint8_t *__restrict__ imgs,
+                                                         uint8_t *__restrict__ ws) {
+    const int seg = blockIdx.y;
+    const int b = seg / g.nlevels, l = seg % g.nlevels;
+    const int C = min(reinterpret_cast<int32_t *>(ws + g.cnt_off)[seg], g.cand_cap[l]);
+    const uint32_t thr = reinterpret_cast<uint32_t *>(ws + g.thr_off)[seg];
+    const uint32_t *cand = reinterpret_cast<const uint32_t *>(ws + g.cand_off[l]) + (size_t)b * g.cand_cap[l];
+    int32_t *kcnt = reinterpret_cast<int32_t *>(ws + g.kcnt_off) + seg;
+    uint32_t *kkey = reinterpret_cast<uint32_t *>(ws + g.kkey_off) + (size_t)seg * g.kcap;
+    long long *kh = reinterpret_cast<long long *>(ws + g.kh_off) + (size_t)seg * g.kcap;
+    int pitch;
+    const uint8_t *img = level_ptr(g, imgs, ws, l, b, pitch);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < C; i += gridDim.x * 256) {
+        const uint32_t key = cand[i];
+        if (key > thr || g.nfeat[l] == 0) continue;
+        const int x = key & 0xFFF, y = (key >> 12) & 0xFFF;
+        const long long hv = harris25(img, pitch, x, y);
+        const int slot = atomicAdd(kcnt, 1);
+        if (slot < g.kcap) {
+            kkey[slot] = key;
+            kh[slot] = hv;
+        }
+    }
+}
+
+// ---- rank by (Harris desc, y asc, x asc), keep n, write keypoints in order ------------------------------------------------
+__global__ __launch_bounds__(256) void orb_rank_kernel(OrbGeom g, uint8_t *__restrict__ ws, float *__restrict__ kp_xy,
+                                                       int32_t *__restrict__ kp_meta, float *__restrict__ kp_resp,
+                                                       int32_t *__restrict__ n_out) {
+    __shared__ long long sh[256];
+    __shared__ uint32_t sp[256];
+    const int seg = blockIdx.y;
+    const int b = seg / g.nlevels, l = seg % g.nlevels;
+    const int32_t *kcnt = reinterpret_cast<const int32_t *>(ws + g.kcnt_off) + (size_t)b * g.nlevels;
+    const int m = min(kcnt[l], g.kcap);
+    int base = 0, total = 0;
+    for (int q = 0; q < g.nlevels; ++q) {
+        const int mq = min(min(kcnt[q], g.kcap), g.nfeat[q]);
+        if (q < l) base += mq;
+        total += mq;
+    }
+    if (l == 0 && blockIdx.x == 0 && threadIdx.x == 0) n_out[b] = total;
+    if ((int)blockIdx.x * 256 >= m) return;
+    const uint32_t *kkey = reinterpret_cast<const uint32_t *>(ws + g.kkey_off) + (size_t)seg * g.kcap;
+    const long long *kh = reinterpret_cast<const long long *>(ws + g.kh_off) + (size_t)seg * g.kcap;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    long long hi = 0;
+    uint32_t pi = 0;
+    if (i < m) {
+        hi = kh[i];
+        pi = kkey[i] & 0xFFFFFFu;
+    }
+    int rank = 0;
+    for (int j0 = 0; j0 < m; j0 += 256) {
+        __syncthreads();
+        if (j0 + (int)threadIdx.x < m) {
+            sh[threadIdx.x] = kh[j0 + threadIdx.x];
+            sp[threadIdx.x] = kkey[j0 + threadIdx.x] & 0xFFFFFFu;
+        }
+        __syncthreads();
+        const int nj = min(256, m - j0);
+        for (int j = 0; j < nj; ++j) rank += (sh[j] > hi) || (sh[j] == hi && sp[j] < pi);
+    }
+    if (i < m && rank < g.nfeat[l]) {
+        const size_t o = (size_t)b * g.cap_out + base + rank;
+        const int x = pi & 0xFFF, y = pi >> 12;
+        kp_xy[o * 2] = (float)x * g.scale[l];
+        kp_xy[o * 2 + 1] = (float)y * g.scale[l];
+        kp_meta[o * 4] = l;
+        kp_meta[o * 4 + 1] = x;
+        kp_meta[o * 4 + 2] = y;
+        kp_meta[o * 4 + 3] = (int32_t)(hi & 0xFFFFFFFFll);
+        // cv2 response = (ab - c^2 - 0.04 (a+b)^2) * (1/(4*7*255))^4 ; `hi` is exactly 25x the bracket
+        kp_resp[o] = (float)hi * (float)(1.0 / (25.0 * 7140.0 * 7140.0 * 7140.0 * 7140.0));
+    }
+}
+
+// ---- orientation + descriptor ----------------------------------------------------------------------------------------------
+__constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+__constant__ int c_gw[7] = {18, 33, 49, 56, 49, 33, 18};  // 7-tap sigma=2 Gaussian, 8-bit fixed point, sum 256
+
+constexpr int DP = 39;  // raw patch side (31 + 2*(1 rotation slack) + 2*3 blur) -> offsets -19..19
+constexpr int DB = 33;  // blurred patch side, offsets -16..16
+constexpr int DESC_WAVES = 4;
+
+__global__ __launch_bounds__(64 * DESC_WAVES) void orb_describe_kernel(OrbGeom g, const uint8_t *__restrict__ imgs,
+                                                                       const uint8_t *__restrict__ ws,
+                                                                       const int8_t *__restrict__ pattern,
+                                                                       const int32_t *__restrict__ kp_meta,
+                                                                       const int32_t *__restrict__ n_out,
+                                                                       int32_t *__restrict__ kp_mom,
+                                                                       uint8_t *__restrict__ desc) {
+    __shared__ uint8_t raw[DESC_WAVES][DP][DP + 1];
+    __shared__ uint16_t hb[DESC_WAVES][DP][DB + 1];
+    __shared__ uint8_t bl[DESC_WAVES][DB][DB + 3];
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int kp = blockIdx.x * DESC_WAVES + wv;
+    if (kp >= n_out[b]) return;  // wave-uniform; no workgroup barriers below
+    const size_t o = (size_t)b * g.cap_out + kp;
+    const int l = kp_meta[o * 4], x = kp_meta[o * 4 + 1], y = kp_meta[o * 4 + 2];
+    int pitch;
+    const uint8_t *img = level_ptr(g, imgs, ws, l, b, pitch);
+    for (int e = lane; e < DP * DP; e += 64) {
+        const int r = e / DP, c = e % DP;
+        raw[wv][r][c] = img[(size_t)(y - 19 + r) * pitch + (x - 19 + c)];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // intensity-centroid moments over the radius-15 disc (rows v = -15..15 over lanes 0..30)
+    int m10 = 0, m01 = 0;
+    if (lane < 31) {
+        const int v = lane - 15;
+        const int um = c_umax[v < 0 ? -v : v];
+        int rs = 0;
+        for (int u = -um; u <= um; ++u) {
+            const int val = raw[wv][19 + v][19 + u];
+            m10 += u * val;
+            rs += val;
+        }
+        m01 = v * rs;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        m10 += __shfl_xor(m10, off, 64);
+        m01 += __shfl_xor(m01, off, 64);
+    }
+    if (lane == 0) {
+        kp_mom[o * 2] = m10;
+        kp_mom[o * 2 + 1] = m01;
+    }
+    // horizontal blur: rows 0..38 (offset -19..19), cols -16..16
+    for (int e = lane; e < DP * DB; e += 64) {
+        const int r = e / DB, c = e % DB;  // output col offset = c - 16 -> raw col index c + 3
+        int s = 0;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) s += c_gw[k] * raw[wv][r][c + k];
+        hb[wv][r][c] = (uint16_t)s;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int e = lane; e < DB * DB; e += 64) {
+        const int r = e / DB, c = e % DB;
+        int s = 0;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) s += c_gw[k] * hb[wv][r + k][c];
+        bl[wv][r][c] = (uint8_t)((s + 32768) >> 16);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // steering: cos = m10 / |m|, sin = m01 / |m| in IEEE f64 (no trig), offsets rounded half-to-even.
+    // No FMA contraction here: the CPU oracle must reproduce every rounding (file is built with -ffp-contract=off).
+    double cs = 1.0, sn = 0.0;
+    {
+        const long long q = (long long)m10 * m10 + (long long)m01 * m01;
+        if (q > 0) {
+            const double rr = __dsqrt_rn((double)q);
+            cs = __ddiv_rn((double)m10, rr);
+            sn = __ddiv_rn((double)m01, rr);
+        }
+    }
+    // lane computes 4 bits: pairs 4*lane .. 4*lane+3
+    uint32_t nib = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int bit = lane * 4 + k;
+        const int8_t *pp = pattern + bit * 4;
+        int val[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const double px = (double)pp[2 * e], py = (double)pp[2 * e + 1];
+            const double fx = __dsub_rn(__dmul_rn(px, cs), __dmul_rn(py, sn));
+            const double fy = __dadd_rn(__dmul_rn(px, sn), __dmul_rn(py, cs));
+            const int ix = (int)rint(fx), iy = (int)rint(fy);
+            val[e] = bl[wv][16 + iy][16 + ix];
+        }
+        nib |= (uint32_t)(val[0] < val[1]) << k;
+    }
+    // two lanes per byte: low nibble from the even lane
+    const uint32_t other = __shfl_xor(nib, 1, 64);
+    if ((lane & 1) == 0) desc[o * 32 + (lane >> 1)] = (uint8_t)(nib | (other << 4));
+}
+
+// ---- host side geometry ---------------------------------------------------------------------------------------------------
+int cv_round(double v) { return (int)__builtin_rint(v); }
+
+int build_geom(int batch, int H, int W, int stride, const mm_orb_params *prm, OrbGeom &g, size_t &total) {
+    if (!prm || prm->nlevels < 1 || prm->nlevels > MAXL || prm->nfeatures < 0 || H <= 0 || W <= 0 || batch <= 0)
+        return MM_ERR_ARG;
+    if (H >= 4096 || W >= 4096) return MM_ERR_ARG;  // 12-bit coordinates in the candidate key
+    if (prm->edge_threshold != EDGE) return MM_ERR_ARG;
+    memset(&g, 0, sizeof(g));
+    g.nlevels = prm->nlevels;
+    g.batch = batch;
+    g.H = H;
+    g.W = W;
+    g.stride0 = stride;
+    g.cap_out = prm->nfeatures;
+    // OpenCV orb.cpp: scale_l = (float)pow(scaleFactor, l); size = cvRound(dim / scale_l)
+    const float factor = (float)(1.0 / (double)prm->scale_factor);
+    float ndes = (float)prm->nfeatures * (1.0f - factor) /
+                 (1.0f - (float)__builtin_pow((double)factor, (double)prm->nlevels));
+    int sum = 0;
+    for (int l = 0; l < g.nlevels; ++l) {
+        const float sc = (float)__builtin_pow((double)prm->scale_factor, (double)l);
+        g.scale[l] = sc;
+        g.w[l] = l == 0 ? W : cv_round((double)((float)W / sc));
+        g.h[l] = l == 0 ? H : cv_round((double)((float)H / sc));
+        g.pitch[l] = l == 0 ? stride : (int)mm_align_up((size_t)g.w[l], 64);
+        if (l < g.nlevels - 1) {
+            g.nfeat[l] = cv_round((double)ndes);
+            sum += g.nfeat[l];
+            ndes *= factor;
+        } else {
+            g.nfeat[l] = prm->nfeatures - sum > 0 ? prm->nfeatures - sum : 0;
+        }
+    }
+    size_t off = 0;
+    for (int l = 1; l < g.nlevels; ++l) {
+        g.pyr_off[l] = off;
+        g.pyr_bytes[l] = mm_align_up((size_t)g.pitch[l] * g.h[l] + 64, 256);
+        off += g.pyr_bytes[l] * batch;
+    }
+    g.tile_start[0] = 0;
+    for (int l = 0; l < g.nlevels; ++l) {
+        const int vw = g.w[l] - 2 * EDGE, vh = g.h[l] - 2 * EDGE;
+        int tx = 0, ty = 0;
+        if (vw > 0 && vh > 0) {
+            tx = (vw + FT_W - 1) / FT_W;
+            ty = (vh + FT_H - 1) / FT_H;
+        }
+        g.tiles_x[l] = tx > 0 ? tx : 1;
+        g.tile_start[l + 1] = g.tile_start[l] + tx * ty;
+        g.cand_cap[l] = (vw > 0 && vh > 0) ? (int)(((size_t)vw * vh + 3) / 4 + 64) : 64;
+        g.cand_off[l] = off;
+        off += mm_align_up((size_t)g.cand_cap[l] * 4, 256) * batch;
+        // per-frame stride of the candidate array must equal cand_cap entries: keep arrays dense per frame
+    }
+    for (int l = 1; l < g.nlevels; ++l) {
+        g.tab_off[l] = off;
+        off += mm_align_up((size_t)(2 * g.w[l] + 2 * g.h[l]) * 4, 256);
+    }
+    int nmax = 0;
+    for (int l = 0; l < g.nlevels; ++l) nmax = g.nfeat[l] > nmax ? g.nfeat[l] : nmax;
+    g.kcap = 2 * nmax + 8;
+    const size_t segs = (size_t)batch * g.nlevels;
+    g.cnt_off = off;
+    off += mm_align_up(segs * 4, 256);
+    g.kcnt_off = off;
+    off += mm_align_up(segs * 4, 256);
+    g.hist_off = off;
+    off += mm_align_up(segs * 256 * 4, 256);
+    g.thr_off = off;
+    off += mm_align_up(segs * 4, 256);
+    g.kkey_off = off;
+    off += mm_align_up(segs * g.kcap * 4, 256);
+    g.kh_off = off;
+    off += mm_align_up(segs * g.kcap * 8, 256);
+    total = off;
+    return MM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mm_orb_level_sizes(int height, int width, const mm_orb_params *prm, int32_t *lvl_w, int32_t *lvl_h, int32_t *lvl_n,
+                       float *lvl_scale) {
+    OrbGeom g;
+    size_t total;
+    int rc = build_geom(1, height, width, width, prm, g, total);
+    if (rc) return rc;
+    for (int l = 0; l < g.nlevels; ++l) {
+        if (lvl_w) lvl_w[l] = g.w[l];
+        if (lvl_h) lvl_h[l] = g.h[l];
+        if (lvl_n) lvl_n[l] = g.nfeat[l];
+        if (lvl_scale) lvl_scale[l] = g.scale[l];
+    }
+    return MM_OK;
+}
+
+size_t mm_orb_workspace_bytes(int batch, int height, int width, const mm_orb_params *prm) {
+    OrbGeom g;
+    size_t total = 0;
+    if (build_geom(batch, height, width, width, prm, g, total)) return 0;
+    return total;
+}
+
+int mm_orb_detect_compute(mm_ctx *ctx, const uint8_t *imgs, int batch, int height, int width, int stride,
+                          const mm_orb_params *prm, const int8_t *pattern, void *ws, size_t ws_bytes, float *kp_xy,
+                          int32_t *kp_meta, float *kp_resp, int32_t *kp_mom, uint8_t *desc, int32_t *n_out) {
+    if (!ctx) return MM_ERR_ARG;
+    if (batch == 0) return MM_OK;
+    OrbGeom g;
+    size_t total = 0;
+    if (build_geom(batch, height, width, stride, prm, g, total))
+        return mm_fail(ctx, MM_ERR_ARG, "mm_orb_detect_compute: bad geometry / parameters");
+    if (!imgs || !pattern || !ws || !kp_xy || !kp_meta || !kp_resp || !kp_mom || !desc || !n_out)
+        return mm_fail(ctx, MM_ERR_ARG, "mm_orb_detect_compute: null pointer");
+    if (stride < width || (stride & 3) || ((uintptr_t)imgs & 3) || ((uintptr_t)ws & 255))
+        return mm_fail(ctx, MM_ERR_ARG, "mm_orb_detect_compute: stride must be a multiple of 4 >= width, imgs 4-byte and ws 256-byte aligned");
+    if (ws_bytes < total) return mm_fail(ctx, MM_ERR_WORKSPACE, "mm_orb_detect_compute: workspace %zu < %zu", ws_bytes, total);
+    if (batch > 65535) return mm_fail(ctx, MM_ERR_ARG, "mm_orb_detect_compute: batch > 65535");
+    uint8_t *w8 = (uint8_t *)ws;
+    hipStream_t st = ctx->stream;
+    // counters, kept counters and histograms are contiguous: [cnt_off, thr_off)
+    MM_HIP(ctx, hipMemsetAsync(w8 + g.cnt_off, 0, g.thr_off - g.cnt_off, st));
+    if (g.nlevels > 1) {
+        MM_LAUNCH(ctx, "orb_tables_kernel", orb_tables_kernel, dim3(g.nlevels - 1), dim3(256), 0, g, w8);
+        for (int l = 1; l < g.nlevels; ++l) {
+            dim3 grid((g.pitch[l] / 4 + 63) / 64, (g.h[l] + 3) / 4, batch);
+            MM_LAUNCH(ctx, "orb_resize_kernel", orb_resize_kernel, grid, dim3(256), 0, g, imgs, w8, l);
+        }
+    }
+    if (g.tile_start[g.nlevels] > 0) {
+        MM_LAUNCH(ctx, "orb_fast_kernel", orb_fast_kernel, dim3(g.tile_start[g.nlevels], batch), dim3(256), 0, g, imgs, w8, prm->fast_threshold);
+    }
+    const int segs = batch * g.nlevels;
+    MM_LAUNCH(ctx, "orb_select_kernel", orb_select_kernel, dim3(segs), dim3(256), 0, g, w8);
+    MM_LAUNCH(ctx, "orb_harris_kernel", orb_harris_kernel, dim3(32, segs), dim3(256), 0, g, imgs, w8);
+    MM_LAUNCH(ctx, "orb_rank_kernel", orb_rank_kernel, dim3((g.kcap + 255) / 256, segs), dim3(256), 0, g, w8, kp_xy, kp_meta, kp_resp, n_out);
+    if (g.cap_out > 0) {
+        MM_LAUNCH(ctx, "orb_describe_kernel", orb_describe_kernel, dim3((g.cap_out + DESC_WAVES - 1) / DESC_WAVES, batch), dim3(64 * DESC_WAVES), 0, g, imgs, (const uint8_t *)w8, pattern, (const int32_t *)kp_meta, (const int32_t *)n_out, kp_mom, desc);
+    }
+    return MM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,239 @@
+"""Thin tensor-level wrappers over the C ABI (include/meatmodeler.h).
+
+torch is used for device memory and streams only; every computation below is a HIP kernel launched through
+`libmeatmodeler_hip.so`.  All functions take/return torch tensors on the context's device.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, ptr, vp, OrbParams, BAProblem, default_context
+
+
+def _i32(t):
+    assert t.dtype == torch.int32 and t.is_contiguous()
+    return t
+
+
+# ------------------------------------------------------------------------------------------------ matching
+
+def bf_knn2_batched(q, t, nq=None, nt=None, ctx=None):
+    """q [n_pairs, nq_cap, 32] u8, t [n_pairs, nt_cap, 32] u8 (may be strided views over a descriptor table
+    as long as rows are contiguous); nq / nt optional int32 [n_pairs] valid counts.
+    Returns idx, dist int32 [n_pairs, nq_cap, 2]."""
+    ctx = ctx or default_context()
+    assert q.dtype == torch.uint8 and t.dtype == torch.uint8 and q.shape[-1] == 32 and t.shape[-1] == 32
+    assert q.stride(-1) == 1 and q.stride(-2) == 32 and t.stride(-1) == 1 and t.stride(-2) == 32
+    n_pairs, nq_cap, nt_cap = q.shape[0], q.shape[1], t.shape[1]
+    assert t.shape[0] == n_pairs
+    idx = torch.full((n_pairs, nq_cap, 2), -1, dtype=torch.int32, device=q.device)
+    dist = torch.full((n_pairs, nq_cap, 2), -1, dtype=torch.int32, device=q.device)
+    if n_pairs == 0 or nq_cap == 0:
+        return idx, dist
+    wsb = lib.mm_bf_workspace_bytes(n_pairs, nq_cap, nt_cap)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=q.device)
+    qs = q.stride(0) if n_pairs > 1 else 0
+    ts = t.stride(0) if n_pairs > 1 else 0
+    ctx.check(lib.mm_bf_knn2_batched(ctx.h, ptr(q), ptr(nq), nq_cap, qs, ptr(t), ptr(nt), nt_cap, ts, n_pairs,
+                                     ptr(idx), ptr(dist), ptr(ws), wsb), "mm_bf_knn2_batched")
+    return idx, dist
+
+
+def bf_knn2(q, t, ctx=None):
+    """Single pair: q [nq,32], t [nt,32] -> idx, dist int32 [nq,2] (mm_bf_knn2_hamming)."""
+    ctx = ctx or default_context()
+    assert q.dtype == torch.uint8 and t.dtype == torch.uint8 and q.is_contiguous() and t.is_contiguous()
+    nq, nt = q.shape[0], t.shape[0]
+    idx = torch.full((nq, 2), -1, dtype=torch.int32, device=q.device)
+    dist = torch.full((nq, 2), -1, dtype=torch.int32, device=q.device)
+    if nq == 0:
+        return idx, dist
+    wsb = lib.mm_bf_workspace_bytes(1, nq, nt)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=q.device)
+    ctx.check(lib.mm_bf_knn2_hamming(ctx.h, ptr(q), nq, ptr(t), nt, ptr(idx), ptr(dist), ptr(ws), wsb),
+              "mm_bf_knn2_hamming")
+    return idx, dist
+
+
+def ratio_filter_batched(idx, dist, threshold=0.75, nq=None, ctx=None):
+    """idx/dist [n_pairs, nq_cap, 2] -> pairs int32 [n_pairs, nq_cap, 2] (queryIdx, trainIdx), m int32 [n_pairs]."""
+    ctx = ctx or default_context()
+    n_pairs, nq_cap = idx.shape[0], idx.shape[1]
+    pairs = torch.full((n_pairs, nq_cap, 2), -1, dtype=torch.int32, device=idx.device)
+    m = torch.zeros(n_pairs, dtype=torch.int32, device=idx.device)
+    if n_pairs == 0:
+        return pairs, m
+    ctx.check(lib.mm_ratio_filter_batched(ctx.h, ptr(_i32(idx)), ptr(_i32(dist)), ptr(nq), nq_cap, n_pairs,
+                                          float(threshold), ptr(pairs), ptr(m)), "mm_ratio_filter_batched")
+    return pairs, m
+
+
+# ------------------------------------------------------------------------------------------------ ORB
+
+def orb_params(nfeatures, nlevels=8, scale_factor=1.2, edge_threshold=31, fast_threshold=20):
+    return OrbParams(int(nfeatures), int(nlevels), int(edge_threshold), int(fast_threshold), float(scale_factor), 0)
+
+
+def orb_level_sizes(H, W, prm):
+    L = prm.nlevels
+    w = (C.c_int32 * L)()
+    h = (C.c_int32 * L)()
+    n = (C.c_int32 * L)()
+    s = (C.c_float * L)()
+    rc = lib.mm_orb_level_sizes(H, W, C.byref(prm), w, h, n, s)
+    if rc != 0:
+        raise _lib.MMError(f"mm_orb_level_sizes failed ({rc})")
+    return np.array(w), np.array(h), np.array(n), np.array(s, np.float32)
+
+
+class OrbWorkspace:
+    """Reusable device workspace + output buffers for a fixed (batch, H, W, params)."""
+
+    def __init__(self, batch, H, W, prm, device, pattern):
+        self.batch, self.H, self.W, self.prm = batch, H, W, prm
+        nb = lib.mm_orb_workspace_bytes(batch, H, W, C.byref(prm))
+        if nb == 0:
+            raise _lib.MMError("mm_orb_workspace_bytes: unsupported geometry")
+        self.nbytes = nb
+        self.ws = torch.empty(nb, dtype=torch.uint8, device=device)
+        self.pattern = torch.as_tensor(np.ascontiguousarray(pattern, np.int8)).to(device)
+        cap = prm.nfeatures
+        self.xy = torch.zeros((batch, cap, 2), dtype=torch.float32, device=device)
+        self.meta = torch.zeros((batch, cap, 4), dtype=torch.int32, device=device)
+        self.resp = torch.zeros((batch, cap), dtype=torch.float32, device=device)
+        self.mom = torch.zeros((batch, cap, 2), dtype=torch.int32, device=device)
+        self.desc = torch.zeros((batch, cap, 32), dtype=torch.uint8, device=device)
+        self.n = torch.zeros(batch, dtype=torch.int32, device=device)
+
+
+def orb_detect_compute(imgs, wsp, ctx=None, out=None):
+    """imgs [B,H,W] u8 (B <= wsp.batch).  Fills (and returns) wsp.xy/meta/resp/mom/desc/n for the first B frames,
+    or the tensors in `out` = (xy, meta, resp, mom, desc, n) if given (each with leading dim >= B)."""
+    ctx = ctx or default_context()
+    assert imgs.dtype == torch.uint8 and imgs.dim() == 3 and imgs.stride(2) == 1
+    B, H, W = imgs.shape
+    assert B <= wsp.batch and H == wsp.H and W == wsp.W and imgs.stride(0) == H * imgs.stride(1)
+    xy, meta, resp, mom, desc, n = out if out is not None else (wsp.xy, wsp.meta, wsp.resp, wsp.mom, wsp.desc, wsp.n)
+    ctx.check(lib.mm_orb_detect_compute(ctx.h, ptr(imgs), B, H, W, imgs.stride(1), C.byref(wsp.prm), ptr(wsp.pattern),
+                                        ptr(wsp.ws), wsp.nbytes, ptr(xy), ptr(meta), ptr(resp), ptr(mom), ptr(desc),
+                                        ptr(n)), "mm_orb_detect_compute")
+    return xy, meta, resp, mom, desc, n
+
+
+# ------------------------------------------------------------------------------------------------ triangulation
+
+def triangulate_dlt(proj, f0, f1, x0, x1, ctx=None):
+    """proj [F,3,4] f64, f0/f1 int32 [n], x0/x1 f64 [n,2] -> X f64 [n,3]."""
+    ctx = ctx or default_context()
+    n = f0.shape[0]
+    X = torch.empty((n, 3), dtype=torch.float64, device=proj.device)
+    if n:
+        ctx.check(lib.mm_triangulate_dlt(ctx.h, ptr(proj.contiguous()), ptr(_i32(f0)), ptr(_i32(f1)),
+                                         ptr(x0.contiguous()), ptr(x1.contiguous()), n, ptr(X)), "mm_triangulate_dlt")
+    return X
+
+
+# ------------------------------------------------------------------------------------------------ bundle adjustment
+
+def ba_build_index(F, P, fi, pi):
+    """Host CSR build (mm_ba_build_index).  fi, pi: int32 numpy [O]."""
+    fi = np.ascontiguousarray(fi, np.int32)
+    pi = np.ascontiguousarray(pi, np.int32)
+    O = fi.size
+    pt_ptr = np.zeros(P + 1, np.int32)
+    cam_ptr = np.zeros(F + 1, np.int32)
+    pt_obs = np.zeros(max(O, 1), np.int32)
+    cam_obs = np.zeros(max(O, 1), np.int32)
+    i32p = _lib.c_i32p
+    rc = lib.mm_ba_build_index(F, P, O, fi.ctypes.data_as(i32p), pi.ctypes.data_as(i32p), pt_ptr.ctypes.data_as(i32p),
+                               pt_obs.ctypes.data_as(i32p), cam_ptr.ctypes.data_as(i32p), cam_obs.ctypes.data_as(i32p))
+    if rc != 0:
+        raise ValueError(f"mm_ba_build_index failed ({rc}): frame/point index out of range")
+    return pt_ptr, pt_obs[:O], cam_ptr, cam_obs[:O]
+
+
+class BADevice:
+    """Device-resident BA problem: observation arrays, CSR indices and the mm_ba_problem descriptor."""
+
+    def __init__(self, K, fi, pi, obs, F, P, device, ctx=None):
+        self.ctx = ctx or default_context()
+        self.F, self.P, self.O = int(F), int(P), int(len(fi))
+        fi = np.ascontiguousarray(fi, np.int32)
+        pi = np.ascontiguousarray(pi, np.int32)
+        pt_ptr, pt_obs, cam_ptr, cam_obs = ba_build_index(self.F, self.P, fi, pi)
+        dev = device
+        self.K = torch.as_tensor(np.ascontiguousarray(K, np.float64).reshape(9)).to(dev)
+        self.fi = torch.as_tensor(fi).to(dev)
+        self.pi = torch.as_tensor(pi).to(dev)
+        self.obs = torch.as_tensor(np.ascontiguousarray(obs, np.float64).reshape(-1, 2)).to(dev)
+        self.pt_ptr = torch.as_tensor(pt_ptr).to(dev)
+        self.pt_obs = torch.as_tensor(np.ascontiguousarray(pt_obs)).to(dev)
+        self.cam_ptr = torch.as_tensor(cam_ptr).to(dev)
+        self.cam_obs = torch.as_tensor(np.ascontiguousarray(cam_obs)).to(dev)
+        self.device = dev
+        self.pb = BAProblem(self.F, self.P, self.O, ptr(self.K), ptr(self.fi), ptr(self.pi), ptr(self.obs),
+                            ptr(self.pt_ptr), ptr(self.pt_obs), ptr(self.cam_ptr), ptr(self.cam_obs))
+        self._ws = torch.empty(2048 * 8, dtype=torch.uint8, device=dev)
+        self._cost2 = torch.zeros(1, dtype=torch.float64, device=dev)
+
+    def residual(self, cams, pts, want_res=False):
+        """-> (sum of squared residuals as a 1-element device tensor, res [O,2] or None)."""
+        res = torch.empty((self.O, 2), dtype=torch.float64, device=self.device) if want_res else None
+        cost2 = torch.empty(1, dtype=torch.float64, device=self.device)
+        self.ctx.check(lib.mm_ba_residual(self.ctx.h, C.byref(self.pb), ptr(cams), ptr(pts), ptr(res), ptr(cost2),
+                                          ptr(self._ws), self._ws.numel()), "mm_ba_residual")
+        return cost2, res
+
+    def jacobian(self, cams, pts):
+        Jc = torch.empty((self.O, 2, 6), dtype=torch.float64, device=self.device)
+        Jp = torch.empty((self.O, 2, 3), dtype=torch.float64, device=self.device)
+        self.ctx.check(lib.mm_ba_jacobian(self.ctx.h, C.byref(self.pb), ptr(cams), ptr(pts), ptr(Jc), ptr(Jp)),
+                       "mm_ba_jacobian")
+        return Jc, Jp
+
+    def normal_eq(self, cams, pts, want_cams=True, want_pts=True):
+        d = self.device
+        B = torch.empty((self.F, 6, 6), dtype=torch.float64, device=d) if want_cams else None
+        gc = torch.empty((self.F, 6), dtype=torch.float64, device=d) if want_cams else None
+        Cb = torch.empty((self.P, 6), dtype=torch.float64, device=d) if want_pts else None
+        gp = torch.empty((self.P, 3), dtype=torch.float64, device=d) if want_pts else None
+        self.ctx.check(lib.mm_ba_normal_eq(self.ctx.h, C.byref(self.pb), ptr(cams), ptr(pts), ptr(B), ptr(gc), ptr(Cb),
+                                           ptr(gp)), "mm_ba_normal_eq")
+        return B, gc, Cb, gp
+
+    def jvp(self, cams, pts, wc, wp):
+        out = torch.empty((self.O, 2), dtype=torch.float64, device=self.device)
+        self.ctx.check(lib.mm_ba_jvp(self.ctx.h, C.byref(self.pb), ptr(cams), ptr(pts), ptr(wc), ptr(wp), ptr(out)),
+                       "mm_ba_jvp")
+        return out
+
+    def schur(self, cams, pts, Bd, Cd, gc, gp):
+        n = 6 * self.F
+        S = torch.empty((n, n), dtype=torch.float64, device=self.device)
+        v = torch.empty(n, dtype=torch.float64, device=self.device)
+        Cinv = torch.empty((self.P, 6), dtype=torch.float64, device=self.device)
+        self.ctx.check(lib.mm_ba_schur(self.ctx.h, C.byref(self.pb), ptr(cams), ptr(pts), ptr(Bd), ptr(Cd), ptr(gc),
+                                       ptr(gp), ptr(S), ptr(v), ptr(Cinv)), "mm_ba_schur")
+        return S, v, Cinv
+
+    def backsub(self, cams, pts, Cinv, gp, dc):
+        dp = torch.empty((self.P, 3), dtype=torch.float64, device=self.device)
+        self.ctx.check(lib.mm_ba_backsub(self.ctx.h, C.byref(self.pb), ptr(cams), ptr(pts), ptr(Cinv), ptr(gp), ptr(dc),
+                                         ptr(dp)), "mm_ba_backsub")
+        return dp
+
+
+def chol_solve(A, b, ctx=None):
+    """In place: A [n,n] f64 SPD (lower triangle used, overwritten by L), b [n] or [nrhs,n] overwritten by x.
+    Returns the device int32 info tensor (0 = ok)."""
+    ctx = ctx or default_context()
+    n = A.shape[0]
+    assert A.dtype == torch.float64 and A.is_contiguous() and b.is_contiguous() and b.shape[-1] == n
+    nrhs = 1 if b.dim() == 1 else b.shape[0]
+    info = torch.zeros(1, dtype=torch.int32, device=A.device)
+    wsb = lib.mm_chol_workspace_bytes(n)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=A.device)
+    ctx.check(lib.mm_chol_solve(ctx.h, ptr(A), n, ptr(b), nrhs, ptr(info), ptr(ws), wsb), "mm_chol_solve")
+    return info

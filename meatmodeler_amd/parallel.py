@@ -1,0 +1,78 @@
+"""Sharding of the hot path over the GPUs of one node (one process per GPU, torch.distributed; backend "nccl" is
+RCCL on ROCm, "gloo" in the CPU tests).  SURVEY.md §8e:
+
+  * detection / matching: consecutive frame pairs are independent -> block partition of the pairs; a rank detects its
+    frame block plus one halo frame (recomputed, not exchanged); match lists (KBs) are all-gathered so every rank
+    links the same tracks;
+  * bundle adjustment: points (with all their observations) are partitioned, cameras are replicated; the only data-path
+    collective is the all-reduce(sum) of the camera-side blocks: B, g_c, the reduced camera system S, v and a few
+    scalars per trust-region iteration.
+"""
+import numpy as np
+
+
+def block_range(n, rank, world):
+    """[lo, hi) of a balanced contiguous block partition of range(n)."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def pair_block(n_frames, rank, world):
+    """Frame pairs (k, k+1) owned by `rank` and the frames it must detect (its pairs' frames incl. the halo)."""
+    p_lo, p_hi = block_range(max(n_frames - 1, 0), rank, world)
+    if p_hi <= p_lo:
+        return (p_lo, p_lo), (0, 0)
+    return (p_lo, p_hi), (p_lo, p_hi + 1)
+
+
+def partition_points(fi, pi, n_points, rank, world):
+    """Contiguous split of the points balanced by observation count.  Returns (p_lo, p_hi, obs_mask) where obs_mask
+    selects the observations of the local points (point-major input keeps them contiguous)."""
+    pi = np.asarray(pi)
+    counts = np.bincount(pi, minlength=n_points)
+    cum = np.concatenate([[0], np.cumsum(counts)])
+    total = cum[-1]
+    bounds = [int(np.searchsorted(cum, total * r / world, side="left")) for r in range(world)] + [n_points]
+    bounds[0] = 0
+    for r in range(1, world + 1):
+        bounds[r] = max(bounds[r], bounds[r - 1])
+    lo, hi = bounds[rank], bounds[rank + 1]
+    mask = (pi >= lo) & (pi < hi)
+    return lo, hi, mask
+
+
+class AllReduce:
+    """Callable all-reduce over a torch.distributed process group (in place)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.world_size = dist.get_world_size(group)
+
+    def __call__(self, tensor, op="sum"):
+        if self.world_size == 1:
+            return tensor
+        d = self.dist
+        d.all_reduce(tensor, op=d.ReduceOp.SUM if op == "sum" else d.ReduceOp.MAX, group=self.group)
+        return tensor
+
+
+def gather_varlen(local, world, dist, group=None):
+    """All-gather of variable-length int32/float arrays (numpy, host) with a size prefix.  Returns the list of
+    per-rank arrays.  Match lists are KBs, so this goes through host memory."""
+    import torch
+    backend = dist.get_backend(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    flat = np.ascontiguousarray(local).reshape(-1)
+    n = torch.tensor([flat.size], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    m = max(sizes + [1])
+    buf = torch.zeros(m, dtype=torch.from_numpy(flat[:0]).dtype, device=dev)
+    buf[:flat.size] = torch.from_numpy(flat).to(dev)
+    outs = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(outs, buf, group=group)
+    return [o[:s].cpu().numpy() for o, s in zip(outs, sizes)]

@@ -1,0 +1,207 @@
+"""Batched clip pipeline: the hot path of `processor.process` (reference processor.py:356-470) run over a whole
+clip with device-resident state — detect all frames, match all consecutive pairs, link tracks, triangulate, bundle
+adjust.  Same stages and semantics as the per-keyframe drop-in functions in `processor.py`, but frames, descriptors
+and key points stay in HBM and each stage is a few large launches instead of one small launch per keyframe.
+
+Keyframe gating, calibration and PnP are outside the scope: the caller provides K and one extrinsic
+per frame (the reference gets them from calibrate / poseEstimation / adjustPose, processor.py:422-448).
+"""
+import ctypes as C
+import time
+
+import numpy as np
+import torch
+
+from . import ops, parallel
+from ._lib import lib, default_context, c_i32p, c_i64p, c_f32p, MMError
+from .bundleAdjuster import SchurTRF, frameParameters
+from .orb_pattern import brief_pattern
+
+
+class ClipPipeline:
+    def __init__(self, height, width, nfeatures, batch=32, ratio=0.75, device=None, ctx=None, nlevels=8):
+        self.ctx = ctx or default_context()
+        self.device = device or self.ctx.device
+        self.H, self.W = height, width
+        self.prm = ops.orb_params(nfeatures, nlevels=nlevels)
+        self.cap = nfeatures
+        self.batch = batch
+        self.ratio = ratio
+        self.wsp = ops.OrbWorkspace(batch, height, width, self.prm, self.device, brief_pattern())
+        self.scales = ops.orb_level_sizes(height, width, self.prm)[3]
+
+    # ------------------------------------------------------------------------------------------- detect
+    def detect(self, frames):
+        """frames [F,H,W] u8 on the device -> dict of per-frame tables (xy [F,cap,2] f32, desc [F,cap,32] u8, n [F],
+        meta, resp, mom), all device tensors."""
+        F = frames.shape[0]
+        d = self.device
+        out = dict(xy=torch.zeros((F, self.cap, 2), dtype=torch.float32, device=d),
+                   meta=torch.zeros((F, self.cap, 4), dtype=torch.int32, device=d),
+                   resp=torch.zeros((F, self.cap), dtype=torch.float32, device=d),
+                   mom=torch.zeros((F, self.cap, 2), dtype=torch.int32, device=d),
+                   desc=torch.zeros((F, self.cap, 32), dtype=torch.uint8, device=d),
+                   n=torch.zeros(F, dtype=torch.int32, device=d))
+        for b0 in range(0, F, self.batch):
+            b1 = min(F, b0 + self.batch)
+            ops.orb_detect_compute(frames[b0:b1], self.wsp, self.ctx,
+                                   out=(out["xy"][b0:b1], out["meta"][b0:b1], out["resp"][b0:b1], out["mom"][b0:b1],
+                                        out["desc"][b0:b1], out["n"][b0:b1]))
+        return out
+
+    # ------------------------------------------------------------------------------------------- match
+    def match(self, det, pair_lo=0, pair_hi=None):
+        """Consecutive pairs (k, k+1), k in [pair_lo, pair_hi) relative to the frames in `det`:
+        query = frame k, train = frame k+1 (processor.py:133).  -> pairs [n_pairs, cap, 2] i32, m [n_pairs] i32."""
+        F = det["desc"].shape[0]
+        if pair_hi is None:
+            pair_hi = F - 1
+        npairs = max(pair_hi - pair_lo, 0)
+        desc, n = det["desc"], det["n"]
+        if npairs == 0:
+            return (torch.zeros((0, self.cap, 2), dtype=torch.int32, device=self.device),
+                    torch.zeros(0, dtype=torch.int32, device=self.device))
+        q = desc[pair_lo:pair_hi]
+        t = desc[pair_lo + 1:pair_hi + 1]
+        idx, dist = ops.bf_knn2_batched(q, t, n[pair_lo:pair_hi].contiguous(), n[pair_lo + 1:pair_hi + 1].contiguous(),
+                                        self.ctx)
+        return ops.ratio_filter_batched(idx, dist, self.ratio, n[pair_lo:pair_hi].contiguous(), self.ctx)
+
+    # ------------------------------------------------------------------------------------------- link
+    def link(self, kp_count, kp_xy, match_count, matches):
+        """Host track linking over the clip (mm_link_tracks_clip).  numpy inputs:
+        kp_count [F] i32, kp_xy [F,cap,2] f32, match_count [F-1] i32, matches [F-1,mcap,2] i32.
+        -> (track_ptr [T+1] i64, obs_frame [O] i32, obs_kp [O] i32)."""
+        kp_count = np.ascontiguousarray(kp_count, np.int32)
+        kp_xy = np.ascontiguousarray(kp_xy, np.float32)
+        match_count = np.ascontiguousarray(match_count, np.int32)
+        matches = np.ascontiguousarray(matches, np.int32)
+        F = len(kp_count)
+        cap = kp_xy.shape[1] if kp_xy.ndim == 3 else 0
+        mcap = matches.shape[1] if matches.ndim == 3 else 0
+        total = int(match_count.sum())
+        track_ptr = np.zeros(total + 2, np.int64)
+        obs_frame = np.zeros(2 * total + 2, np.int32)
+        obs_kp = np.zeros(2 * total + 2, np.int32)
+        n_obs = C.c_int64(0)
+        nt = lib.mm_link_tracks_clip(F, cap, kp_count.ctypes.data_as(c_i32p), kp_xy.ctypes.data_as(c_f32p), mcap,
+                                     match_count.ctypes.data_as(c_i32p), matches.ctypes.data_as(c_i32p), total + 1,
+                                     2 * total + 1, track_ptr.ctypes.data_as(c_i64p), obs_frame.ctypes.data_as(c_i32p),
+                                     obs_kp.ctypes.data_as(c_i32p), C.byref(n_obs))
+        if nt < 0:
+            raise MMError(f"mm_link_tracks_clip failed ({nt})")
+        return track_ptr[:nt + 1], obs_frame[:n_obs.value], obs_kp[:n_obs.value]
+
+    # ------------------------------------------------------------------------------------------- triangulate
+    def triangulate(self, track_ptr, obs_frame, obs_kp, kp_xy_dev, projections):
+        """First/last observation of every track -> 3-D points [T,3] f64 on the device (processor.py:246-261)."""
+        d = self.device
+        T = len(track_ptr) - 1
+        first = track_ptr[:-1]
+        last = track_ptr[1:] - 1
+        f0 = torch.as_tensor(obs_frame[first].astype(np.int32)).to(d)
+        f1 = torch.as_tensor(obs_frame[last].astype(np.int32)).to(d)
+        k0 = torch.as_tensor(obs_kp[first].astype(np.int64)).to(d)
+        k1 = torch.as_tensor(obs_kp[last].astype(np.int64)).to(d)
+        x0 = kp_xy_dev[f0.long(), k0].to(torch.float64)
+        x1 = kp_xy_dev[f1.long(), k1].to(torch.float64)
+        proj = torch.as_tensor(np.ascontiguousarray(projections, np.float64)).to(d)
+        return ops.triangulate_dlt(proj, f0, f1, x0, x1, self.ctx) if T else torch.zeros((0, 3), dtype=torch.float64,
+                                                                                        device=d)
+
+    # ------------------------------------------------------------------------------------------- flatten (managePoints)
+    @staticmethod
+    def flatten(track_ptr, obs_frame, obs_kp, kp_xy_host):
+        """(coordinates [O,2] f64, frame_indices [O] i32, point_indices [O] i32) in managePoints order
+        (processor.py:264-291): point-major, insertion order inside a track."""
+        lens = np.diff(track_ptr).astype(np.int64)
+        pi = np.repeat(np.arange(len(lens), dtype=np.int32), lens)
+        coords = kp_xy_host[obs_frame, obs_kp].astype(np.float64)
+        return coords, obs_frame.astype(np.int32), pi
+
+    # ------------------------------------------------------------------------------------------- whole clip
+    def run(self, frames, K, extrinsics, ba=True, ftol=1e-4, verbose=0, dist=None, timers=None):
+        """frames [F,H,W] u8 (device).  With `dist` = torch.distributed (initialised), frames are the FULL clip on
+        every rank (synthetic input is generated locally) and the work is sharded as described in parallel.py."""
+        F = frames.shape[0]
+        world = dist.get_world_size() if dist is not None else 1
+        rank = dist.get_rank() if dist is not None else 0
+        T = timers if timers is not None else {}
+
+        def tic(name):
+            self.ctx.sync()
+            T.setdefault("_open", {})[name] = time.perf_counter()
+
+        def toc(name):
+            self.ctx.sync()
+            T[name] = T.get(name, 0.0) + (time.perf_counter() - T["_open"].pop(name)) * 1e3
+
+        (p_lo, p_hi), (f_lo, f_hi) = parallel.pair_block(F, rank, world)
+        tic("detect")
+        det = self.detect(frames[f_lo:f_hi]) if f_hi > f_lo else None
+        toc("detect")
+        tic("match")
+        if det is not None:
+            pairs, m = self.match(det)
+        else:
+            pairs = torch.zeros((0, self.cap, 2), dtype=torch.int32, device=self.device)
+            m = torch.zeros(0, dtype=torch.int32, device=self.device)
+        toc("match")
+        tic("link")
+        m_h = m.cpu().numpy()
+        mmax = int(m_h.max()) if m_h.size else 0
+        pairs_h = pairs[:, :max(mmax, 1)].cpu().numpy()
+        n_h = det["n"].cpu().numpy() if det is not None else np.zeros(0, np.int32)
+        xy_h = det["xy"].cpu().numpy() if det is not None else np.zeros((0, self.cap, 2), np.float32)
+        if world > 1:
+            # every rank needs every frame's key points and every pair's matches to link identical tracks
+            own = p_hi - p_lo  # frames f_lo .. f_lo+own-1 are owned; the halo frame belongs to the next rank
+            last_rank_with_pairs = max(r for r in range(world) if parallel.block_range(F - 1, r, world)[1] >
+                                       parallel.block_range(F - 1, r, world)[0])
+            keep = own + (1 if rank == last_rank_with_pairs else 0)
+            g_n = parallel.gather_varlen(n_h[:keep], world, dist)
+            g_xy = parallel.gather_varlen(xy_h[:keep], world, dist)
+            g_m = parallel.gather_varlen(m_h, world, dist)
+            pad = np.full((len(m_h), self.cap, 2), -1, np.int32)
+            pad[:, :pairs_h.shape[1]] = pairs_h
+            g_p = parallel.gather_varlen(pad, world, dist)
+            n_h = np.concatenate(g_n).astype(np.int32)
+            xy_h = np.concatenate([a.reshape(-1, self.cap, 2) for a in g_xy]).astype(np.float32)
+            m_h = np.concatenate(g_m).astype(np.int32)
+            pairs_h = np.concatenate([a.reshape(-1, self.cap, 2) for a in g_p]).astype(np.int32)
+            xy_dev = torch.as_tensor(xy_h).to(self.device)
+        else:
+            xy_dev = det["xy"]
+        track_ptr, obs_frame, obs_kp = self.link(n_h, xy_h, m_h, pairs_h)
+        toc("link")
+        ext = np.asarray(extrinsics, float)[:, :3, :]
+        proj = np.einsum("ij,fjk->fik", np.asarray(K, float), ext)   # K [R|t], processor.py:184,448
+        tic("triangulate")
+        X = self.triangulate(track_ptr, obs_frame, obs_kp, xy_dev, proj)
+        toc("triangulate")
+        out = dict(det=det, n_tracks=len(track_ptr) - 1, n_obs=len(obs_frame), points0=X, track_ptr=track_ptr,
+                   obs_frame=obs_frame, obs_kp=obs_kp, match_count=m_h, kp_count=n_h, pairs_local=int(p_hi - p_lo),
+                   frames_local=int(f_hi - f_lo))
+        if not ba or len(obs_frame) == 0:
+            return out
+        tic("ba")
+        coords, fi, pi = self.flatten(track_ptr, obs_frame, obs_kp, xy_h)
+        P = len(track_ptr) - 1
+        with np.errstate(all="ignore"):
+            cams0 = frameParameters(ext).reshape(F, 6)
+        X_h = None
+        if world > 1:
+            lo, hi, mask = parallel.partition_points(fi, pi, P, rank, world)
+            pb = ops.BADevice(K, fi[mask], pi[mask] - lo, coords[mask], F, hi - lo, self.device, self.ctx)
+            pts0 = X[lo:hi].contiguous()
+            solver = SchurTRF(pb, allreduce=parallel.AllReduce())
+        else:
+            pb = ops.BADevice(K, fi, pi, coords, F, P, self.device, self.ctx)
+            pts0 = X
+            solver = SchurTRF(pb)
+        cams_d = torch.as_tensor(cams0).to(self.device)
+        res = solver.solve(cams_d, pts0, ftol=ftol, verbose=verbose if rank == 0 else 0)
+        toc("ba")
+        out.update(ba=res, n_obs_local=pb.O)
+        T.pop("_open", None)
+        return out

@@ -1,0 +1,252 @@
+"""Drop-in for the hot-path functions of the reference's ``processor.py`` — same names, argument order and
+return order, HIP kernels underneath (no CPU fallback: a missing extension or GPU raises).
+
+    reference                                      here
+    ---------------------------------------------  ---------------------------------------------------------
+    cv2.ORB_create(nfeatures=...)  processor.py:308  ORB_create(nfeatures=...) -> ORB (detectAndCompute on device)
+    featureTracking                processor.py:113  featureTracking     (mm_orb_detect_compute + mm_bf_knn2_* + ratio)
+    pointTracking                  processor.py:190  pointTracking       (hash join; same list semantics)
+    triangulatePoints              processor.py:246  triangulatePoints   (mm_triangulate_dlt, batched over tracks)
+    managePoints                   processor.py:264  managePoints
+
+Frame I/O, CLAHE, keyframe gating, calibration, PnP and PLY export stay outside (SURVEY.md §8 "out of scope").
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import default_context
+from .orb_pattern import brief_pattern
+from .track import Track
+
+
+# ----------------------------------------------------------------------------------------------- key points
+
+class KeyPoint:
+    """Minimal cv2.KeyPoint look-alike (`.pt`, `.size`, `.angle`, `.response`, `.octave`)."""
+    __slots__ = ("pt", "size", "angle", "response", "octave", "class_id")
+
+    def __init__(self, x, y, size, angle, response, octave):
+        self.pt = (x, y)
+        self.size = size
+        self.angle = angle
+        self.response = response
+        self.octave = octave
+        self.class_id = -1
+
+
+class KeyPoints:
+    """Sequence of the key points of one frame.  Holds the device tensors (coordinates, descriptors) so that
+    featureTracking never re-uploads them; `kps[i]` builds a `KeyPoint` on demand (its `.pt` is a pair of Python
+    floats converted from float32, as cv2.KeyPoint.pt is)."""
+
+    def __init__(self, xy_dev, meta_dev, resp_dev, mom_dev, desc_dev, scales):
+        self.xy_dev, self.meta_dev, self.resp_dev, self.mom_dev, self.desc_dev = xy_dev, meta_dev, resp_dev, mom_dev, desc_dev
+        self._scales = scales
+        self._host = None
+
+    def _h(self):
+        if self._host is None:
+            self._host = (self.xy_dev.cpu().numpy(), self.meta_dev.cpu().numpy(), self.resp_dev.cpu().numpy(),
+                          self.mom_dev.cpu().numpy())
+        return self._host
+
+    @property
+    def xy(self):
+        """[n,2] float32 numpy (level-0 coordinates)."""
+        return self._h()[0]
+
+    def __len__(self):
+        return self.xy_dev.shape[0]
+
+    def __getitem__(self, i):
+        xy, meta, resp, mom = self._h()
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        lvl = int(meta[i, 0])
+        ang = math.degrees(math.atan2(float(mom[i, 1]), float(mom[i, 0]))) % 360.0
+        return KeyPoint(float(xy[i, 0]), float(xy[i, 1]), 31.0 * float(self._scales[lvl]), ang, float(resp[i]), lvl)
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
+class ORB:
+    """Device ORB with the cv2.ORB_create defaults the reference relies on (processor.py:308)."""
+
+    def __init__(self, nfeatures=500, scaleFactor=1.2, nlevels=8, edgeThreshold=31, fastThreshold=20, device=None):
+        self.prm = ops.orb_params(nfeatures, nlevels, scaleFactor, edgeThreshold, fastThreshold)
+        self.device = device
+        self._wsp = {}
+
+    def workspace(self, batch, H, W, device):
+        key = (batch, H, W, str(device))
+        w = self._wsp.get(key)
+        if w is None:
+            w = self._wsp[key] = ops.OrbWorkspace(batch, H, W, self.prm, device, brief_pattern())
+        return w
+
+    def _as_device_image(self, image):
+        if isinstance(image, torch.Tensor):
+            img = image
+        else:
+            img = torch.as_tensor(np.ascontiguousarray(image))
+        if img.dtype != torch.uint8 or img.dim() != 2:
+            raise ValueError("detectAndCompute expects a single-channel uint8 image [H, W]")
+        dev = self.device or torch.device("cuda", torch.cuda.current_device())
+        img = img.to(dev)
+        if img.stride(1) != 1 or img.stride(0) % 4 != 0:
+            H, W = img.shape
+            pad = torch.zeros((H, (W + 3) // 4 * 4), dtype=torch.uint8, device=dev)
+            pad[:, :W] = img
+            img = pad[:, :W]
+        return img
+
+    def detectAndCompute(self, image, mask=None):
+        """-> (KeyPoints, descriptors ndarray [n,32] uint8), like cv2.ORB.detectAndCompute(img, None)."""
+        if mask is not None:
+            raise NotImplementedError("mask is not supported (the reference always passes None, processor.py:129)")
+        img = self._as_device_image(image)
+        H, W = img.shape
+        wsp = self.workspace(1, H, W, img.device)
+        ops.orb_detect_compute(img.as_strided((1, H, W), (H * img.stride(0), img.stride(0), 1)), wsp)
+        n = int(wsp.n[0].item())
+        kps = KeyPoints(wsp.xy[0, :n].clone(), wsp.meta[0, :n].clone(), wsp.resp[0, :n].clone(), wsp.mom[0, :n].clone(),
+                        wsp.desc[0, :n].clone(), ops.orb_level_sizes(H, W, self.prm)[3])
+        desc = DeviceBackedDescriptors(kps.desc_dev)
+        return kps, desc
+
+
+class DeviceBackedDescriptors(np.ndarray):
+    """ndarray [n,32] uint8 (what cv2 returns) that remembers its device twin."""
+
+    def __new__(cls, desc_dev):
+        obj = np.asarray(desc_dev.cpu().numpy()).view(cls)
+        obj._dev = desc_dev
+        return obj
+
+    def __array_finalize__(self, obj):
+        self._dev = getattr(obj, "_dev", None) if obj is not None and getattr(obj, "shape", None) == self.shape else None
+
+
+def ORB_create(nfeatures=500, scaleFactor=1.2, nlevels=8, edgeThreshold=31, fastThreshold=20, **_ignored):
+    return ORB(nfeatures, scaleFactor, nlevels, edgeThreshold, fastThreshold)
+
+
+def _device_descriptors(desc, device):
+    dev = getattr(desc, "_dev", None)
+    if dev is not None and dev.shape[0] == len(desc):
+        return dev
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    if isinstance(desc, torch.Tensor):
+        return desc.to(device).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(desc, np.uint8)).to(device)
+
+
+def _points_xy(points):
+    if isinstance(points, KeyPoints):
+        return points.xy
+    return np.array([p.pt for p in points], np.float32).reshape(-1, 2)
+
+
+# ----------------------------------------------------------------------------------------------- featureTracking
+
+def featureTracking(new_keyframe, prev_orb_points, prev_orb_descriptors, orb, flann_params, threshold=0.75):
+    """Detect + describe the new keyframe and match the previous keyframe against it (processor.py:113-142).
+
+    `flann_params` is accepted for signature compatibility and ignored: the matcher is the exact brute-force
+    Hamming 2-NN that FLANN-LSH approximates (query = previous keyframe, train = new keyframe, processor.py:133);
+    a match is kept iff it has two neighbours and d0 < threshold * d1 (processor.py:136-137).
+    Returns (prev_matches [M,2] f64, curr_matches [M,2] f64, new_points, new_descriptors); M = 0 gives the
+    reference's `np.array([])`.
+    """
+    new_points, new_descriptors = orb.detectAndCompute(new_keyframe, None)
+    t_dev = _device_descriptors(new_descriptors, None)
+    q_dev = _device_descriptors(prev_orb_descriptors, t_dev.device)
+    idx, dist = ops.bf_knn2(q_dev, t_dev)
+    pairs, m = ops.ratio_filter_batched(idx.unsqueeze(0), dist.unsqueeze(0), threshold)
+    M = int(m[0].item())
+    good = pairs[0, :M].cpu().numpy()
+    if M == 0:
+        return np.array([]), np.array([]), new_points, new_descriptors
+    pxy = _points_xy(prev_orb_points)
+    nxy = _points_xy(new_points)
+    prev_matches = pxy[good[:, 0]].astype(np.float64)
+    curr_matches = nxy[good[:, 1]].astype(np.float64)
+    return prev_matches, curr_matches, new_points, new_descriptors
+
+
+# ----------------------------------------------------------------------------------------------- pointTracking
+
+def pointTracking(tracks, prev_keyframe_ID, feature_points, keyframe_ID, correspondents):
+    """Track linking with the reference's list semantics (processor.py:190-243) as a hash join:
+    the FIRST live track whose coordinate at `prev_keyframe_ID` equals the match's previous-frame point is
+    updated (a later match on the same track overwrites its new coordinate); other matches start new tracks,
+    appended after the surviving ones in match order; tracks not updated are popped in list order."""
+    first = {}
+    for pos, track in enumerate(tracks):
+        c = track.getCoordinate(prev_keyframe_ID)
+        if c is not None:
+            first.setdefault((float(c[0]), float(c[1])), pos)
+    new_tracks = []
+    for fp, co in zip(feature_points, correspondents):
+        feature_point = (fp[0], fp[1])
+        correspondent = (co[0], co[1])
+        pos = first.get((float(fp[0]), float(fp[1])))
+        if pos is None:
+            new_tracks.append(Track(prev_keyframe_ID, feature_point, keyframe_ID, correspondent))
+        else:
+            tracks[pos].update(keyframe_ID, correspondent)
+    updated_tracks, popped_tracks = [], []
+    for track in tracks:
+        if track.wasUpdated():
+            track.reset()
+            updated_tracks.append(track)
+        else:
+            popped_tracks.append(track)
+    updated_tracks += new_tracks
+    return popped_tracks, updated_tracks
+
+
+# ----------------------------------------------------------------------------------------------- triangulatePoints
+
+def triangulatePoints(tracks, projections):
+    """Two-view DLT of every track from its first and last observation (processor.py:246-261), one kernel launch
+    for all tracks; each track receives a (1,3) float64 array via setPoint, as in the reference."""
+    n = len(tracks)
+    if n == 0:
+        return
+    f0 = np.empty(n, np.int32)
+    f1 = np.empty(n, np.int32)
+    x0 = np.empty((n, 2), np.float64)
+    x1 = np.empty((n, 2), np.float64)
+    for i, track in enumerate(tracks):
+        a, b, pa, pb = track.getTriangulationData()
+        f0[i], f1[i] = a, b
+        x0[i] = (pa[0], pa[1])
+        x1[i] = (pb[0], pb[1])
+    ctx = default_context()
+    dev = ctx.device
+    proj = torch.as_tensor(np.ascontiguousarray(np.asarray(projections, np.float64).reshape(-1, 3, 4))).to(dev)
+    X = ops.triangulate_dlt(proj, torch.as_tensor(f0).to(dev), torch.as_tensor(f1).to(dev),
+                            torch.as_tensor(x0).to(dev), torch.as_tensor(x1).to(dev), ctx).cpu().numpy()
+    for i, track in enumerate(tracks):
+        track.setPoint(X[i:i + 1].copy())
+
+
+# ----------------------------------------------------------------------------------------------- managePoints
+
+def managePoints(tracks):
+    """Flatten tracks into BA arrays (processor.py:264-291).  Return order is the reference's:
+    (points, coordinates, frame_indices, point_indices)."""
+    points, coordinates, frame_indices, point_indices = [], [], [], []
+    for point_index, track in enumerate(tracks):
+        points.append(track.getPoint())
+        obs = track.getCoordinates()
+        coordinates.extend(obs.values())
+        frame_indices.extend(obs.keys())
+        point_indices.extend([point_index] * len(obs))
+    return points, coordinates, frame_indices, point_indices

@@ -1,0 +1,491 @@
+"""GPU parity tests: every HIP path, called through the C ABI (ctypes), against the CPU oracle on identical seeded
+inputs.  Bit-exact for integer / byte / index work; floating-point tolerances are written next to each check.
+
+Run on the MI355X box:  python -m pytest tests -m gpu -q
+"""
+import contextlib
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+if not torch.cuda.is_available():
+    pytest.skip("needs a GPU", allow_module_level=True)
+
+from meatmodeler_amd import ops, synth, processor, bundleAdjuster  # noqa: E402
+from meatmodeler_amd._lib import default_context  # noqa: E402
+from meatmodeler_amd.orb_pattern import brief_pattern  # noqa: E402
+from meatmodeler_amd.pipeline import ClipPipeline  # noqa: E402
+from oracle import ba_oracle as bo  # noqa: E402
+from oracle import orb_oracle as oo  # noqa: E402
+
+DEV = torch.device("cuda", 0)
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).to(DEV)
+
+
+# ============================================================================================== matching
+
+@pytest.mark.parametrize("n,seed", [(2000, 0), (4000, 1), (777, 2)])
+def test_bf_knn2_single_pair_bit_exact(n, seed):
+    q, t, _ = synth.random_descriptors(n, seed=seed)
+    t[5] = t[4]            # exact duplicate train rows -> distance ties
+    q[9] = q[8]
+    idx_o, dist_o = oo.bf_knn2(q, t)
+    idx, dist = ops.bf_knn2(dev(q), dev(t))
+    np.testing.assert_array_equal(dist.cpu().numpy(), dist_o)
+    np.testing.assert_array_equal(idx.cpu().numpy(), idx_o)
+    pairs, m = ops.ratio_filter_batched(idx.unsqueeze(0), dist.unsqueeze(0), 0.75)
+    po = oo.ratio_filter(idx_o, dist_o, 0.75)
+    assert int(m[0]) == len(po)
+    np.testing.assert_array_equal(pairs[0, :len(po)].cpu().numpy(), po)
+
+
+def test_bf_knn2_ties_resolve_to_lowest_train_index():
+    rng = np.random.default_rng(5)
+    t = rng.integers(0, 256, (300, 32), dtype=np.uint8)
+    t[100:110] = t[7]                      # ten copies of row 7
+    q = t[[7, 100, 250]].copy()
+    idx, dist = ops.bf_knn2(dev(q), dev(t))
+    idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+    assert list(idx[0]) == [7, 100] and list(dist[0]) == [0, 0]
+    assert list(idx[1]) == [7, 100]
+    io_, do_ = oo.bf_knn2(q, t)
+    np.testing.assert_array_equal(idx, io_)
+    np.testing.assert_array_equal(dist, do_)
+
+
+@pytest.mark.parametrize("nq,nt", [(0, 10), (5, 0), (5, 1), (5, 2), (1, 3), (513, 129)])
+def test_bf_knn2_edge_sizes(nq, nt):
+    rng = np.random.default_rng(nq * 31 + nt)
+    q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+    idx, dist = ops.bf_knn2(dev(q), dev(t) if nt else torch.zeros((0, 32), dtype=torch.uint8, device=DEV))
+    io_, do_ = oo.bf_knn2(q, t)
+    np.testing.assert_array_equal(idx.cpu().numpy().reshape(-1, 2), io_)
+    np.testing.assert_array_equal(dist.cpu().numpy().reshape(-1, 2), do_)
+    if nq:
+        pairs, m = ops.ratio_filter_batched(idx.unsqueeze(0), dist.unsqueeze(0), 0.75)
+        po = oo.ratio_filter(io_, do_, 0.75)
+        assert int(m[0]) == len(po)          # fewer than two neighbours -> never a match (processor.py:137)
+
+
+def test_bf_knn2_batched_ragged_counts():
+    rng = np.random.default_rng(11)
+    F, cap = 7, 600
+    table = rng.integers(0, 256, (F, cap, 32), dtype=np.uint8)
+    counts = np.array([600, 512, 0, 1, 333, 600, 2], np.int32)
+    for f in range(1, F):                      # plant matches between consecutive frames
+        k = min(counts[f - 1], counts[f]) // 2
+        table[f, :k] = table[f - 1, :k]
+        flips = rng.random((k, 256)) < 0.03
+        table[f, :k] ^= np.packbits(flips, axis=1, bitorder="little")
+    d = dev(table)
+    n = dev(counts)
+    idx, dist = ops.bf_knn2_batched(d[:-1], d[1:], n[:-1].contiguous(), n[1:].contiguous())
+    pairs, m = ops.ratio_filter_batched(idx, dist, 0.75, n[:-1].contiguous())
+    idx, dist, pairs, m = idx.cpu().numpy(), dist.cpu().numpy(), pairs.cpu().numpy(), m.cpu().numpy()
+    for p in range(F - 1):
+        nq, nt = counts[p], counts[p + 1]
+        io_, do_ = oo.bf_knn2(table[p, :nq], table[p + 1, :nt])
+        np.testing.assert_array_equal(idx[p, :nq], io_, err_msg=f"pair {p}")
+        np.testing.assert_array_equal(dist[p, :nq], do_, err_msg=f"pair {p}")
+        po = oo.ratio_filter(io_, do_, 0.75)
+        assert m[p] == len(po)
+        np.testing.assert_array_equal(pairs[p, :len(po)], po)
+
+
+def test_bf_knn2_full_size_properties():
+    """C3 size (4000 x 4000) x 16 pairs: self-match property instead of the oracle (size independent)."""
+    rng = np.random.default_rng(3)
+    base = rng.integers(0, 256, (17, 4000, 32), dtype=np.uint8)
+    d = dev(base)
+    idx, dist = ops.bf_knn2_batched(d[:-1], d[:-1])          # every set against itself
+    idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+    assert (dist[:, :, 0] == 0).all() and (idx[:, :, 0] == np.arange(4000)[None]).all()
+    assert (dist[:, :, 1] > 0).all()
+    sub = rng.choice(4000, 50, replace=False)
+    io_, do_ = oo.bf_knn2(base[3, sub], base[3])
+    np.testing.assert_array_equal(idx[3, sub], io_)
+    np.testing.assert_array_equal(dist[3, sub], do_)
+
+
+# ============================================================================================== ORB
+
+def _orb_gpu(frames, nfeatures):
+    B, H, W = frames.shape
+    prm = ops.orb_params(nfeatures)
+    wsp = ops.OrbWorkspace(B, H, W, prm, DEV, brief_pattern())
+    xy, meta, resp, mom, desc, n = ops.orb_detect_compute(dev(frames), wsp)
+    torch.cuda.synchronize()
+    return [a.cpu().numpy() for a in (xy, meta, resp, mom, desc, n)]
+
+
+def _cmp_orb(frames, nfeatures):
+    xy, meta, resp, mom, desc, n = _orb_gpu(frames, nfeatures)
+    for b in range(frames.shape[0]):
+        r = oo.detect_compute(frames[b], nfeatures, brief_pattern())
+        assert n[b] == r["n"], f"frame {b}: keypoint count {n[b]} vs oracle {r['n']}"
+        k = r["n"]
+        assert k > nfeatures // 4, "synthetic frame should be corner-rich"
+        np.testing.assert_array_equal(meta[b, :k, :3], r["meta"][:, :3], err_msg=f"frame {b} (level,x,y)")
+        np.testing.assert_array_equal(meta[b, :k, 3], r["meta"][:, 3], err_msg=f"frame {b} harris low bits")
+        np.testing.assert_array_equal(xy[b, :k], r["xy"], err_msg=f"frame {b} pt")
+        np.testing.assert_array_equal(resp[b, :k], r["resp"], err_msg=f"frame {b} response")
+        np.testing.assert_array_equal(mom[b, :k], r["mom"], err_msg=f"frame {b} moments")
+        bad = np.nonzero((desc[b, :k] != r["desc"]).any(axis=1))[0]
+        assert bad.size == 0, f"frame {b}: {bad.size} descriptors differ, first {bad[:5]}"
+
+
+def test_orb_small_frames_bit_exact():
+    frames, _, _ = synth.render_orbit_frames(3, 640, 480, arc_deg=6.0)
+    _cmp_orb(frames, 1000)
+
+
+def test_orb_odd_size_and_few_features_bit_exact():
+    frames, _, _ = synth.render_orbit_frames(2, 652, 364, arc_deg=2.0, seed=11)   # width % 4 == 0, small levels
+    _cmp_orb(frames, 300)
+
+
+def test_orb_1080p_bit_exact():
+    frames, _, _ = synth.render_orbit_frames(1, 1920, 1080, arc_deg=1.0, seed=5, tex_size=2048)
+    _cmp_orb(frames, 4000)
+
+
+def test_orb_flat_image_gives_no_keypoints():
+    frames = np.full((1, 480, 640), 90, np.uint8)
+    n = _orb_gpu(frames, 500)[5]
+    assert n[0] == 0
+
+
+def test_orb_pyramid_matches_oracle_resize():
+    """Level geometry from the C ABI equals the oracle's independent computation."""
+    prm = ops.orb_params(4000)
+    w, h, nf, sc = ops.orb_level_sizes(1080, 1920, prm)
+    wo, ho, no, so = oo.level_sizes(1080, 1920, 4000)
+    np.testing.assert_array_equal(w, wo)
+    np.testing.assert_array_equal(h, ho)
+    np.testing.assert_array_equal(nf, no)
+    np.testing.assert_array_equal(sc, so)
+
+
+# ============================================================================================== triangulation
+
+def test_triangulate_dlt_vs_oracle():
+    pr = synth.make_ba_problem(30, 500, 6, seed=8)
+    F = 30
+    proj = np.einsum("ij,fjk->fik", pr["K"], pr["ext"])
+    fi = pr["fi"].reshape(500, 6)
+    obs = pr["obs"].reshape(500, 6, 2)
+    f0, f1 = fi[:, 0].astype(np.int32), fi[:, -1].astype(np.int32)
+    x0, x1 = obs[:, 0], obs[:, -1]
+    X = ops.triangulate_dlt(dev(proj), dev(f0), dev(f1), dev(x0), dev(x1)).cpu().numpy()
+    Xo = bo.triangulate_dlt(proj[f0], proj[f1], x0, x1)
+    # f64 Jacobi SVD vs LAPACK SVD of the same 4x4 systems: 1e-8 relative (north star asks 1e-4)
+    np.testing.assert_allclose(X, Xo, rtol=1e-8, atol=1e-9)
+    assert np.abs(X - pr["pts_gt"]).max() < 0.2       # and they are the scene points
+
+
+# ============================================================================================== BA sweeps
+
+def _problem(F, P, L, seed):
+    pr = synth.make_ba_problem(F, P, L, seed=seed)
+    cams = bo.frame_parameters(pr["ext"]).reshape(F, 6)
+    ctx = default_context()
+    pb = ops.BADevice(pr["K"], pr["fi"], pr["pi"], pr["obs"], F, P, DEV, ctx)
+    return pr, cams, pb
+
+
+def test_ba_residual_matches_golden_and_oracle(golden_dir):
+    d = np.load(os.path.join(golden_dir, "g3_point_pose_fun.npz"))
+    for tag in ("small", "mid"):
+        F, P, L, seed = (int(d[f"{tag}_{k}"]) for k in ("F", "P", "L", "seed"))
+        pr, cams, pb = _problem(F, P, L, seed)
+        c2, res = pb.residual(dev(cams), dev(pr["pts0"]), True)
+        res = res.cpu().numpy()
+        # reference pointFun output captured by import: 1e-10 relative
+        np.testing.assert_allclose(res[d[f"{tag}_sel"]], d[f"{tag}_res"], rtol=1e-10, atol=1e-9)
+        assert abs(0.5 * float(c2) - float(d[f"{tag}_cost"])) <= 1e-11 * float(d[f"{tag}_cost"])
+        x = np.hstack([cams.ravel(), pr["pts0"].ravel()])
+        np.testing.assert_allclose(res.ravel(), bo.point_fun(x, pr["K"], F, P, pr["fi"], pr["pi"], pr["obs"]),
+                                   rtol=1e-10, atol=1e-9)
+
+
+def test_ba_residual_zero_and_tiny_rotation():
+    F, P = 4, 10
+    pr = synth.make_ba_problem(F, P, 4, seed=4)
+    cams = bo.frame_parameters(pr["ext"]).reshape(F, 6)
+    cams[0, :3] = 0.0                 # theta == 0 : nan_to_num branch of the reference (bundleAdjuster.py:19-21)
+    cams[1, :3] = [1e-9, 0, 0]
+    cams[2, :3] = [3e-3, -2e-3, 1e-3]  # series / closed-form boundary region
+    pb = ops.BADevice(pr["K"], pr["fi"], pr["pi"], pr["obs"], F, P, DEV)
+    _, res = pb.residual(dev(cams), dev(pr["pts0"]), True)
+    x = np.hstack([cams.ravel(), pr["pts0"].ravel()])
+    np.testing.assert_allclose(res.cpu().numpy().ravel(), bo.point_fun(x, pr["K"], F, P, pr["fi"], pr["pi"], pr["obs"]),
+                               rtol=1e-10, atol=1e-8)
+    Jc, Jp = pb.jacobian(dev(cams), dev(pr["pts0"]))
+    Jco, Jpo = bo.jacobian_fd(x, pr["K"], F, P, pr["fi"], pr["pi"], pr["obs"])
+    np.testing.assert_allclose(Jc.cpu().numpy(), Jco, rtol=2e-6, atol=2e-4)
+    np.testing.assert_allclose(Jp.cpu().numpy(), Jpo, rtol=2e-6, atol=2e-4)
+
+
+def test_ba_jacobian_vs_central_differences():
+    pr, cams, pb = _problem(12, 300, 5, 5)
+    x = np.hstack([cams.ravel(), pr["pts0"].ravel()])
+    Jc, Jp = pb.jacobian(dev(cams), dev(pr["pts0"]))
+    Jco, Jpo = bo.jacobian_fd(x, pr["K"], 12, 300, pr["fi"], pr["pi"], pr["obs"])
+    # central differences with h=1e-6 on pixel-scale derivatives (up to ~1e4): truncation+rounding ~1e-4 absolute
+    np.testing.assert_allclose(Jc.cpu().numpy(), Jco, rtol=2e-6, atol=5e-4)
+    np.testing.assert_allclose(Jp.cpu().numpy(), Jpo, rtol=2e-6, atol=5e-4)
+
+
+def _dense_normal(pr, F, P, Jc, Jp, res):
+    fi, pi = pr["fi"], pr["pi"]
+    B = np.zeros((F, 6, 6))
+    gc = np.zeros((F, 6))
+    C = np.zeros((P, 3, 3))
+    gp = np.zeros((P, 3))
+    np.add.at(B, fi, np.einsum("omi,omj->oij", Jc, Jc))
+    np.add.at(gc, fi, np.einsum("omi,om->oi", Jc, res))
+    np.add.at(C, pi, np.einsum("omi,omj->oij", Jp, Jp))
+    np.add.at(gp, pi, np.einsum("omi,om->oi", Jp, res))
+    return B, gc, C, gp
+
+
+def test_ba_normal_equations_jvp_schur_backsub_consistent():
+    F, P, L = 12, 300, 5
+    pr, cams, pb = _problem(F, P, L, 5)
+    cd, pd = dev(cams), dev(pr["pts0"])
+    Jc, Jp = (a.cpu().numpy() for a in pb.jacobian(cd, pd))
+    res = pb.residual(cd, pd, True)[1].cpu().numpy()
+    Bo, gco, Co, gpo = _dense_normal(pr, F, P, Jc, Jp, res)
+    B, gc, C, gp = pb.normal_eq(cd, pd)
+    np.testing.assert_allclose(B.cpu().numpy(), Bo, rtol=1e-11, atol=1e-6)
+    np.testing.assert_allclose(gc.cpu().numpy(), gco, rtol=1e-11, atol=1e-6)
+    tri = [(0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)]
+    np.testing.assert_allclose(C.cpu().numpy(), np.stack([Co[:, i, j] for i, j in tri], 1), rtol=1e-11, atol=1e-6)
+    np.testing.assert_allclose(gp.cpu().numpy(), gpo, rtol=1e-11, atol=1e-6)
+    # J w
+    rng = np.random.default_rng(0)
+    wc, wp = rng.normal(size=(F, 6)), rng.normal(size=(P, 3))
+    jv = pb.jvp(cd, pd, dev(wc), dev(wp)).cpu().numpy()
+    jvo = np.einsum("omi,oi->om", Jc, wc[pr["fi"]]) + np.einsum("omi,oi->om", Jp, wp[pr["pi"]])
+    np.testing.assert_allclose(jv, jvo, rtol=1e-11, atol=1e-8)
+    # damped system solved through Schur + Cholesky + back-substitution == dense solve of the full normal equations
+    reg = 1e-3
+    n = 6 * F + 3 * P
+    H = np.zeros((n, n))
+    for f in range(F):
+        H[6 * f:6 * f + 6, 6 * f:6 * f + 6] = Bo[f]
+    for p in range(P):
+        H[6 * F + 3 * p:6 * F + 3 * p + 3, 6 * F + 3 * p:6 * F + 3 * p + 3] = Co[p]
+    for o, (f, p) in enumerate(zip(pr["fi"], pr["pi"])):
+        E = Jc[o].T @ Jp[o]
+        H[6 * f:6 * f + 6, 6 * F + 3 * p:6 * F + 3 * p + 3] += E
+        H[6 * F + 3 * p:6 * F + 3 * p + 3, 6 * f:6 * f + 6] += E.T
+    Dm = np.concatenate([np.sqrt(np.einsum("fii->fi", Bo)).ravel(), np.sqrt(np.einsum("pii->pi", Co)).ravel()])
+    Hd = H + reg * np.diag(Dm ** 2)
+    g = np.concatenate([gco.ravel(), gpo.ravel()])
+    sol = np.linalg.solve(Hd, g)
+    Bd = B.clone()
+    Bd.diagonal(dim1=1, dim2=2).add_(reg * torch.diagonal(B, dim1=1, dim2=2))
+    Cd = C.clone()
+    Cd[:, [0, 3, 5]] += reg * C[:, [0, 3, 5]]
+    S, v, Cinv = pb.schur(cd, pd, Bd, Cd, gc, gp)
+    Sl = np.tril(S.cpu().numpy())
+    Sfull = Sl + np.tril(Sl, -1).T
+    Hcc, Hcp, Hpp = Hd[:6 * F, :6 * F], Hd[:6 * F, 6 * F:], Hd[6 * F:, 6 * F:]
+    So = Hcc - Hcp @ np.linalg.solve(Hpp, Hcp.T)
+    np.testing.assert_allclose(Sfull, So, rtol=1e-9, atol=1e-6 * np.abs(So).max())
+    info = ops.chol_solve(S, v)
+    assert int(info) == 0
+    dc = v.reshape(F, 6)
+    dp = pb.backsub(cd, pd, Cinv, gp, dc)
+    got = np.concatenate([dc.cpu().numpy().ravel(), dp.cpu().numpy().ravel()])
+    np.testing.assert_allclose(got, sol, rtol=1e-6, atol=1e-9 * np.abs(sol).max())
+
+
+@pytest.mark.parametrize("n", [2, 64, 130, 500, 1000])
+def test_chol_solve_random_spd(n):
+    rng = np.random.default_rng(n)
+    M = rng.normal(size=(n, n))
+    A = M @ M.T + n * np.eye(n)
+    b = rng.normal(size=n)
+    Ad, bd = dev(A), dev(b)
+    info = ops.chol_solve(Ad, bd)
+    assert int(info) == 0
+    np.testing.assert_allclose(bd.cpu().numpy(), np.linalg.solve(A, b), rtol=1e-9, atol=1e-12)
+    L = np.tril(Ad.cpu().numpy())
+    np.testing.assert_allclose(L @ L.T, A, rtol=1e-10, atol=1e-9 * n)
+
+
+def test_chol_reports_non_spd():
+    A = np.eye(70)
+    A[66, 66] = -1.0
+    info = ops.chol_solve(dev(A), dev(np.ones(70)))
+    assert int(info) == 67
+
+
+# ============================================================================================== adjustPoints
+
+def _similarity_align(X, Y):
+    """Least-squares similarity (7-DoF gauge) mapping X onto Y."""
+    mx, my = X.mean(0), Y.mean(0)
+    Xc, Yc = X - mx, Y - my
+    U, S, Vt = np.linalg.svd(Yc.T @ Xc)
+    D = np.diag([1, 1, np.sign(np.linalg.det(U @ Vt))])
+    R = U @ D @ Vt
+    s = np.trace(np.diag(S) @ D) / (Xc ** 2).sum()
+    return s * Xc @ R.T + my
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_adjust_points_vs_reference_golden(golden_dir, tag):
+    d = np.load(os.path.join(golden_dir, f"g5_adjust_points_{tag}.npz"))
+    F, P, L, seed = (int(d[k]) for k in ("F", "P", "L", "seed"))
+    pr = synth.make_ba_problem(F, P, L, seed=seed)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        pts, ext = bundleAdjuster.adjustPoints(pr["ext"], pr["K"], pr["pts0"][:, None, :], pr["obs"], pr["fi"], pr["pi"])
+    table = buf.getvalue()
+    assert table.splitlines()[0].split() == ["Iteration", "Total", "nfev", "Cost", "Cost", "reduction", "Step", "norm",
+                                             "Optimality"]
+    assert pts.shape == (P, 3) and len(ext) == F and ext[0].shape == (4, 4)
+    # cost / reprojection error at the returned solution, evaluated by the ORACLE cost function
+    cams = np.array([np.concatenate([bo.frame_parameters(e[None, :3])[:3], e[:3, 3]]) for e in ext])
+    x = np.hstack([cams.ravel(), pts.ravel()])
+    cost = 0.5 * np.sum(bo.point_fun(x, pr["K"], F, P, pr["fi"], pr["pi"], pr["obs"]) ** 2)
+    cost_ref = float(d["cost_ref"])
+    # north star: reprojection error within 1e-4 relative of the reference's result, and not worse beyond that
+    assert cost <= cost_ref * (1 + 1e-4), (cost, cost_ref)
+    assert abs(np.sqrt(cost) - np.sqrt(cost_ref)) <= 1e-4 * np.sqrt(cost_ref)
+    # 3-D points: the problem has a 7-DoF gauge freedom and the reference's own result is only reproducible to
+    # ~1e-3 in x (tests/test_oracle_golden.py::test_g5); compare directly at that level and at 1e-4 after removing
+    # the gauge (similarity alignment).
+    ref = d["points"]
+    scale = np.abs(ref).max()
+    assert np.abs(pts - ref).max() <= 5e-3 * scale
+    aligned = _similarity_align(pts, ref)
+    assert np.abs(aligned - ref).max() <= 1e-4 * scale, np.abs(aligned - ref).max() / scale
+
+
+def test_adjust_points_iterates_follow_scipy(golden_dir):
+    """Same trust-region algorithm, exact instead of LSMR inner solve: the iteration table matches the reference's."""
+    meta = json.load(open(os.path.join(golden_dir, "g5_adjust_points_meta.json")))
+    d = np.load(os.path.join(golden_dir, "g5_adjust_points_c.npz"))
+    F, P, L, seed = (int(d[k]) for k in ("F", "P", "L", "seed"))
+    pr = synth.make_ba_problem(F, P, L, seed=seed)
+    res = bundleAdjuster.solvePoints(pr["ext"], pr["K"], pr["pts0"], pr["obs"], pr["fi"], pr["pi"], verbose=0)
+    assert res.status == int(d["status_ref"]) and res.nfev == int(d["nfev_ref"])
+    assert abs(res.cost - float(d["cost_ref"])) <= 1e-5 * float(d["cost_ref"])
+    ref_costs = [float(line.split()[2]) for line in meta["c"]["table"].splitlines()[1:1 + int(d["nfev_ref"])]]
+    assert abs(ref_costs[-1] - res.cost) <= 1e-3 * res.cost
+
+
+def test_adjust_points_raises_on_non_finite():
+    pr = synth.make_ba_problem(4, 10, 3, seed=1)
+    pts = pr["pts0"].copy()
+    pts[0, 0] = np.nan
+    with pytest.raises(ValueError):
+        bundleAdjuster.solvePoints(pr["ext"], pr["K"], pts, pr["obs"], pr["fi"], pr["pi"], verbose=0)
+
+
+def test_point_fun_and_project_surface(golden_dir):
+    d = np.load(os.path.join(golden_dir, "g1_rotate_project.npz"))
+    np.testing.assert_allclose(bundleAdjuster.project(d["pts"], d["params"], d["K"]), d["projected"], rtol=1e-10,
+                               atol=1e-8)
+    np.testing.assert_allclose(bundleAdjuster.rotate(d["pts"], d["params"][:, :3]), d["rotated"], rtol=1e-12, atol=1e-12)
+    g3 = np.load(os.path.join(golden_dir, "g3_point_pose_fun.npz"))
+    F = 4
+    fi = np.repeat(np.arange(F), 12)
+    pi = np.tile(np.arange(12), F)
+    r = bundleAdjuster.poseFun(g3["pose_cams"], g3["pose_K"], F, fi, pi, g3["pose_pts3"], g3["pose_obs"])
+    np.testing.assert_allclose(r, g3["pose_res"], rtol=1e-10, atol=1e-9)
+
+
+# ============================================================================================== drop-in flow
+
+def test_processor_drop_in_flow_matches_oracle_flow():
+    """featureTracking -> pointTracking -> triangulatePoints -> managePoints on a 4-frame clip, against the same flow
+    built from the oracle's functions."""
+    frames, ext, K = synth.render_orbit_frames(4, 640, 480, arc_deg=4.5)
+    orb = processor.ORB_create(nfeatures=800)
+    pts_prev, desc_prev = orb.detectAndCompute(frames[0], None)
+    o_prev = oo.detect_compute(frames[0], 800, brief_pattern())
+    np.testing.assert_array_equal(np.asarray(desc_prev), o_prev["desc"])
+    assert pts_prev[3].pt == (float(o_prev["xy"][3, 0]), float(o_prev["xy"][3, 1]))
+    tracks, otracks, popped, opopped = [], [], [], []
+    for k in range(1, 4):
+        pm, cm, pts_new, desc_new = processor.featureTracking(frames[k], pts_prev, desc_prev, orb, dict(algorithm=6))
+        o_new = oo.detect_compute(frames[k], 800, brief_pattern())
+        io_, do_ = oo.bf_knn2(o_prev["desc"], o_new["desc"])
+        good = oo.ratio_filter(io_, do_, 0.75)
+        opm = o_prev["xy"][good[:, 0]].astype(np.float64)
+        ocm = o_new["xy"][good[:, 1]].astype(np.float64)
+        np.testing.assert_array_equal(pm, opm)
+        np.testing.assert_array_equal(cm, ocm)
+        assert pm.dtype == np.float64 and len(pm) > 100
+        p, tracks = processor.pointTracking(tracks, k - 1, pm, k, cm)
+        op, otracks = bo.point_tracking(otracks, k - 1, opm, k, ocm)
+        popped += p
+        opopped += op
+        pts_prev, desc_prev, o_prev = pts_new, desc_new, o_new
+    final, ofinal = popped + tracks, opopped + otracks
+    assert len(final) == len(ofinal) and len(final) > 100
+    proj = [K @ e for e in ext]
+    processor.triangulatePoints(final, proj)
+    for t, ot in zip(final, ofinal):
+        assert list(t.getCoordinates().items()) == list(ot.getCoordinates().items())
+    f0 = np.array([t.getTriangulationData()[0] for t in ofinal])
+    f1 = np.array([t.getTriangulationData()[1] for t in ofinal])
+    x0 = np.array([t.getTriangulationData()[2] for t in ofinal])
+    x1 = np.array([t.getTriangulationData()[3] for t in ofinal])
+    Xo = bo.triangulate_dlt(np.array(proj)[f0], np.array(proj)[f1], x0, x1)
+    X = np.concatenate([t.getPoint() for t in final])
+    assert final[0].getPoint().shape == (1, 3)
+    ok = np.isfinite(Xo).all(1) & (np.abs(Xo).max(1) < 1e3)
+    np.testing.assert_allclose(X[ok], Xo[ok], rtol=1e-6, atol=1e-7)
+    points, coords, fidx, pidx = processor.managePoints(final)
+    for i, t in enumerate(ofinal):
+        t.setPoint(final[i].getPoint())
+    op_, oc_, of_, opi_ = bo.manage_points(ofinal)
+    assert coords == oc_ and fidx == of_ and pidx == opi_ and np.array(points).shape == (len(final), 1, 3)
+
+
+def test_clip_pipeline_equals_per_keyframe_drop_in():
+    """The batched pipeline (detect all / match all / mm_link_tracks_clip) produces the same tracks as the per-keyframe
+    drop-in functions."""
+    frames, ext, K = synth.render_orbit_frames(5, 640, 480, arc_deg=6.0)
+    pipe = ClipPipeline(480, 640, 800, batch=3)
+    out = pipe.run(dev(frames), K, ext, ba=False)
+    orb = processor.ORB_create(nfeatures=800)
+    pts_prev, desc_prev = orb.detectAndCompute(frames[0], None)
+    tracks, popped = [], []
+    for k in range(1, 5):
+        pm, cm, pts_prev, desc_prev = processor.featureTracking(frames[k], pts_prev, desc_prev, orb, None)
+        p, tracks = processor.pointTracking(tracks, k - 1, pm, k, cm)
+        popped += p
+    final = popped + tracks
+    assert out["n_tracks"] == len(final)
+    xy = out["det"]["xy"].cpu().numpy()
+    tp, of, ok = out["track_ptr"], out["obs_frame"], out["obs_kp"]
+    for i, t in enumerate(final):
+        got = [(int(of[j]), (float(xy[of[j], ok[j], 0]), float(xy[of[j], ok[j], 1]))) for j in range(tp[i], tp[i + 1])]
+        want = [(int(f), (float(c[0]), float(c[1]))) for f, c in t.getCoordinates().items()]
+        assert got == want, i
+
+
+def test_clip_pipeline_with_ba_reduces_reprojection_error():
+    frames, ext, K = synth.render_orbit_frames(6, 640, 480, arc_deg=8.0)
+    pipe = ClipPipeline(480, 640, 1000, batch=6)
+    out = pipe.run(dev(frames), K, ext, ba=True)
+    res = out["ba"]
+    assert res.status in (1, 2, 3, 4) and np.isfinite(res.cost)
+    assert out["n_obs"] >= 2 * out["n_tracks"] > 200

@@ -1,0 +1,240 @@
+"""CPU: host-side logic of the product (track linking, flattening, index build, level geometry, trust-region
+scalars) against the golden vectors captured from the reference and against the oracle."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from meatmodeler_amd import ops, processor, bundleAdjuster, synth, parallel
+from meatmodeler_amd._lib import lib, c_i32p, c_i64p, c_f32p
+from meatmodeler_amd.track import Track
+from meatmodeler_amd.pipeline import ClipPipeline
+from oracle import ba_oracle as bo
+from oracle import orb_oracle as oo
+
+
+def _dump(tracks):
+    return [dict(coords=[[int(k), [float(v[0]), float(v[1])]] for k, v in t.getCoordinates().items()],
+                 updated=bool(t.wasUpdated())) for t in tracks]
+
+
+def _scripts(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "g7_point_tracking.json")))
+
+
+def test_point_tracking_and_manage_points_golden(golden_dir):
+    """processor.pointTracking / managePoints reproduce the reference's outputs call by call (G7)."""
+    for sc in _scripts(golden_dir):
+        kp = {int(k): v for k, v in sc["kp"].items()}
+        matches = {int(k): v for k, v in sc["matches"].items()}
+        tracks, popped_all = [], []
+        for call in sc["calls"]:
+            f = call["prev_ID"]
+            m = matches[f]
+            prev = np.array([kp[f][q] for q, _ in m])
+            cur = np.array([kp[f + 1][t] for _, t in m])
+            popped, tracks = processor.pointTracking(tracks, f, prev, f + 1, cur)
+            popped_all += popped
+            assert _dump(popped) == call["popped"]
+            assert _dump(tracks) == call["updated"]
+        final = popped_all + tracks
+        for i, t in enumerate(final):
+            t.setPoint(np.array([[float(i), float(i) + 0.5, -float(i)]]))
+        points, coords, fidx, pidx = processor.managePoints(final)
+        mg = sc["manage"]
+        assert list(np.array(points).shape) == mg["points_shape"]
+        assert [[float(c[0]), float(c[1])] for c in coords] == mg["coordinates"]
+        assert [int(i) for i in fidx] == mg["frame_indices"]
+        assert [int(i) for i in pidx] == mg["point_indices"]
+
+
+def test_link_tracks_clip_golden(golden_dir):
+    """mm_link_tracks_clip (bulk C linker) == the reference's per-call pointTracking + managePoints (G7)."""
+    for sc in _scripts(golden_dir):
+        kp = {int(k): v for k, v in sc["kp"].items()}
+        matches = {int(k): v for k, v in sc["matches"].items()}
+        F = len(kp)
+        cap = max(len(v) for v in kp.values())
+        mcap = max(len(v) for v in matches.values())
+        kp_xy = np.zeros((F, cap, 2), np.float32)
+        kp_count = np.zeros(F, np.int32)
+        for f, v in kp.items():
+            kp_xy[f, :len(v)] = v
+            kp_count[f] = len(v)
+        mm = np.zeros((F - 1, mcap, 2), np.int32)
+        mc = np.zeros(F - 1, np.int32)
+        for f, v in matches.items():
+            mm[f, :len(v)] = v
+            mc[f] = len(v)
+        tp, of, ok = ClipPipeline.link(None, kp_count, kp_xy, mc, mm)
+        coords, fi, pi = ClipPipeline.flatten(tp, of, ok, kp_xy)
+        mg = sc["manage"]
+        assert coords.tolist() == mg["coordinates"]
+        assert fi.tolist() == mg["frame_indices"]
+        assert pi.tolist() == mg["point_indices"]
+        assert len(tp) - 1 == mg["points_shape"][0]
+
+
+def test_link_tracks_clip_random_vs_oracle():
+    rng = np.random.default_rng(123)
+    F, nk = 9, 120
+    kp_xy = (np.round(rng.uniform(0, 300, (F, nk, 2)) * 2) / 2).astype(np.float32)
+    kp_xy[:, 7] = kp_xy[:, 3]       # duplicate coordinates in every frame
+    kp_count = np.full(F, nk, np.int32)
+    kp_count[4] = 100
+    mc = np.zeros(F - 1, np.int32)
+    mm = np.zeros((F - 1, nk, 2), np.int32)
+    for f in range(F - 1):
+        q = np.sort(rng.choice(kp_count[f], size=int(kp_count[f] * 0.6), replace=False))
+        t = rng.integers(0, kp_count[f + 1], size=q.size)
+        mc[f] = q.size
+        mm[f, :q.size, 0] = q
+        mm[f, :q.size, 1] = t
+    tp, of, ok = ClipPipeline.link(None, kp_count, kp_xy, mc, mm)
+    tracks, popped = [], []
+    for f in range(F - 1):
+        m = mm[f, :mc[f]]
+        p, tracks = bo.point_tracking(tracks, f, kp_xy[f][m[:, 0]].astype(np.float64), f + 1,
+                                      kp_xy[f + 1][m[:, 1]].astype(np.float64))
+        popped += p
+    final = popped + tracks
+    assert len(final) == len(tp) - 1
+    _, coords, fidx, pidx = bo.manage_points(final)
+    c2, f2, p2 = ClipPipeline.flatten(tp, of, ok, kp_xy)
+    assert [[float(a), float(b)] for a, b in coords] == c2.tolist()
+    assert list(fidx) == f2.tolist() and list(pidx) == p2.tolist()
+
+
+def test_link_tracks_empty_and_single_frame():
+    tp, of, ok = ClipPipeline.link(None, np.zeros(1, np.int32), np.zeros((1, 4, 2), np.float32), np.zeros(0, np.int32),
+                                   np.zeros((0, 4, 2), np.int32))
+    assert len(tp) == 1 and len(of) == 0
+    tp, of, ok = ClipPipeline.link(None, np.array([3, 3], np.int32), np.zeros((2, 4, 2), np.float32),
+                                   np.zeros(1, np.int32), np.zeros((1, 4, 2), np.int32))
+    assert len(tp) == 1 and len(of) == 0
+
+
+def test_track_api_golden(golden_dir):
+    log = json.load(open(os.path.join(golden_dir, "g8_track_api.json")))
+    t = Track(3, (1.0, 2.0), 4, (1.5, 2.5))
+    tri = lambda: json.loads(json.dumps(list(t.getTriangulationData())))
+    assert _dump([t])[0] == log[0]["coords"] and tri() == log[0]["tri"] and t.getPoint() is None
+    t.update(5, (2.0, 3.0))
+    assert t.wasUpdated() and _dump([t])[0] == log[1]["coords"] and tri() == log[1]["tri"]
+    t.reset()
+    assert t.wasUpdated() == log[2]["updated"] and list(t.getCoordinate(4)) == log[2]["get4"]
+    assert t.getCoordinate(9) is None
+    t.update(4, (9.0, 9.0))
+    assert _dump([t])[0] == log[3]["coords"] and tri() == log[3]["tri"]
+
+
+def test_frame_parameters_and_sparsity_golden(golden_dir):
+    d = np.load(os.path.join(golden_dir, "g2_frame_parameters.npz"))
+    np.testing.assert_allclose(bundleAdjuster.frameParameters(d["ext34"]), d["params34"], rtol=1e-13, atol=1e-14)
+    np.testing.assert_allclose(bundleAdjuster.frameParameters(d["ext44"]), d["params44"], rtol=1e-13, atol=1e-14)
+    s = np.load(os.path.join(golden_dir, "g4_sparsity.npz"))
+    A = bundleAdjuster.pointAdjustmentSparsity(5, 9, s["fi"], s["pi"]).tocsr()
+    A.sort_indices()
+    np.testing.assert_array_equal(A.indptr, s["indptr"])
+    np.testing.assert_array_equal(A.indices, s["indices"])
+
+
+def test_reformat_results_match_golden(golden_dir):
+    d = np.load(os.path.join(golden_dir, "g5_adjust_points_a.npz"))
+    F, P = int(d["F"]), int(d["P"])
+
+    class R:
+        x = d["x_ref"]
+    pts, ext = bundleAdjuster.reformatPointResult(R, F, P)
+    np.testing.assert_array_equal(pts, d["points"])
+    np.testing.assert_allclose(np.array(ext), d["extrinsics"], rtol=1e-12, atol=1e-13)
+    g6 = np.load(os.path.join(golden_dir, "g6_adjust_pose.npz"))
+    cams = np.array([np.concatenate([bo.frame_parameters(e[None])[:3], e[:, 3]]) for e in g6["result"]])
+
+    class R2:
+        x = cams.ravel()
+    out = bundleAdjuster.reformatPoseResult(R2, len(cams))
+    np.testing.assert_allclose(np.array(out), g6["result"], rtol=1e-9, atol=1e-10)
+
+
+def test_ba_build_index_stable_csr():
+    rng = np.random.default_rng(1)
+    F, P, O = 7, 40, 500
+    fi = rng.integers(0, F, O).astype(np.int32)
+    pi = rng.integers(0, P, O).astype(np.int32)
+    pt_ptr, pt_obs, cam_ptr, cam_obs = ops.ba_build_index(F, P, fi, pi)
+    np.testing.assert_array_equal(pt_obs, np.argsort(pi, kind="stable"))
+    np.testing.assert_array_equal(cam_obs, np.argsort(fi, kind="stable"))
+    np.testing.assert_array_equal(np.diff(pt_ptr), np.bincount(pi, minlength=P))
+    np.testing.assert_array_equal(np.diff(cam_ptr), np.bincount(fi, minlength=F))
+    with pytest.raises(ValueError):
+        ops.ba_build_index(F, P, np.array([F], np.int32), np.array([0], np.int32))
+
+
+@pytest.mark.parametrize("hw,nf", [((1080, 1920), 4000), ((480, 640), 1000), ((2160, 3840), 8000), ((364, 652), 300),
+                                   ((1080, 1920), 20000)])
+def test_orb_level_geometry_matches_oracle(hw, nf):
+    prm = ops.orb_params(nf)
+    w, h, n, s = ops.orb_level_sizes(hw[0], hw[1], prm)
+    wo, ho, no, so = oo.level_sizes(hw[0], hw[1], nf)
+    np.testing.assert_array_equal(w, wo)
+    np.testing.assert_array_equal(h, ho)
+    np.testing.assert_array_equal(n, no)
+    np.testing.assert_array_equal(s, so)
+    assert n.sum() == nf
+
+
+def test_trust_region_scalar_helpers_match_scipy():
+    from scipy.optimize._lsq import common
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        M = rng.normal(size=(2, 2))
+        B = M @ M.T + 1e-3 * np.eye(2)
+        g = rng.normal(size=2) * 10
+        for Delta in (1e-3, 0.5, 10.0):
+            p, nw = bundleAdjuster._solve_trust_region_2d(B, g, Delta)
+            ps, nws = common.solve_trust_region_2d(B, g, Delta)
+            np.testing.assert_allclose(p, ps, rtol=1e-12, atol=1e-14)
+            assert nw == nws
+    assert bundleAdjuster._update_tr_radius(1.0, 0.1, 1.0, 0.5, True) == common.update_tr_radius(1.0, 0.1, 1.0, 0.5, True)
+    assert bundleAdjuster._update_tr_radius(1.0, 0.9, 1.0, 0.99, True) == common.update_tr_radius(1.0, 0.9, 1.0, 0.99, True)
+    for args in [(1e-6, 1.0, 1e-3, 1.0, 0.5, 1e-4, 1e-8), (1e-2, 1.0, 1e-12, 1.0, 0.5, 1e-4, 1e-8),
+                 (1e-6, 1.0, 1e-12, 1.0, 0.5, 1e-4, 1e-8), (1e-6, 1.0, 1e-3, 1.0, 0.1, 1e-4, 1e-8)]:
+        assert bundleAdjuster._check_termination(*args) == common.check_termination(*args)
+
+
+def test_partitions_cover_everything_once():
+    for n, world in [(499, 8), (3, 8), (0, 2), (17, 4)]:
+        seen = []
+        for r in range(world):
+            lo, hi = parallel.block_range(n, r, world)
+            seen += list(range(lo, hi))
+        assert seen == list(range(n))
+    pr = synth.make_ba_problem(20, 333, 5, seed=2)
+    total = 0
+    last = 0
+    for r in range(4):
+        lo, hi, mask = parallel.partition_points(pr["fi"], pr["pi"], 333, r, 4)
+        assert lo == last
+        last = hi
+        total += mask.sum()
+        assert abs(mask.sum() - len(pr["fi"]) / 4) <= 10
+    assert last == 333 and total == len(pr["fi"])
+    (p_lo, p_hi), (f_lo, f_hi) = parallel.pair_block(500, 7, 8)
+    assert p_hi == 499 and f_hi == 500 and f_lo == p_lo
+
+
+def test_brief_pattern_is_fixed_and_inside_the_disc():
+    from meatmodeler_amd.orb_pattern import brief_pattern
+    p = brief_pattern().astype(int)
+    assert p.shape == (256, 4)
+    assert ((p[:, 0] ** 2 + p[:, 1] ** 2) <= 225).all() and ((p[:, 2] ** 2 + p[:, 3] ** 2) <= 225).all()
+    assert not ((p[:, 0] == p[:, 2]) & (p[:, 1] == p[:, 3])).any()
+    assert int(p.sum()) == int(brief_pattern().astype(int).sum())
+    import hashlib
+    assert hashlib.sha1(brief_pattern().tobytes()).hexdigest() == PATTERN_SHA1
+
+
+PATTERN_SHA1 = "12fa8b026f52705ed79d4c58f8d8ff7fe21aba5a"
