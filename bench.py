@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""bench.py — the hot path (detect -> match -> link -> triangulate -> bundle adjust) on a synthetic clip.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+Workload = BASELINE.json configs[2] (the configuration the metric is quoted on): 500 frames 1080p, 4000 ORB key points
+per frame, consecutive-pair BF Hamming matching, track linking, 2-view triangulation, full BA.  A "step" is one pass of
+that path over the whole clip with the frames already resident in HBM.  With N > 1 the SAME clip is sharded over the
+ranks (strong scaling): frame pairs for detect/match, points for BA, one RCCL all-reduce of the camera-side blocks
+per trust-region iteration.
+
+One JSON line on rank 0.  `value` = descriptor-match pairs/s over the match stage of the timed steps (first quantity of
+the metric); `ba_residuals_per_s`, `frames_per_s` and `stage_ms` are reported beside it; `roofline` describes the kernel
+with the largest share of device time inside the timed steps (per-launch HIP events on the launch stream, see
+mm_profile_* in include/meatmodeler.h); `cpu_baseline` times the CPU oracle on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+VALU_PEAK_TLOPS = 78.6         # 256 CU x 4 SIMD-32 x 2.4 GHz (157.3 TF FP32 vector / 2)
+MFMA_F64_PEAK_TF = 78.6        # v_mfma_f64_16x16x4: 2048 flop / 64 clk / SIMD
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=500)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--nfeatures", type=int, default=4000)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--arc", type=float, default=None, help="orbit arc in degrees (default 0.72 deg/frame)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ba", action="store_true")
+    return ap.parse_args()
+
+
+def algorithmic_work(name, cfg):
+    """(bytes, lane_ops, mfma_flops) per STEP for kernel `name` — the per-unit figures of DESIGN.md x the units."""
+    F, N = cfg["frames_local"], cfg["nfeatures"]
+    lv = cfg["levels"]           # list of (w, h)
+    px = [w * h for w, h in lv]
+    O, P, Fc = cfg.get("n_obs_local", 0), cfg.get("n_points_local", 0), cfg["frames"]
+    it = cfg.get("ba_iters", 0)   # Jacobian evaluations
+    nfev = cfg.get("ba_nfev", 0)
+    kp = cfg.get("kp_total_local", F * N)
+    if name == "bf_knn2_kernel":
+        pairs = cfg["pair_evals_local"]
+        return cfg["pairs_local"] * (32 * 2 * N + 16 * N), pairs * 20.6, 0
+    if name == "orb_fast_kernel":
+        return F * (sum(px) + 4 * cfg.get("cand_per_frame", 0)), F * sum(px) * 80, 0
+    if name == "orb_resize_kernel":
+        return F * sum(px[i - 1] + px[i] for i in range(1, len(px))), 0, 0
+    if name == "orb_describe_kernel":
+        return kp * (39 * 39 + 32 + 8 + 16), 0, 0
+    if name == "orb_harris_kernel":
+        return F * (4 * cfg.get("cand_per_frame", 0)) + 2 * kp * (81 + 12), 0, 0
+    if name == "orb_rank_kernel":
+        return 2 * kp * 12 + kp * 32, 0, 0
+    if name == "orb_select_kernel":
+        return F * 4 * 4 * cfg.get("cand_per_frame", 0), 0, 0
+    if name == "ba_residual_kernel":
+        return nfev * O * 48, 0, 0                      # idx 8 + obs 16 + point 24 (cameras stay in L2)
+    if name in ("ba_point_blocks_kernel", "ba_backsub_kernel"):
+        return it * (O * 28 + P * (24 + 72)), 0, 0
+    if name == "ba_camera_blocks_kernel":
+        return it * (O * (4 + 4 + 16 + 24) + Fc * 42 * 8), 0, 0
+    if name == "ba_jvp_kernel":
+        return 2 * it * O * (48 + 16 + 24), 0, 0
+    if name == "schur_accum_kernel":
+        return it * (O * 28 + P * 72), 0, 0
+    if name == "schur_init_kernel":
+        return it * (6 * Fc) ** 2 * 8, 0, 0
+    if name == "chol_update_kernel":
+        n = 6 * Fc
+        return 0, 0, it * n ** 3 / 3.0
+    return None, 0, 0
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    use_dist = world > 1
+    if use_dist:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from meatmodeler_amd import synth, ops
+    from meatmodeler_amd._lib import default_context
+    from meatmodeler_amd.pipeline import ClipPipeline
+
+    ctx = default_context()
+    F, H, W, N = a.frames, a.height, a.width, a.nfeatures
+    arc = a.arc if a.arc is not None else min(360.0, 0.72 * F)
+    K = synth.default_K(W, H, f=525.0 * W / 640.0)
+    t0 = time.time()
+    frames, ext_gt, _ = synth.render_orbit_frames_torch(F, W, H, dev, arc_deg=arc, seed=7, K=K)
+    # poses: ground truth + small noise (stands in for calibrate / solvePnP / adjustPose, out of scope)
+    rng = np.random.default_rng(5)
+    ext = ext_gt.copy()
+    for f in range(F):
+        ext[f, :, :3] = synth.rodrigues(rng.normal(0, 5e-4, 3)) @ ext_gt[f, :, :3]
+        ext[f, :, 3] += rng.normal(0, 2e-3, 3)
+    torch.cuda.synchronize()
+    t_render = time.time() - t0
+    pipe = ClipPipeline(H, W, N, batch=a.batch, device=dev, ctx=ctx)
+    d = dist if use_dist else None
+
+    def step(timers=None):
+        return pipe.run(frames, K, ext, ba=not a.no_ba, ftol=1e-4, verbose=0, dist=d, timers=timers)
+
+    for _ in range(a.warmup):
+        out = step()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ctx.profile(True)
+    timers = {}
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step(timers)
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.profile_report()
+    ctx.profile(False)
+    el = torch.tensor([elapsed] + [timers.get(k, 0.0) for k in ("detect", "match", "link", "triangulate", "ba")],
+                      dtype=torch.float64, device=dev)
+    if use_dist:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el[0])
+    stage_ms = {k: float(v) / a.steps for k, v in zip(("detect", "match", "link", "triangulate", "ba"), el[1:])}
+
+    kp_count = out["kp_count"]
+    pair_evals = float(np.sum(kp_count[:-1].astype(np.float64) * kp_count[1:].astype(np.float64)))
+    res = out.get("ba")
+    n_obs = out["n_obs"]
+    nfev = res.nfev if res is not None else 0
+    value = pair_evals / (stage_ms["match"] * 1e-3) if stage_ms["match"] > 0 else 0.0
+    ba_rps = n_obs * nfev / (stage_ms["ba"] * 1e-3) if stage_ms["ba"] > 0 else 0.0
+
+    # ---- roofline of the dominant kernel (this rank's launches; rank 0 reports) ----
+    lv_w, lv_h, _, _ = ops.orb_level_sizes(H, W, pipe.prm)
+    (p_lo, p_hi), (f_lo, f_hi) = __import__("meatmodeler_amd.parallel", fromlist=["x"]).pair_block(F, rank, world)
+    kpl = kp_count[f_lo:f_hi].astype(np.float64)
+    cfg = dict(frames=F, frames_local=f_hi - f_lo, nfeatures=N, levels=list(zip(lv_w.tolist(), lv_h.tolist())),
+               pairs_local=p_hi - p_lo, pair_evals_local=float(np.sum(kpl[:-1] * kpl[1:])) if len(kpl) > 1 else 0.0,
+               kp_total_local=float(kpl.sum()), n_obs_local=out.get("n_obs_local", n_obs),
+               n_points_local=out["n_tracks"] // world, ba_iters=res.njev if res is not None else 0, ba_nfev=nfev)
+    kernels = []
+    for name, (cnt, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
+        by, lops, fl = algorithmic_work(name, cfg)
+        per = ms / a.steps
+        row = dict(kernel=name, launches_per_step=cnt / a.steps, ms_per_step=per, avg_us=1e3 * ms / max(cnt, 1))
+        if by:
+            row["algorithmic_GBps"] = by / (per * 1e-3) / 1e9
+        if lops:
+            row["valu_Tlops"] = lops / (per * 1e-3) / 1e12
+        if fl:
+            row["mfma_f64_TFLOPs"] = fl / (per * 1e-3) / 1e12
+        kernels.append(row)
+    dom = kernels[0] if kernels else None
+    roofline = None
+    if dom is not None:
+        if "mfma_f64_TFLOPs" in dom:
+            roofline = dict(kernel=dom["kernel"], bound="mfma", achieved=dom["mfma_f64_TFLOPs"], peak=MFMA_F64_PEAK_TF,
+                            unit="TFLOP/s", frac=dom["mfma_f64_TFLOPs"] / MFMA_F64_PEAK_TF, traffic=None)
+        else:
+            ach = dom.get("algorithmic_GBps", 0.0)
+            roofline = dict(kernel=dom["kernel"], bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=ach / HBM_PEAK_GBS, traffic=None, avg_launch_us=dom["avg_us"])
+            if "valu_Tlops" in dom:   # VALU-issue-bound kernels: the binding roof, stated beside the HBM one
+                roofline["valu_achieved_Tlops"] = dom["valu_Tlops"]
+                roofline["valu_peak_Tlops"] = VALU_PEAK_TLOPS
+                roofline["valu_frac"] = dom["valu_Tlops"] / VALU_PEAK_TLOPS
+    bf = next((k for k in kernels if k["kernel"] == "bf_knn2_kernel"), None)
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(frames, N, F)
+
+    if rank == 0:
+        line = {
+            "metric": "descriptor-match pairs/sec + BA residuals/sec, 500×1080p frames, 1/2/4/8 GPU",
+            "value": value, "unit": "descriptor pairs/s (match stage)",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8/int32 (match), f64 (BA)",
+            "data": "synthetic",
+            "config": {"workload": f"{F} frames {W}x{H}, {N} ORB kpts/frame, BF Hamming 2-NN + ratio, track linking, "
+                                   "2-view DLT, full BA (TRF, Schur, f64 MFMA Cholesky)" + (" [BA off]" if a.no_ba else ""),
+                       "frames": F, "height": H, "width": W, "nfeatures": N, "parallelism": f"pairs/points x{world}"},
+            "ba_residuals_per_s": ba_rps, "frames_per_s": F / (elapsed / a.steps), "stage_ms": stage_ms,
+            "problem": {"keypoints": int(kp_count.sum()), "descriptor_pairs": pair_evals,
+                        "matches": int(out["match_count"].sum()), "tracks": out["n_tracks"], "observations": n_obs,
+                        "ba_nfev": nfev, "ba_status": res.status if res is not None else None,
+                        "ba_cost": res.cost if res is not None else None, "render_s": t_render},
+            "roofline": roofline,
+            "bf_knn2": bf,
+            "kernels": kernels[:12],
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if use_dist:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(frames, nfeatures, n_frames):
+    """The CPU oracle ("port" of the reference's CPU path: the C restatement of ORB + BF matching, and the reference's
+    own SciPy TRF/LSMR recipe on the NumPy restatement of pointFun) timed on this box's host cores, single thread,
+    on a bounded sample of the same workload."""
+    from oracle import orb_oracle as oo
+    from oracle import ba_oracle as bo
+    from meatmodeler_amd import synth
+    from meatmodeler_amd.orb_pattern import brief_pattern
+    ns = min(2, frames.shape[0])
+    host = frames[:ns].cpu().numpy()
+    t0 = time.perf_counter()
+    dets = [oo.detect_compute(host[i], nfeatures, brief_pattern()) for i in range(ns)]
+    t_orb = (time.perf_counter() - t0) / ns
+    t0 = time.perf_counter()
+    a_, b_ = dets[0]["desc"], dets[-1]["desc"]
+    idx, dist_ = oo.bf_knn2(a_, b_)
+    oo.ratio_filter(idx, dist_, 0.75)
+    t_match = time.perf_counter() - t0
+    pairs = float(len(a_)) * float(len(b_))
+    pr = synth.make_ba_problem(40, 4000, 6, seed=1)
+    t0 = time.perf_counter()
+    _, _, r = bo.adjust_points(pr["ext"], pr["K"], pr["pts0"][:, None, :], pr["obs"], pr["fi"], pr["pi"],
+                               return_result=True)
+    t_ba = time.perf_counter() - t0
+    O = len(pr["fi"])
+    ba_rps = O * r.nfev / t_ba
+    obs_per_frame = 0.9 * nfeatures
+    frame_s = t_orb + t_match + obs_per_frame * 4 / ba_rps
+    return {"value": pairs / t_match, "unit": "descriptor pairs/s", "cores": 1, "kind": "port",
+            "sample": f"{ns} frames ORB ({t_orb * 1e3:.0f} ms/frame), 1 frame pair {len(a_)}x{len(b_)} BF match "
+                      f"({t_match * 1e3:.0f} ms), SciPy TRF+LSMR BA on 40 frames/4000 points/{O} observations "
+                      f"({t_ba:.2f} s, {r.nfev} nfev)",
+            "orb_ms_per_frame": t_orb * 1e3, "match_ms_per_pair": t_match * 1e3, "ba_residuals_per_s": ba_rps,
+            "frames_per_s_estimate": 1.0 / frame_s, "host_cpu_count": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()
