@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--arc", type=float, default=None, help="orbit arc in degrees (default 0.72 deg/frame)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ba", action="store_true")
+    ap.add_argument("--verbose", type=int, default=0)
     return ap.parse_args()
 
 
@@ -128,7 +129,7 @@ def main():
     d = dist if use_dist else None
 
     def step(timers=None):
-        return pipe.run(frames, K, ext, ba=not a.no_ba, ftol=1e-4, verbose=0, dist=d, timers=timers)
+        return pipe.run(frames, K, ext, ba=not a.no_ba, ftol=1e-4, verbose=a.verbose, dist=d, timers=timers)
 
     for _ in range(a.warmup):
         out = step()

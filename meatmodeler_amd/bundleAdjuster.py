@@ -197,10 +197,11 @@ class SchurTRF:
     (points partitioned over GPUs, cameras replicated): it is called on every tensor that is a sum over
     observations."""
 
-    def __init__(self, pb, allreduce=None, timers=None):
+    def __init__(self, pb, allreduce=None, timers=None, min_damping=1e-9):
         self.pb = pb
         self.allreduce = allreduce
         self.timers = timers
+        self.min_damping = min_damping
 
     # -- reductions that need the cross-rank sum when sharded --
     def _ar(self, *tensors):
@@ -286,28 +287,35 @@ class SchurTRF:
             ts = np.asarray(ts)
             ag_value = float(np.min(ts * (a_q * ts + b_q)))
             reg = -ag_value / Delta ** 2
-            # damped blocks: J^T J + reg * D^-2  (D^-2 = scale_inv^2)
-            Bd = B.clone()
-            Bd.diagonal(dim1=1, dim2=2).add_(reg * sic * sic)
-            Cd = C.clone()
-            Cd[:, diag_idx] += reg * sip * sip
-            S, v, Cinv = pb.schur(cams, pts, Bd, Cd, gc, gp)
-            if self.allreduce is not None:
-                # every rank added the full blockdiag(Bd) and gc: remove the duplicates after the sum
-                ws = self.allreduce.world_size
-                self.allreduce(S)
-                self.allreduce(v)
-                if ws > 1:
-                    idx = torch.arange(6 * pb.F, device=dev).reshape(pb.F, 6)
-                    blk = S.reshape(pb.F, 6, pb.F, 6)
-                    f = torch.arange(pb.F, device=dev)
-                    blk[f, :, f, :] -= (ws - 1) * Bd
-                    v -= (ws - 1) * gc.reshape(-1)
-            info = ops.chol_solve(S, v, pb.ctx)
+            # damped blocks: J^T J + reg * D^-2  (D^-2 = scale_inv^2).  No gauge is fixed (as in the reference), so
+            # J^T J has a 7-dimensional null space and only the damping makes the reduced system definite; SciPy's
+            # LSMR copes with a singular system, a Cholesky factorisation needs `reg` to stay above rounding:
+            # a floor of 1e-9 (relative to the unit diagonal of the scaled system) and x100 retries on a bad pivot.
+            reg_eff = max(reg, self.min_damping)
+            for attempt in range(6):
+                Bd = B.clone()
+                Bd.diagonal(dim1=1, dim2=2).add_(reg_eff * sic * sic)
+                Cd = C.clone()
+                Cd[:, diag_idx] += reg_eff * sip * sip
+                S, v, Cinv = pb.schur(cams, pts, Bd, Cd, gc, gp)
+                if self.allreduce is not None:
+                    # every rank added the full blockdiag(Bd) and gc: remove the duplicates after the sum
+                    ws = self.allreduce.world_size
+                    self.allreduce(S)
+                    self.allreduce(v)
+                    if ws > 1:
+                        blk = S.reshape(pb.F, 6, pb.F, 6)
+                        f = torch.arange(pb.F, device=dev)
+                        blk[f, :, f, :] -= (ws - 1) * Bd
+                        v -= (ws - 1) * gc.reshape(-1)
+                info = ops.chol_solve(S, v, pb.ctx)
+                if int(info.item()) == 0:
+                    break
+                reg_eff *= 100.0
+            else:
+                raise MMError(f"reduced camera system is not positive definite (pivot {int(info.item())})")
             dc = v.reshape(pb.F, 6)
             dp = pb.backsub(cams, pts, Cinv, gp, dc)
-            if int(info.item()) != 0:
-                raise MMError(f"reduced camera system is not positive definite (pivot {int(info.item())})")
             gnc, gnp = dc * sic, dp * sip          # gn_h = q * scale_inv
             # orthonormal basis of span{g_h, gn_h} (trf.py:481-482)
             q1c, q1p = ghc / gh_norm, ghp / gh_norm

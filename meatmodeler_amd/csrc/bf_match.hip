@@ -213,7 +213,7 @@ int mm_bf_knn2_batched(mm_ctx *ctx, const uint8_t *q, const int32_t *nq, int nq_
                        int32_t *idx, int32_t *dist, void *ws, size_t ws_bytes) {
     if (!ctx) return MM_ERR_ARG;
     if (n_pairs == 0 || nq_cap == 0) return MM_OK;
-    if (!q || !t || !idx || !dist || n_pairs < 0 || nq_cap < 0 || nt_cap < 0)
+    if (!q || (!t && nt_cap > 0) || !idx || !dist || n_pairs < 0 || nq_cap < 0 || nt_cap < 0)
         return mm_fail(ctx, MM_ERR_ARG, "mm_bf_knn2_batched: bad argument");
     if (nt_cap >= (1 << BF_IDX_BITS)) return mm_fail(ctx, MM_ERR_ARG, "mm_bf_knn2_batched: nt_cap must be < 2^20");
     if (((uintptr_t)q | (uintptr_t)t | q_set_stride | t_set_stride) & 15)
