@@ -217,7 +217,8 @@ def main():
             "problem": {"keypoints": int(kp_count.sum()), "descriptor_pairs": pair_evals,
                         "matches": int(out["match_count"].sum()), "tracks": out["n_tracks"], "observations": n_obs,
                         "ba_nfev": nfev, "ba_status": res.status if res is not None else None,
-                        "ba_cost": res.cost if res is not None else None, "render_s": t_render},
+                        "ba_cost": res.cost if res is not None else None, "cam_span": out.get("cam_span"),
+                        "schur_pairs": out.get("n_pairs"), "render_s": t_render},
             "roofline": roofline,
             "bf_knn2": bf,
             "kernels": kernels[:12],

@@ -117,6 +117,12 @@ int64_t mm_link_tracks_clip(int n_frames, int cap, const int32_t *kp_count, cons
                             const int32_t *match_count, const int32_t *matches, int64_t max_tracks,
                             int64_t max_obs, int64_t *track_ptr /*[max_tracks+1]*/, int32_t *obs_frame,
                             int32_t *obs_kp, int64_t *n_obs_out);
+/* Host: co-observation pairs (o, o2) of one point with camera(o2) <= camera(o), grouped by block segment
+ * camera(o) * (span + 1) + camera(o) - camera(o2) in a fixed canonical order.  seg_ptr [F*(span+1)+1].  Call with
+ * pair_o == NULL to get the pair count.  Returns the count or a negative error (MM_ERR_ARG if span is too small). */
+int64_t mm_ba_build_pairs(int F, int P, int64_t O, const int32_t *fi, const int32_t *pi, const int32_t *pt_ptr,
+                          const int32_t *pt_obs, const int32_t *cam_ptr, const int32_t *cam_obs, int span,
+                          int64_t *seg_ptr, int32_t *pair_o, int32_t *pair_o2, int64_t max_pairs);
 /* Host index build for BA: CSR of observations by point and by camera (stable). */
 int mm_ba_build_index(int F, int P, int64_t O, const int32_t *fi, const int32_t *pi, int32_t *pt_ptr /*[P+1]*/,
                       int32_t *pt_obs /*[O]*/, int32_t *cam_ptr /*[F+1]*/, int32_t *cam_obs /*[O]*/);
@@ -140,6 +146,14 @@ typedef struct mm_ba_problem {
     const double *obs;       /* dev [O,2] */
     const int32_t *pt_ptr, *pt_obs;   /* dev CSR by point  (mm_ba_build_index) */
     const int32_t *cam_ptr, *cam_obs; /* dev CSR by camera */
+    /* optional co-observation pair list (mm_ba_build_pairs) for the banded, bitwise reproducible Schur kernel;
+     * n_seg == 0 / NULL pointers select the general kernel */
+    int32_t cam_span;                 /* max over points of (largest - smallest observing camera index) */
+    int32_t reserved;
+    int64_t n_seg;                    /* number of NON-EMPTY block segments */
+    const int32_t *seg_ids;           /* dev [n_seg]   segment id = camera * (cam_span + 1) + (camera - camera2) */
+    const int64_t *seg_ptr;           /* dev [n_seg+1] offsets into the pair arrays */
+    const int32_t *pair_o, *pair_o2;  /* dev [n_pairs] */
 } mm_ba_problem;
 
 /* res [O,2] (may be NULL) ; cost2 [1] receives sum of squared residuals (caller halves it). */
@@ -158,18 +172,23 @@ int mm_ba_normal_eq(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, co
 int mm_ba_jvp(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, const double *pts, const double *wc,
               const double *wp, double *out);
 /* Reduced camera system.  Cd [P,6] = damped point blocks (C + reg*diag), Bd [F,6,6] damped camera blocks.
- * S [6F,6F] (full symmetric, row-major) = blockdiag(Bd) - sum_p E_p Cd_p^-1 E_p^T ;  v [6F] = gc - E Cd^-1 gp.
- * Cinv [P,6] receives Cd^-1 (upper triangle).  S and v are overwritten. */
+ * S [6F,6F] (row-major) = blockdiag(Bd) - sum_p E_p Cd_p^-1 E_p^T ;  v [6F] = gc - E Cd^-1 gp.
+ * Cinv [P,6] receives Cd^-1 (upper triangle).  S and v are overwritten.
+ * If the problem carries a co-observation pair list (mm_ba_build_pairs) the LOWER block band |i - j| <= cam_span of S
+ * is computed by an atomic-free, bitwise reproducible kernel and the rest of S is zero; otherwise a general kernel
+ * fills all of S (LDS f64 atomics, last bits vary from run to run). */
 int mm_ba_schur(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, const double *pts, const double *Bd,
                 const double *Cd, const double *gc, const double *gp, double *S, double *v, double *Cinv);
 /* dp [P,3] = Cinv (gp - E^T dc). */
 int mm_ba_backsub(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, const double *pts, const double *Cinv,
                   const double *gp, const double *dc /*dev [F,6]*/, double *dp);
-/* Dense SPD solve A x = b by blocked Cholesky (f64 MFMA trailing updates).  A [n,n] row-major, lower triangle is
- * overwritten by L; b is overwritten by x.  info [1] dev int32: 0 ok, k>0 = non-positive pivot at column k. */
+/* SPD solve A x = b by blocked Cholesky (f64 MFMA trailing updates).  A [n,n] row-major, lower triangle is
+ * overwritten by L; b [nrhs,n] is overwritten by x.  half_bandwidth: A[i][j] == 0 whenever i - j > half_bandwidth
+ * (pass n for a dense matrix); the factorisation and the substitutions skip blocks outside the band.
+ * info [1] dev int32: 0 ok, k>0 = non-positive pivot at column k. */
 size_t mm_chol_workspace_bytes(int n);
-int mm_chol_solve(mm_ctx *ctx, double *A /*dev*/, int n, double *b /*dev*/, int nrhs, int32_t *info /*dev*/,
-                  void *ws, size_t ws_bytes);
+int mm_chol_solve(mm_ctx *ctx, double *A /*dev*/, int n, double *b /*dev*/, int nrhs, int half_bandwidth,
+                  int32_t *info /*dev*/, void *ws, size_t ws_bytes);
 
 #ifdef __cplusplus
 }

@@ -30,7 +30,9 @@ class OrbParams(C.Structure):
 
 class BAProblem(C.Structure):
     _fields_ = [("F", C.c_int32), ("P", C.c_int32), ("O", C.c_int64), ("K", vp), ("fi", vp), ("pi", vp),
-                ("obs", vp), ("pt_ptr", vp), ("pt_obs", vp), ("cam_ptr", vp), ("cam_obs", vp)]
+                ("obs", vp), ("pt_ptr", vp), ("pt_obs", vp), ("cam_ptr", vp), ("cam_obs", vp),
+                ("cam_span", C.c_int32), ("reserved", C.c_int32), ("n_seg", C.c_int64), ("seg_ids", vp),
+                ("seg_ptr", vp), ("pair_o", vp), ("pair_o2", vp)]
 
 
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header.
@@ -58,6 +60,8 @@ SIGNATURES = {
     "mm_orb_level_sizes": (C.c_int, [C.c_int, C.c_int, C.POINTER(OrbParams), c_i32p, c_i32p, c_i32p, c_f32p]),
     "mm_link_tracks_clip": (C.c_int64, [C.c_int, C.c_int, c_i32p, c_f32p, C.c_int, c_i32p, c_i32p, C.c_int64,
                                         C.c_int64, c_i64p, c_i32p, c_i32p, c_i64p]),
+    "mm_ba_build_pairs": (C.c_int64, [C.c_int, C.c_int, C.c_int64, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, C.c_int,
+                                      c_i64p, c_i32p, c_i32p, C.c_int64]),
     "mm_ba_build_index": (C.c_int, [C.c_int, C.c_int, C.c_int64, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p]),
     "mm_triangulate_dlt": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int64, vp]),
     "mm_ba_residual": (C.c_int, [vp, C.POINTER(BAProblem), vp, vp, vp, vp, vp, C.c_size_t]),
@@ -67,7 +71,7 @@ SIGNATURES = {
     "mm_ba_schur": (C.c_int, [vp, C.POINTER(BAProblem), vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "mm_ba_backsub": (C.c_int, [vp, C.POINTER(BAProblem), vp, vp, vp, vp, vp, vp]),
     "mm_chol_workspace_bytes": (C.c_size_t, [C.c_int]),
-    "mm_chol_solve": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, vp, vp, C.c_size_t]),
+    "mm_chol_solve": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, C.c_size_t]),
 }
 
 

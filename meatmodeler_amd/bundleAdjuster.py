@@ -238,6 +238,12 @@ class SchurTRF:
         cost = self._cost(cams, pts)
         if not np.isfinite(cost):
             raise ValueError("Residuals are not finite in the initial point.")
+        # band of the reduced camera system: |camera i - camera j| <= span  ->  |row - col| <= 6 span + 5
+        span = torch.tensor([float(pb.cam_span)], dtype=torch.float64, device=dev)
+        if self.allreduce is not None:
+            self.allreduce(span, op="max")
+        span_cams = int(span.item())
+        half_bw = 6 * span_cams + 5
         nfev, njev = 1, 1
         B, gc, C, gp = self._normal(cams, pts)
         diag_idx = torch.tensor([0, 3, 5], device=dev)
@@ -308,7 +314,7 @@ class SchurTRF:
                         f = torch.arange(pb.F, device=dev)
                         blk[f, :, f, :] -= (ws - 1) * Bd
                         v -= (ws - 1) * gc.reshape(-1)
-                info = ops.chol_solve(S, v, pb.ctx)
+                info = ops.chol_solve(S, v, pb.ctx, half_bandwidth=half_bw)
                 if int(info.item()) == 0:
                     break
                 reg_eff *= 100.0

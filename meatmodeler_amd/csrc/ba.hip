@@ -15,122 +15,9 @@
 // per observation against ~350 f64 flops — HBM-bound on MI355X (f64 ridge ~12 flop/B).  Reductions are segmented
 // (CSR by point / by camera, built once on the host by mm_ba_build_index) and atomic-free, so B, C, g and the cost
 // are bitwise reproducible; only the Schur scatter into S uses f64 atomics.
-#include "mm_common.h"
+#include "ba_eval.h"
 
 namespace {
-
-struct Proj {
-    double r0, r1;          // residual
-    double Jc[2][6];        // d r / d (rvec, tvec)
-    double Jp[2][3];        // d r / d X
-};
-
-template <bool WANT_JC, bool WANT_JP>
-__device__ __forceinline__ void ba_eval(const double *__restrict__ cam, const double *__restrict__ Xp,
-                                        const double *__restrict__ K, double ox, double oy, Proj &o) {
-    const double rx = cam[0], ry = cam[1], rz = cam[2];
-    const double X0 = Xp[0], X1 = Xp[1], X2 = Xp[2];
-    const double th2 = rx * rx + ry * ry + rz * rz;
-    double c, a, b, a1 = 0, b1 = 0;
-    if (th2 < 1e-4) {
-        c = cos(sqrt(th2));
-        a = 1.0 + th2 * (-1.0 / 6 + th2 * (1.0 / 120 - th2 * (1.0 / 5040)));
-        b = 0.5 + th2 * (-1.0 / 24 + th2 * (1.0 / 720 - th2 * (1.0 / 40320)));
-        if (WANT_JC) {
-            a1 = -1.0 / 3 + th2 * (1.0 / 30 + th2 * (-1.0 / 840 + th2 * (1.0 / 45360)));
-            b1 = -1.0 / 12 + th2 * (1.0 / 180 + th2 * (-1.0 / 6720 + th2 * (1.0 / 453600)));
-        }
-    } else {
-        const double th = sqrt(th2);
-        double s;
-        sincos(th, &s, &c);
-        const double sh = sin(0.5 * th);
-        const double omc = 2.0 * sh * sh;  // 1 - cos, without cancellation
-        a = s / th;
-        b = omc / th2;
-        if (WANT_JC) {
-            a1 = (th * c - s) / (th2 * th);
-            b1 = (th * s - 2.0 * omc) / (th2 * th2);
-        }
-    }
-    // r x X and r.X
-    const double cx0 = ry * X2 - rz * X1, cx1 = rz * X0 - rx * X2, cx2 = rx * X1 - ry * X0;
-    const double rdx = rx * X0 + ry * X1 + rz * X2;
-    const double Xr0 = c * X0 + a * cx0 + b * rdx * rx;
-    const double Xr1 = c * X1 + a * cx1 + b * rdx * ry;
-    const double Xr2 = c * X2 + a * cx2 + b * rdx * rz;
-    const double Y0 = Xr0 + cam[3], Y1 = Xr1 + cam[4], Y2 = Xr2 + cam[5];
-    const double u0 = K[0] * Y0 + K[1] * Y1 + K[2] * Y2;
-    const double u1 = K[3] * Y0 + K[4] * Y1 + K[5] * Y2;
-    const double u2 = K[6] * Y0 + K[7] * Y1 + K[8] * Y2;
-    const double p0 = u0 / u2, p1 = u1 / u2;
-    o.r0 = p0 - ox;
-    o.r1 = p1 - oy;
-    if (!WANT_JC && !WANT_JP) return;
-    const double iz = 1.0 / u2;
-    double M[2][3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        M[0][j] = (K[j] - p0 * K[6 + j]) * iz;
-        M[1][j] = (K[3 + j] - p1 * K[6 + j]) * iz;
-    }
-    if (WANT_JC) {
-        // common vector  w = -a X + a1 (r x X) + b1 (r.X) r
-        const double w0 = -a * X0 + a1 * cx0 + b1 * rdx * rx;
-        const double w1 = -a * X1 + a1 * cx1 + b1 * rdx * ry;
-        const double w2 = -a * X2 + a1 * cx2 + b1 * rdx * rz;
-        const double rr[3] = {rx, ry, rz};
-        const double XX[3] = {X0, X1, X2};
-        // e_k x X
-        const double ex[3][3] = {{0.0, -X2, X1}, {X2, 0.0, -X0}, {-X1, X0, 0.0}};
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            double d0 = rr[k] * w0 + a * ex[k][0] + b * XX[k] * rx;
-            double d1 = rr[k] * w1 + a * ex[k][1] + b * XX[k] * ry;
-            double d2 = rr[k] * w2 + a * ex[k][2] + b * XX[k] * rz;
-            if (k == 0) d0 += b * rdx;
-            if (k == 1) d1 += b * rdx;
-            if (k == 2) d2 += b * rdx;
-            o.Jc[0][k] = M[0][0] * d0 + M[0][1] * d1 + M[0][2] * d2;
-            o.Jc[1][k] = M[1][0] * d0 + M[1][1] * d1 + M[1][2] * d2;
-            o.Jc[0][3 + k] = M[0][k];
-            o.Jc[1][3 + k] = M[1][k];
-        }
-    }
-    if (WANT_JP) {
-        // R = c I + a [r]x + b r r^T
-        const double R[3][3] = {{c + b * rx * rx, -a * rz + b * rx * ry, a * ry + b * rx * rz},
-                                {a * rz + b * ry * rx, c + b * ry * ry, -a * rx + b * ry * rz},
-                                {-a * ry + b * rz * rx, a * rx + b * rz * ry, c + b * rz * rz}};
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            o.Jp[0][k] = M[0][0] * R[0][k] + M[0][1] * R[1][k] + M[0][2] * R[2][k];
-            o.Jp[1][k] = M[1][0] * R[0][k] + M[1][1] * R[1][k] + M[1][2] * R[2][k];
-        }
-    }
-}
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
-
-// Deterministic workgroup sum (fixed tree); result valid in thread 0.
-template <int THREADS>
-__device__ __forceinline__ double block_sum(double v, double *sm) {
-    v = wave_sum(v);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    __syncthreads();
-    if (lane == 0) sm[w] = v;
-    __syncthreads();
-    double t = 0;
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int i = 0; i < THREADS / 64; ++i) t += sm[i];
-    }
-    return t;
-}
 
 // ---- residual + cost ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ba_residual_kernel(mm_ba_problem pb, const double *__restrict__ cams,
@@ -299,143 +186,6 @@ __global__ __launch_bounds__(256) void ba_jvp_kernel(mm_ba_problem pb, const dou
     out[2 * o + 1] = y1;
 }
 
-// ---- Schur complement ------------------------------------------------------------------------------------------------
-// S <- blockdiag(Bd), v <- gc
-__global__ __launch_bounds__(256) void schur_init_kernel(int F, const double *__restrict__ Bd,
-                                                         const double *__restrict__ gc, double *__restrict__ S,
-                                                         double *__restrict__ v) {
-    const size_t n = (size_t)F * 6;
-    const size_t total = n * n;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        size_t r = i / n, c = i % n;
-        size_t fr = r / 6, fc = c / 6;
-        S[i] = (fr == fc) ? Bd[fr * 36 + (r % 6) * 6 + (c % 6)] : 0.0;
-        if (i < n) v[i] = gc[i];
-    }
-}
-
-// Cinv = Cd^-1 (3x3 symmetric, upper triangle storage xx,xy,xz,yy,yz,zz)
-__global__ __launch_bounds__(256) void point_inverse_kernel(int P, const double *__restrict__ Cd,
-                                                            double *__restrict__ Cinv) {
-    int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= P) return;
-    const double *c = Cd + (size_t)p * 6;
-    const double a = c[0], b = c[1], d = c[2], e = c[3], f = c[4], g = c[5];
-    const double m00 = e * g - f * f, m01 = d * f - b * g, m02 = b * f - d * e;
-    const double det = a * m00 + b * m01 + d * m02;
-    const double id = 1.0 / det;
-    double *o = Cinv + (size_t)p * 6;
-    o[0] = m00 * id;
-    o[1] = m01 * id;
-    o[2] = m02 * id;
-    o[3] = (a * g - d * d) * id;
-    o[4] = (b * d - a * f) * id;
-    o[5] = (a * e - b * b) * id;
-}
-
-// One wave per point.  Lanes first build E_i = Jc_i^T Jp_i and Y_i = E_i Cinv for a tile of the point's observations
-// in LDS, then the wave spreads the (i, j) camera-pair 6x6 blocks  -Y_i E_j^T  over its lanes and adds them into the
-// LOWER block triangle of S with f64 atomics; v gets  -Y_i gp.
-constexpr int SCH_TILE = 16;
-constexpr int SCH_WAVES = 4;
-
-__global__ __launch_bounds__(64 * SCH_WAVES) void schur_accum_kernel(mm_ba_problem pb, const double *__restrict__ cams,
-                                                                     const double *__restrict__ pts,
-                                                                     const double *__restrict__ Cinv,
-                                                                     const double *__restrict__ gp,
-                                                                     double *__restrict__ S, double *__restrict__ v) {
-    __shared__ double Ks[9];
-    __shared__ double Ei[SCH_WAVES][SCH_TILE][18], Yi[SCH_WAVES][SCH_TILE][18], Ej[SCH_WAVES][SCH_TILE][18];
-    __shared__ int fI[SCH_WAVES][SCH_TILE], fJ[SCH_WAVES][SCH_TILE];
-    if (threadIdx.x < 9) Ks[threadIdx.x] = pb.K[threadIdx.x];
-    __syncthreads();
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const size_t n = (size_t)pb.F * 6;
-    for (int p = blockIdx.x * SCH_WAVES + w; p < pb.P; p += gridDim.x * SCH_WAVES) {
-        const int e0 = pb.pt_ptr[p], e1 = pb.pt_ptr[p + 1];
-        const double *Xp = pts + (size_t)p * 3;
-        const double *ci = Cinv + (size_t)p * 6;
-        const double q00 = ci[0], q01 = ci[1], q02 = ci[2], q11 = ci[3], q12 = ci[4], q22 = ci[5];
-        const double g0 = gp[(size_t)p * 3], g1 = gp[(size_t)p * 3 + 1], g2 = gp[(size_t)p * 3 + 2];
-        for (int it = e0; it < e1; it += SCH_TILE) {
-            const int ni = min(SCH_TILE, e1 - it);
-            // --- tile i: E, Y
-            if (lane < ni) {
-                int o = pb.pt_obs[it + lane];
-                int f = pb.fi[o];
-                Proj pr;
-                ba_eval<true, true>(cams + (size_t)f * 6, Xp, Ks, pb.obs[2 * (size_t)o], pb.obs[2 * (size_t)o + 1], pr);
-                fI[w][lane] = f;
-                double yg[6];
-#pragma unroll
-                for (int a = 0; a < 6; ++a) {
-                    double ea0 = pr.Jc[0][a] * pr.Jp[0][0] + pr.Jc[1][a] * pr.Jp[1][0];
-                    double ea1 = pr.Jc[0][a] * pr.Jp[0][1] + pr.Jc[1][a] * pr.Jp[1][1];
-                    double ea2 = pr.Jc[0][a] * pr.Jp[0][2] + pr.Jc[1][a] * pr.Jp[1][2];
-                    Ei[w][lane][a * 3 + 0] = ea0;
-                    Ei[w][lane][a * 3 + 1] = ea1;
-                    Ei[w][lane][a * 3 + 2] = ea2;
-                    double y0 = ea0 * q00 + ea1 * q01 + ea2 * q02;
-                    double y1 = ea0 * q01 + ea1 * q11 + ea2 * q12;
-                    double y2 = ea0 * q02 + ea1 * q12 + ea2 * q22;
-                    Yi[w][lane][a * 3 + 0] = y0;
-                    Yi[w][lane][a * 3 + 1] = y1;
-                    Yi[w][lane][a * 3 + 2] = y2;
-                    yg[a] = y0 * g0 + y1 * g1 + y2 * g2;
-                }
-#pragma unroll
-                for (int a = 0; a < 6; ++a) unsafeAtomicAdd(&v[(size_t)f * 6 + a], -yg[a]);
-            }
-            for (int jt = it; jt < e1; jt += SCH_TILE) {
-                const int nj = min(SCH_TILE, e1 - jt);
-                // --- tile j: E  (the diagonal tile reuses tile i)
-                if (jt != it) {
-                    if (lane < nj) {
-                        int o = pb.pt_obs[jt + lane];
-                        int f = pb.fi[o];
-                        Proj pr;
-                        ba_eval<true, true>(cams + (size_t)f * 6, Xp, Ks, pb.obs[2 * (size_t)o],
-                                            pb.obs[2 * (size_t)o + 1], pr);
-                        fJ[w][lane] = f;
-#pragma unroll
-                        for (int a = 0; a < 6; ++a) {
-#pragma unroll
-                            for (int k = 0; k < 3; ++k)
-                                Ej[w][lane][a * 3 + k] = pr.Jc[0][a] * pr.Jp[0][k] + pr.Jc[1][a] * pr.Jp[1][k];
-                        }
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const bool diag = (jt == it);
-                const int nent = ni * nj * 36;
-                for (int x = lane; x < nent; x += 64) {
-                    const int ab = x % 36, pairi = x / 36;
-                    const int i = pairi / nj, j = pairi % nj;
-                    if (diag && j < i) continue;  // unordered pairs once
-                    const int a = ab / 6, b2 = ab % 6;
-                    const double *Y = Yi[w][i];
-                    const double *E = diag ? Ei[w][j] : Ej[w][j];
-                    const int fi_ = fI[w][i], fj_ = diag ? fI[w][j] : fJ[w][j];
-                    const double val = -(Y[a * 3] * E[b2 * 3] + Y[a * 3 + 1] * E[b2 * 3 + 1] + Y[a * 3 + 2] * E[b2 * 3 + 2]);
-                    // block (fi, fj) entry (a, b);  keep the lower block triangle
-                    const bool same_obs = diag && (i == j);
-                    if (fi_ > fj_ || same_obs) {
-                        unsafeAtomicAdd(&S[((size_t)fi_ * 6 + a) * n + (size_t)fj_ * 6 + b2], val);
-                    } else if (fi_ < fj_) {
-                        unsafeAtomicAdd(&S[((size_t)fj_ * 6 + b2) * n + (size_t)fi_ * 6 + a], val);
-                    } else {  // two different observations of the point in the same camera: M + M^T on the diagonal block
-                        unsafeAtomicAdd(&S[((size_t)fi_ * 6 + a) * n + (size_t)fj_ * 6 + b2], val);
-                        unsafeAtomicAdd(&S[((size_t)fj_ * 6 + b2) * n + (size_t)fi_ * 6 + a], val);
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-    }
-}
-
 // ---- back-substitution: dp = Cinv (gp - sum_o Jp_o^T (Jc_o dc[f_o])) ------------------------------------------------
 __global__ __launch_bounds__(256) void ba_backsub_kernel(mm_ba_problem pb, const double *__restrict__ cams,
                                                          const double *__restrict__ pts,
@@ -534,24 +284,6 @@ int mm_ba_jvp(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, const do
     if (!cams || !pts || !out) return mm_fail(ctx, MM_ERR_ARG, "mm_ba_jvp: null pointer");
     if (pb->O == 0) return MM_OK;
     MM_LAUNCH(ctx, "ba_jvp_kernel", ba_jvp_kernel, dim3((unsigned)((pb->O + 255) / 256)), dim3(256), 0, *pb, cams, pts, wc, wp, out);
-    return MM_OK;
-}
-
-int mm_ba_schur(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, const double *pts, const double *Bd,
-                const double *Cd, const double *gc, const double *gp, double *S, double *v, double *Cinv) {
-    int rc = check_pb(ctx, pb, "mm_ba_schur");
-    if (rc) return rc;
-    if (!cams || !pts || !Bd || !Cd || !gc || !gp || !S || !v || !Cinv || !pb->pt_ptr || !pb->pt_obs)
-        return mm_fail(ctx, MM_ERR_ARG, "mm_ba_schur: null pointer");
-    if (pb->F == 0) return MM_OK;
-    size_t total = (size_t)pb->F * 6 * pb->F * 6;
-    int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-    MM_LAUNCH(ctx, "schur_init_kernel", schur_init_kernel, dim3(blocks), dim3(256), 0, pb->F, Bd, gc, S, v);
-    if (pb->P == 0) return MM_OK;
-    MM_LAUNCH(ctx, "point_inverse_kernel", point_inverse_kernel, dim3((pb->P + 255) / 256), dim3(256), 0, pb->P, Cd, Cinv);
-    int wgs = (pb->P + SCH_WAVES - 1) / SCH_WAVES;
-    if (wgs > 8192) wgs = 8192;
-    MM_LAUNCH(ctx, "schur_accum_kernel", schur_accum_kernel, dim3(wgs), dim3(64 * SCH_WAVES), 0, *pb, cams, pts, Cinv, gp, S, v);
     return MM_OK;
 }
 

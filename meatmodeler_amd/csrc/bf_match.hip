@@ -12,12 +12,11 @@
 //  * ties resolve to the lowest train index because the index is the low part of the key.
 //  * small launches split the train range over blockIdx.y and merge partial top-2 keys in a second kernel.
 #include "mm_common.h"
+#include <cstdlib>
 
 namespace {
 
 constexpr int BF_THREADS = 256;
-constexpr int BF_QPL = 2;                       // queries per lane
-constexpr int BF_QTILE = BF_THREADS * BF_QPL;   // queries per workgroup
 constexpr uint32_t BF_NONE = 0xFFFFFFFFu;
 constexpr int BF_IDX_BITS = 20;
 
@@ -48,6 +47,7 @@ __device__ __forceinline__ void top2_insert(uint32_t key, uint32_t &b0, uint32_t
     b1 = min(b1, hi);
 }
 
+template <int BF_QPL, int BF_UNROLL>
 __global__ __launch_bounds__(BF_THREADS) void bf_knn2_kernel(
     const uint8_t *__restrict__ q, const int32_t *__restrict__ nq_dev, int nq_cap, size_t q_stride,
     const uint8_t *__restrict__ t, const int32_t *__restrict__ nt_dev, int nt_cap, size_t t_stride, int n_splits,
@@ -56,6 +56,7 @@ __global__ __launch_bounds__(BF_THREADS) void bf_knn2_kernel(
     const int split = blockIdx.y;
     int nq = nq_dev ? min(nq_dev[pair], nq_cap) : nq_cap;
     int nt = nt_dev ? min(nt_dev[pair], nt_cap) : nt_cap;
+    constexpr int BF_QTILE = BF_THREADS * BF_QPL;  // queries per workgroup
     const int qbase = blockIdx.x * BF_QTILE;
     if (qbase >= nq) return;  // workgroup-uniform
 
@@ -74,9 +75,9 @@ __global__ __launch_bounds__(BF_THREADS) void bf_knn2_kernel(
         qa[u][4] = hi.x; qa[u][5] = hi.y; qa[u][6] = hi.z; qa[u][7] = hi.w;
     }
 
-    // train range of this split (multiples of 4 so the unrolled body needs one tail only at the very end)
+    // train range of this split (multiples of the unroll so the unrolled body needs one tail only at the very end)
     int chunk = (nt + n_splits - 1) / n_splits;
-    chunk = (chunk + 3) & ~3;
+    chunk = (chunk + BF_UNROLL - 1) / BF_UNROLL * BF_UNROLL;
     const int j0 = split * chunk;
     const int j1 = min(nt, j0 + chunk);
 
@@ -86,12 +87,12 @@ __global__ __launch_bounds__(BF_THREADS) void bf_knn2_kernel(
 
     const uint4 *__restrict__ tp = reinterpret_cast<const uint4 *>(t + (size_t)pair * t_stride);
     int j = j0;
-    for (; j + 4 <= j1; j += 4) {
-        uint4 tv[8];
+    for (; j + BF_UNROLL <= j1; j += BF_UNROLL) {
+        uint4 tv[2 * BF_UNROLL];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) tv[k] = tp[2 * j + k];  // wave-uniform address -> scalar loads
+        for (int k = 0; k < 2 * BF_UNROLL; ++k) tv[k] = tp[2 * j + k];  // wave-uniform address -> scalar loads
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < BF_UNROLL; ++k) {
 #pragma unroll
             for (int u = 0; u < BF_QPL; ++u) {
                 uint32_t d = ham256(qa[u], tv[2 * k], tv[2 * k + 1]);
@@ -187,7 +188,17 @@ __global__ __launch_bounds__(256) void ratio_filter_kernel(const int32_t *__rest
     if (threadIdx.x == 0) m_out[pair] = base_s;
 }
 
+// queries per lane: 2 amortises the scalar train loads over two descriptor pairs; small launches use 1 to get more waves.
+// MM_BF_VARIANT=<qpl><unroll> (e.g. 24, 28, 44, 14) overrides for tuning runs.
+int bf_variant(int n_pairs, int nq_cap) {
+    const char *e = getenv("MM_BF_VARIANT");
+    const int forced = e ? atoi(e) : 0;
+    if (forced) return forced;
+    return ((long)n_pairs * nq_cap >= 262144) ? 24 : 14;
+}
+
 int bf_choose_splits(int n_pairs, int nq_cap, int nt_cap) {
+    const int BF_QTILE = BF_THREADS * (bf_variant(n_pairs, nq_cap) / 10);
     long waves = (long)n_pairs * ((nq_cap + BF_QTILE - 1) / BF_QTILE) * (BF_THREADS / 64);
     if (waves <= 0) return 1;
     long s = (2048 + waves - 1) / waves;  // aim for >= 2 waves per SIMD on 256 CUs
@@ -222,8 +233,23 @@ int mm_bf_knn2_batched(mm_ctx *ctx, const uint8_t *q, const int32_t *nq, int nq_
     int s = bf_choose_splits(n_pairs, nq_cap, nt_cap);
     if (s > 1 && (!ws || ws_bytes < mm_bf_workspace_bytes(n_pairs, nq_cap, nt_cap)))
         return mm_fail(ctx, MM_ERR_WORKSPACE, "mm_bf_knn2_batched: workspace too small");
-    dim3 grid((nq_cap + BF_QTILE - 1) / BF_QTILE, s, n_pairs);
-    MM_LAUNCH(ctx, "bf_knn2_kernel", bf_knn2_kernel, grid, dim3(BF_THREADS), 0, q, nq, nq_cap, q_set_stride, t, nt, nt_cap, t_set_stride, s, (uint32_t *)ws, idx, dist);
+    const int var = bf_variant(n_pairs, nq_cap);
+    const int qtile = BF_THREADS * (var / 10);
+    dim3 grid((nq_cap + qtile - 1) / qtile, s, n_pairs);
+#define BF_GO(Q, U)                                                                                              \
+    MM_LAUNCH(ctx, "bf_knn2_kernel", (bf_knn2_kernel<Q, U>), grid, dim3(BF_THREADS), 0, q, nq, nq_cap, q_set_stride, t, \
+              nt, nt_cap, t_set_stride, s, (uint32_t *)ws, idx, dist)
+    switch (var) {
+        case 14: BF_GO(1, 4); break;
+        case 18: BF_GO(1, 8); break;
+        case 24: BF_GO(2, 4); break;
+        case 28: BF_GO(2, 8); break;
+        case 34: BF_GO(3, 4); break;
+        case 44: BF_GO(4, 4); break;
+        case 48: BF_GO(4, 8); break;
+        default: return mm_fail(ctx, MM_ERR_ARG, "mm_bf_knn2_batched: unknown MM_BF_VARIANT %d", var);
+    }
+#undef BF_GO
     if (s > 1) {
         dim3 g2((nq_cap + 255) / 256, n_pairs);
         MM_LAUNCH(ctx, "bf_merge_kernel", bf_merge_kernel, g2, dim3(256), 0, (const uint32_t *)ws, nq, nq_cap, s, idx, dist);

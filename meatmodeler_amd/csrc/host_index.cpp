@@ -8,17 +8,23 @@
 //   * a later match hitting the same track overwrites that track's new-frame coordinate (Track.update, track.py:17-19);
 //   * unmatched feature points spawn new tracks, appended after the surviving old ones in match order
 //     (processor.py:226-241); tracks not updated in a call are popped in list order (processor.py:233-238).
-// The O(M*T) scan of the reference becomes a hash join on the coordinate bit patterns.
+// The O(M*T) scan of the reference becomes a hash join on the coordinate bit patterns: observations are nodes of
+// per-track singly linked lists in one pool, the live list is rebuilt per keyframe, the join table is open-addressed.
 #include <cstdint>
 #include <cstring>
-#include <unordered_map>
 #include <vector>
 #include "../../include/meatmodeler.h"
 
 namespace {
 
-struct Obs {
+struct Node {
     int32_t frame, kp;
+    int64_t prev;  // previous observation of the same track (-1 = first)
+};
+
+struct TrackRec {
+    int64_t tail;  // last node
+    int32_t len;
 };
 
 inline uint64_t coord_key(const float *xy) {
@@ -27,6 +33,15 @@ inline uint64_t coord_key(const float *xy) {
     memcpy(&a, &x, 4);
     memcpy(&b, &y, 4);
     return ((uint64_t)a << 32) | b;
+}
+
+inline uint64_t mix(uint64_t k) {
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdULL;
+    k ^= k >> 33;
+    k *= 0xc4ceb9fe1a85ec53ULL;
+    k ^= k >> 33;
+    return k;
 }
 
 }  // namespace
@@ -38,50 +53,76 @@ int64_t mm_link_tracks_clip(int n_frames, int cap, const int32_t *kp_count, cons
                             int64_t *track_ptr, int32_t *obs_frame, int32_t *obs_kp, int64_t *n_obs_out) {
     if (n_frames < 0 || cap < 0 || mcap < 0 || !n_obs_out) return MM_ERR_ARG;
     if (n_frames > 1 && (!kp_count || !kp_xy || !match_count || !matches)) return MM_ERR_ARG;
-    std::vector<std::vector<Obs>> tracks;  // all tracks ever created
-    std::vector<int64_t> live, popped;     // indices into `tracks`
+    std::vector<Node> nodes;
+    std::vector<TrackRec> tracks;
+    std::vector<int64_t> live, next, popped, fresh;
     std::vector<uint8_t> updated;
-    std::unordered_map<uint64_t, int64_t> first_live;  // coordinate at prev frame -> position in `live`
+    std::vector<uint64_t> hkey;
+    std::vector<int32_t> hval;  // position in `live`, -1 = empty
+    int64_t total_matches = 0;
+    for (int k = 0; k + 1 < n_frames; ++k) total_matches += match_count[k] > 0 ? match_count[k] : 0;
+    nodes.reserve((size_t)total_matches * 2 + 16);
+    tracks.reserve((size_t)total_matches + 16);
     for (int k = 0; k + 1 < n_frames; ++k) {
         const int M = match_count[k];
         if (M < 0 || M > mcap) return MM_ERR_ARG;
-        first_live.clear();
-        first_live.reserve(live.size() * 2 + 16);
+        // join table: coordinate at frame k -> FIRST position in `live`
+        size_t tsz = 16;
+        while (tsz < live.size() * 2 + 2) tsz <<= 1;
+        hkey.assign(tsz, 0);
+        hval.assign(tsz, -1);
         for (size_t pos = 0; pos < live.size(); ++pos) {
-            const std::vector<Obs> &t = tracks[live[pos]];
-            // every live track was created or updated at frame k by construction; its coordinate there:
-            const Obs *at = nullptr;
-            for (auto it = t.rbegin(); it != t.rend(); ++it)
-                if (it->frame == k) {
-                    at = &*it;
+            const Node &tl = nodes[tracks[live[pos]].tail];  // every live track ends at frame k by construction
+            if (tl.frame != k) continue;
+            const uint64_t key = coord_key(kp_xy + ((size_t)k * cap + tl.kp) * 2);
+            size_t h = mix(key) & (tsz - 1);
+            bool present = false;
+            while (hval[h] >= 0) {
+                if (hkey[h] == key) {
+                    present = true;  // an earlier (lower position) track already owns this coordinate
                     break;
                 }
-            if (!at) continue;
-            uint64_t key = coord_key(kp_xy + ((size_t)k * cap + at->kp) * 2);
-            first_live.emplace(key, (int64_t)pos);  // emplace keeps the FIRST position
+                h = (h + 1) & (tsz - 1);
+            }
+            if (!present) {
+                hkey[h] = key;
+                hval[h] = (int32_t)pos;
+            }
         }
         updated.assign(live.size(), 0);
-        std::vector<int64_t> fresh;
+        fresh.clear();
         const int32_t *mk = matches + (size_t)k * mcap * 2;
         for (int m = 0; m < M; ++m) {
             const int q = mk[2 * m], tr = mk[2 * m + 1];
             if (q < 0 || q >= kp_count[k] || tr < 0 || tr >= kp_count[k + 1]) return MM_ERR_ARG;
-            uint64_t key = coord_key(kp_xy + ((size_t)k * cap + q) * 2);
-            auto hit = first_live.find(key);
-            if (hit != first_live.end()) {
-                std::vector<Obs> &t = tracks[live[hit->second]];
-                if (t.back().frame == k + 1)
-                    t.back().kp = tr;  // second update in the same call overwrites
-                else
-                    t.push_back(Obs{k + 1, tr});
-                updated[hit->second] = 1;
+            const uint64_t key = coord_key(kp_xy + ((size_t)k * cap + q) * 2);
+            size_t h = mix(key) & (tsz - 1);
+            int32_t pos = -1;
+            while (hval[h] >= 0) {
+                if (hkey[h] == key) {
+                    pos = hval[h];
+                    break;
+                }
+                h = (h + 1) & (tsz - 1);
+            }
+            if (pos >= 0) {
+                TrackRec &t = tracks[live[pos]];
+                if (nodes[t.tail].frame == k + 1) {
+                    nodes[t.tail].kp = tr;  // second update in the same call overwrites the coordinate
+                } else {
+                    nodes.push_back(Node{k + 1, tr, t.tail});
+                    t.tail = (int64_t)nodes.size() - 1;
+                    t.len++;
+                }
+                updated[pos] = 1;
             } else {
-                tracks.push_back(std::vector<Obs>{Obs{k, q}, Obs{k + 1, tr}});
+                nodes.push_back(Node{k, q, -1});
+                nodes.push_back(Node{k + 1, tr, (int64_t)nodes.size() - 1});
+                tracks.push_back(TrackRec{(int64_t)nodes.size() - 1, 2});
                 fresh.push_back((int64_t)tracks.size() - 1);
             }
         }
-        std::vector<int64_t> next;
-        next.reserve(live.size() + fresh.size());
+        next.clear();
         for (size_t pos = 0; pos < live.size(); ++pos) {
             if (updated[pos])
                 next.push_back(live[pos]);
@@ -93,22 +134,67 @@ int64_t mm_link_tracks_clip(int n_frames, int cap, const int32_t *kp_count, cons
     }
     popped.insert(popped.end(), live.begin(), live.end());
     int64_t n_obs = 0;
-    for (int64_t id : popped) n_obs += (int64_t)tracks[id].size();
+    for (int64_t id : popped) n_obs += tracks[id].len;
     *n_obs_out = n_obs;
     const int64_t n_tracks = (int64_t)popped.size();
     if (n_tracks > max_tracks || n_obs > max_obs) return MM_ERR_WORKSPACE;
     if (n_tracks > 0 && (!track_ptr || !obs_frame || !obs_kp)) return MM_ERR_ARG;
     int64_t o = 0;
     for (int64_t i = 0; i < n_tracks; ++i) {
+        const TrackRec &t = tracks[popped[i]];
         track_ptr[i] = o;
-        for (const Obs &ob : tracks[popped[i]]) {
-            obs_frame[o] = ob.frame;
-            obs_kp[o] = ob.kp;
-            ++o;
+        int64_t w = o + t.len - 1;  // walk the list backwards, fill forwards
+        for (int64_t nd = t.tail; nd >= 0; nd = nodes[nd].prev, --w) {
+            obs_frame[w] = nodes[nd].frame;
+            obs_kp[w] = nodes[nd].kp;
         }
+        o += t.len;
     }
     if (track_ptr) track_ptr[n_tracks] = o;
     return n_tracks;
+}
+
+// Co-observation pairs for the banded Schur kernel: every ordered pair (o, o2) of observations of one point with
+// camera(o2) <= camera(o), grouped by block segment s = camera(o) * (span + 1) + (camera(o) - camera(o2)).
+// Inside a segment the pairs appear in a fixed canonical order (camera CSR order of o, then point CSR order of o2),
+// which fixes the summation order of every entry of the reduced camera system.
+// Call with pair_o == NULL to get the number of pairs; seg_ptr has F * (span + 1) + 1 entries.
+int64_t mm_ba_build_pairs(int F, int P, int64_t O, const int32_t *fi, const int32_t *pi, const int32_t *pt_ptr,
+                          const int32_t *pt_obs, const int32_t *cam_ptr, const int32_t *cam_obs, int span,
+                          int64_t *seg_ptr, int32_t *pair_o, int32_t *pair_o2, int64_t max_pairs) {
+    if (F < 0 || P < 0 || O < 0 || span < 0 || !seg_ptr) return MM_ERR_ARG;
+    if (O > 0 && (!fi || !pi || !pt_ptr || !pt_obs || !cam_ptr || !cam_obs)) return MM_ERR_ARG;
+    const int64_t nseg = (int64_t)F * (span + 1);
+    for (int64_t s = 0; s <= nseg; ++s) seg_ptr[s] = 0;
+    for (int i = 0; i < F; ++i)
+        for (int e = cam_ptr[i]; e < cam_ptr[i + 1]; ++e) {
+            const int p = pi[cam_obs[e]];
+            for (int e2 = pt_ptr[p]; e2 < pt_ptr[p + 1]; ++e2) {
+                const int d = i - fi[pt_obs[e2]];
+                if (d < 0) continue;
+                if (d > span) return MM_ERR_ARG;  // span too small for this problem
+                ++seg_ptr[(int64_t)i * (span + 1) + d + 1];
+            }
+        }
+    for (int64_t s = 0; s < nseg; ++s) seg_ptr[s + 1] += seg_ptr[s];
+    const int64_t n = seg_ptr[nseg];
+    if (!pair_o || !pair_o2) return n;
+    if (n > max_pairs) return MM_ERR_WORKSPACE;
+    std::vector<int64_t> cur(seg_ptr, seg_ptr + nseg);
+    for (int i = 0; i < F; ++i)
+        for (int e = cam_ptr[i]; e < cam_ptr[i + 1]; ++e) {
+            const int o = cam_obs[e];
+            const int p = pi[o];
+            for (int e2 = pt_ptr[p]; e2 < pt_ptr[p + 1]; ++e2) {
+                const int o2 = pt_obs[e2];
+                const int d = i - fi[o2];
+                if (d < 0) continue;
+                const int64_t w = cur[(int64_t)i * (span + 1) + d]++;
+                pair_o[w] = o;
+                pair_o2[w] = o2;
+            }
+        }
+    return n;
 }
 
 int mm_ba_build_index(int F, int P, int64_t O, const int32_t *fi, const int32_t *pi, int32_t *pt_ptr, int32_t *pt_obs,

@@ -193,10 +193,15 @@ __global__ __launch_bounds__(256) void orb_fast_kernel(OrbGeom g, const uint8_t 
         Sc[sr][sc] = (uint8_t)s;
     }
     __syncthreads();
-    const int seg = b * g.nlevels + l;
-    int32_t *cnt = reinterpret_cast<int32_t *>(ws + g.cnt_off) + seg;
-    int32_t *hist = reinterpret_cast<int32_t *>(ws + g.hist_off) + (size_t)seg * 256;
-    uint32_t *cand = reinterpret_cast<uint32_t *>(ws + g.cand_off[l]) + (size_t)b * g.cand_cap[l];
+    // Survivors of the strict 3x3 NMS are collected in LDS first (at most 1 in 4 pixels can survive), so the tile costs
+    // ONE returning global atomic on the per-(frame, level) counter plus one add per occupied histogram bin, instead of
+    // one of each per key point on the same few words.
+    __shared__ uint32_t keys[FT_H * FT_W / 4 + 8];
+    __shared__ int lhist[256];
+    __shared__ int lcount, lbase;
+    lhist[threadIdx.x] = 0;
+    if (threadIdx.x == 0) lcount = 0;
+    __syncthreads();
     for (int e = threadIdx.x; e < FT_H * FT_W; e += 256) {
         const int r = e / FT_W, c = e % FT_W;
         const int x = ox + c, y = oy + r;
@@ -206,10 +211,23 @@ __global__ __launch_bounds__(256) void orb_fast_kernel(OrbGeom g, const uint8_t 
         const bool keep = s > Sc[r][c] && s > Sc[r][c + 1] && s > Sc[r][c + 2] && s > Sc[r + 1][c] &&
                           s > Sc[r + 1][c + 2] && s > Sc[r + 2][c] && s > Sc[r + 2][c + 1] && s > Sc[r + 2][c + 2];
         if (!keep) continue;
-        const int slot = atomicAdd(cnt, 1);
-        if (slot < g.cand_cap[l]) cand[slot] = ((uint32_t)(255 - s) << 24) | ((uint32_t)y << 12) | (uint32_t)x;
-        atomicAdd(&hist[255 - s], 1);
+        const int slot = atomicAdd(&lcount, 1);
+        keys[slot] = ((uint32_t)(255 - s) << 24) | ((uint32_t)y << 12) | (uint32_t)x;
+        atomicAdd(&lhist[255 - s], 1);
     }
+    __syncthreads();
+    const int nloc = lcount;
+    if (nloc == 0) return;
+    const int seg = b * g.nlevels + l;
+    int32_t *cnt = reinterpret_cast<int32_t *>(ws + g.cnt_off) + seg;
+    int32_t *hist = reinterpret_cast<int32_t *>(ws + g.hist_off) + (size_t)seg * 256;
+    uint32_t *cand = reinterpret_cast<uint32_t *>(ws + g.cand_off[l]) + (size_t)b * g.cand_cap[l];
+    if (threadIdx.x == 0) lbase = atomicAdd(cnt, nloc);
+    if (lhist[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lhist[threadIdx.x]);
+    __syncthreads();
+    const int base = lbase;
+    for (int e = threadIdx.x; e < nloc; e += 256)
+        if (base + e < g.cand_cap[l]) cand[base + e] = keys[e];
 }
 
 // ---- exact selection of the 2n smallest keys per (frame, level) ----------------------------------------------------------

@@ -1,0 +1,229 @@
+// Reduced camera system (Schur complement of the point blocks), gfx950, f64.
+//
+//   S = blockdiag(Bd) - sum_p E_p Cd_p^-1 E_p^T ,   v = gc - sum_p E_p Cd_p^-1 gp_p ,   E_o = Jc_o^T Jp_o (6x3)
+//
+// One workgroup owns one block ROW of S (camera i) x one window of SR_WIN column blocks.  It walks the observations of
+// camera i (CSR by camera); for each (point p) it forms Y = E_o Cd_p^-1 and then visits the other observations of p
+// (CSR by point, contiguous) whose camera lies in the window, re-evaluates their E and accumulates -Y E_2^T into a
+// 6 x (6*SR_WIN) accumulator held in LDS (f64 LDS atomics, ds_add_f64).  The finished row strip is written with plain
+// coalesced stores: S needs no zero fill, no global atomics and both triangles come out filled.  Every (o, o2) pair is
+// evaluated from both of its rows — 2x the flops of a symmetric scheme, but the flops are free here: the kernel is bound
+// by the LDS atomic rate, and the global-atomic version it replaces ran 16x slower (profiles/r01_*).
+#include "ba_eval.h"
+
+namespace {
+
+constexpr int SR_WIN = 256;  // cameras per column window: 6 x 1536 doubles = 73,728 B of LDS -> 2 workgroups per CU
+
+// Cinv = Cd^-1 (3x3 symmetric, upper triangle storage xx,xy,xz,yy,yz,zz)
+__global__ __launch_bounds__(256) void point_inverse_kernel(int P, const double *__restrict__ Cd,
+                                                            double *__restrict__ Cinv) {
+    int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const double *c = Cd + (size_t)p * 6;
+    const double a = c[0], b = c[1], d = c[2], e = c[3], f = c[4], g = c[5];
+    const double m00 = e * g - f * f, m01 = d * f - b * g, m02 = b * f - d * e;
+    const double det = a * m00 + b * m01 + d * m02;
+    const double id = 1.0 / det;
+    double *o = Cinv + (size_t)p * 6;
+    o[0] = m00 * id;
+    o[1] = m01 * id;
+    o[2] = m02 * id;
+    o[3] = (a * g - d * d) * id;
+    o[4] = (b * d - a * f) * id;
+    o[5] = (a * e - b * b) * id;
+}
+
+__global__ __launch_bounds__(256) void schur_rows_kernel(mm_ba_problem pb, const double *__restrict__ cams,
+                                                         const double *__restrict__ pts, const double *__restrict__ Bd,
+                                                         const double *__restrict__ Cinv, const double *__restrict__ gc,
+                                                         const double *__restrict__ gp, double *__restrict__ S,
+                                                         double *__restrict__ v) {
+    __shared__ double acc[6][SR_WIN * 6];
+    __shared__ double Ks[9];
+    __shared__ double cs[6];
+    __shared__ double sm[4];
+    const int i = blockIdx.x;
+    const int w0 = blockIdx.y * SR_WIN;
+    const int wn = min(SR_WIN, pb.F - w0);
+    const size_t n = (size_t)pb.F * 6;
+    for (int e = threadIdx.x; e < 6 * SR_WIN * 6; e += 256) (&acc[0][0])[e] = 0.0;
+    if (threadIdx.x < 9) Ks[threadIdx.x] = pb.K[threadIdx.x];
+    if (threadIdx.x < 6) cs[threadIdx.x] = cams[(size_t)i * 6 + threadIdx.x];
+    __syncthreads();
+    double vg[6] = {0, 0, 0, 0, 0, 0};
+    for (int e = pb.cam_ptr[i] + threadIdx.x; e < pb.cam_ptr[i + 1]; e += 256) {
+        const int o = pb.cam_obs[e];
+        const int p = pb.pi[o];
+        const double *Xp = pts + (size_t)p * 3;
+        Proj pr;
+        ba_eval<true, true>(cs, Xp, Ks, pb.obs[2 * (size_t)o], pb.obs[2 * (size_t)o + 1], pr);
+        const double *ci = Cinv + (size_t)p * 6;
+        const double q00 = ci[0], q01 = ci[1], q02 = ci[2], q11 = ci[3], q12 = ci[4], q22 = ci[5];
+        double Y[6][3];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            const double e0 = pr.Jc[0][a] * pr.Jp[0][0] + pr.Jc[1][a] * pr.Jp[1][0];
+            const double e1 = pr.Jc[0][a] * pr.Jp[0][1] + pr.Jc[1][a] * pr.Jp[1][1];
+            const double e2 = pr.Jc[0][a] * pr.Jp[0][2] + pr.Jc[1][a] * pr.Jp[1][2];
+            Y[a][0] = e0 * q00 + e1 * q01 + e2 * q02;
+            Y[a][1] = e0 * q01 + e1 * q11 + e2 * q12;
+            Y[a][2] = e0 * q02 + e1 * q12 + e2 * q22;
+        }
+        if (blockIdx.y == 0) {
+            const double g0 = gp[(size_t)p * 3], g1 = gp[(size_t)p * 3 + 1], g2 = gp[(size_t)p * 3 + 2];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) vg[a] += Y[a][0] * g0 + Y[a][1] * g1 + Y[a][2] * g2;
+        }
+        for (int e2i = pb.pt_ptr[p]; e2i < pb.pt_ptr[p + 1]; ++e2i) {
+            const int o2 = pb.pt_obs[e2i];
+            const int f2 = pb.fi[o2];
+            if (f2 < w0 || f2 >= w0 + wn) continue;
+            Proj p2;
+            ba_eval<true, true>(cams + (size_t)f2 * 6, Xp, Ks, pb.obs[2 * (size_t)o2], pb.obs[2 * (size_t)o2 + 1], p2);
+            double *dst = &acc[0][(f2 - w0) * 6];
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                const double e0 = p2.Jc[0][b] * p2.Jp[0][0] + p2.Jc[1][b] * p2.Jp[1][0];
+                const double e1 = p2.Jc[0][b] * p2.Jp[0][1] + p2.Jc[1][b] * p2.Jp[1][1];
+                const double e2 = p2.Jc[0][b] * p2.Jp[0][2] + p2.Jc[1][b] * p2.Jp[1][2];
+#pragma unroll
+                for (int a = 0; a < 6; ++a)
+                    atomicAdd(dst + a * (SR_WIN * 6) + b, Y[a][0] * e0 + Y[a][1] * e1 + Y[a][2] * e2);
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 6 * wn * 6; e += 256) {
+        const int a = e / (wn * 6), c = e % (wn * 6);
+        const int col = w0 * 6 + c;
+        double val = -acc[a][c];
+        if (col / 6 == i) val += Bd[(size_t)i * 36 + a * 6 + (col % 6)];
+        S[((size_t)i * 6 + a) * n + col] = val;
+    }
+    if (blockIdx.y == 0) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            const double s = block_sum<256>(vg[a], sm);
+            if (threadIdx.x == 0) v[(size_t)i * 6 + a] = gc[(size_t)i * 6 + a] - s;
+        }
+    }
+}
+
+// Banded, deterministic variant driven by the co-observation pair list (mm_ba_build_pairs).  One WAVE per non-empty
+// block segment (i, f2 = i - d): lanes stride over the segment's (o, o2) pairs, accumulate Y_o E_o2^T in 36 private
+// registers (+6 for the right-hand side on the self pairs) and a fixed shuffle tree adds the lanes, so every entry of
+// S is summed in the same order on every run — the trust-region iteration, which is chaotic on outlier-laden matches,
+// then repeats bit for bit.  No atomics; only the LOWER block triangle is produced (S is zero-filled first).
+constexpr int SP_WAVES = 4;
+__global__ __launch_bounds__(64 * SP_WAVES) void schur_pairs_kernel(mm_ba_problem pb, const double *__restrict__ cams,
+                                                                    const double *__restrict__ pts,
+                                                                    const double *__restrict__ Bd,
+                                                                    const double *__restrict__ Cinv,
+                                                                    const double *__restrict__ gc,
+                                                                    const double *__restrict__ gp, double *__restrict__ S,
+                                                                    double *__restrict__ v) {
+    __shared__ double Ks[9];
+    if (threadIdx.x < 9) Ks[threadIdx.x] = pb.K[threadIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t sidx = (int64_t)blockIdx.x * SP_WAVES + (threadIdx.x >> 6);
+    if (sidx >= pb.n_seg) return;  // wave-uniform; no workgroup barriers below
+    const int seg = pb.seg_ids[sidx];
+    const int i = seg / (pb.cam_span + 1), d = seg % (pb.cam_span + 1);
+    const int f2 = i - d;
+    const size_t n = (size_t)pb.F * 6;
+    const double *ci_cam = cams + (size_t)i * 6, *c2_cam = cams + (size_t)f2 * 6;
+    double acc[42];
+#pragma unroll
+    for (int q = 0; q < 42; ++q) acc[q] = 0.0;
+    for (int64_t e = pb.seg_ptr[sidx] + lane; e < pb.seg_ptr[sidx + 1]; e += 64) {
+        const int o = pb.pair_o[e], o2 = pb.pair_o2[e];
+        const int p = pb.pi[o];
+        const double *Xp = pts + (size_t)p * 3;
+        Proj pr;
+        ba_eval<true, true>(ci_cam, Xp, Ks, pb.obs[2 * (size_t)o], pb.obs[2 * (size_t)o + 1], pr);
+        const double *ci = Cinv + (size_t)p * 6;
+        const double q00 = ci[0], q01 = ci[1], q02 = ci[2], q11 = ci[3], q12 = ci[4], q22 = ci[5];
+        double Y[6][3];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            const double x0 = pr.Jc[0][a] * pr.Jp[0][0] + pr.Jc[1][a] * pr.Jp[1][0];
+            const double x1 = pr.Jc[0][a] * pr.Jp[0][1] + pr.Jc[1][a] * pr.Jp[1][1];
+            const double x2 = pr.Jc[0][a] * pr.Jp[0][2] + pr.Jc[1][a] * pr.Jp[1][2];
+            Y[a][0] = x0 * q00 + x1 * q01 + x2 * q02;
+            Y[a][1] = x0 * q01 + x1 * q11 + x2 * q12;
+            Y[a][2] = x0 * q02 + x1 * q12 + x2 * q22;
+        }
+        if (o2 == o) {  // self pair: once per observation -> right-hand side
+            const double g0 = gp[(size_t)p * 3], g1 = gp[(size_t)p * 3 + 1], g2 = gp[(size_t)p * 3 + 2];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) acc[36 + a] += Y[a][0] * g0 + Y[a][1] * g1 + Y[a][2] * g2;
+        }
+        Proj p2;
+        ba_eval<true, true>(c2_cam, Xp, Ks, pb.obs[2 * (size_t)o2], pb.obs[2 * (size_t)o2 + 1], p2);
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            const double x0 = p2.Jc[0][b] * p2.Jp[0][0] + p2.Jc[1][b] * p2.Jp[1][0];
+            const double x1 = p2.Jc[0][b] * p2.Jp[0][1] + p2.Jc[1][b] * p2.Jp[1][1];
+            const double x2 = p2.Jc[0][b] * p2.Jp[0][2] + p2.Jc[1][b] * p2.Jp[1][2];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) acc[a * 6 + b] += Y[a][0] * x0 + Y[a][1] * x1 + Y[a][2] * x2;
+        }
+    }
+    const int nred = d == 0 ? 42 : 36;
+#pragma unroll
+    for (int q = 0; q < 42; ++q) {
+        if (q < nred) {
+            const double s = wave_sum(acc[q]);
+            if (lane == 0) {
+                if (q < 36) {
+                    double val = -s;
+                    if (d == 0) val += Bd[(size_t)i * 36 + q];
+                    S[((size_t)i * 6 + q / 6) * n + (size_t)f2 * 6 + q % 6] = val;
+                } else {
+                    v[(size_t)i * 6 + (q - 36)] = gc[(size_t)i * 6 + (q - 36)] - s;
+                }
+            }
+        }
+    }
+}
+
+// cameras without any observation never appear in a segment: their diagonal block / rhs is just (Bd, gc)
+__global__ void schur_diag_fill_kernel(mm_ba_problem pb, const double *__restrict__ Bd, const double *__restrict__ gc,
+                                       double *__restrict__ S, double *__restrict__ v) {
+    const int i = blockIdx.x;
+    if (pb.cam_ptr[i + 1] != pb.cam_ptr[i]) return;
+    const size_t n = (size_t)pb.F * 6;
+    if (threadIdx.x < 36) S[((size_t)i * 6 + threadIdx.x / 6) * n + (size_t)i * 6 + threadIdx.x % 6] = Bd[(size_t)i * 36 + threadIdx.x];
+    if (threadIdx.x < 6) v[(size_t)i * 6 + threadIdx.x] = gc[(size_t)i * 6 + threadIdx.x];
+}
+
+}  // namespace
+
+extern "C" int mm_ba_schur(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, const double *pts,
+                           const double *Bd, const double *Cd, const double *gc, const double *gp, double *S, double *v,
+                           double *Cinv) {
+    if (!ctx) return MM_ERR_ARG;
+    if (!pb || pb->F < 0 || pb->P < 0 || pb->O < 0 || !pb->K) return mm_fail(ctx, MM_ERR_ARG, "mm_ba_schur: bad problem");
+    if (!cams || !pts || !Bd || !Cd || !gc || !gp || !S || !v || !Cinv || !pb->pt_ptr || !pb->cam_ptr ||
+        (pb->O > 0 && (!pb->pt_obs || !pb->cam_obs || !pb->fi || !pb->pi || !pb->obs)))
+        return mm_fail(ctx, MM_ERR_ARG, "mm_ba_schur: null pointer");
+    if (pb->F == 0) return MM_OK;
+    if (pb->P > 0)
+        MM_LAUNCH(ctx, "point_inverse_kernel", point_inverse_kernel, dim3((pb->P + 255) / 256), dim3(256), 0, pb->P, Cd,
+                  Cinv);
+    if (pb->n_seg > 0 && pb->seg_ids && pb->seg_ptr && pb->pair_o && pb->pair_o2) {
+        // banded + deterministic: zero S (the Cholesky touches whole 64-blocks of the band), then the lower blocks
+        MM_HIP(ctx, hipMemsetAsync(S, 0, (size_t)pb->F * 6 * pb->F * 6 * sizeof(double), ctx->stream));
+        MM_LAUNCH(ctx, "schur_diag_fill_kernel", schur_diag_fill_kernel, dim3(pb->F), dim3(64), 0, *pb, Bd, gc, S, v);
+        const int64_t wgs = (pb->n_seg + SP_WAVES - 1) / SP_WAVES;
+        MM_LAUNCH(ctx, "schur_pairs_kernel", schur_pairs_kernel, dim3((unsigned)wgs), dim3(64 * SP_WAVES), 0, *pb, cams,
+                  pts, Bd, Cinv, gc, gp, S, v);
+        return MM_OK;
+    }
+    const int nwin = (pb->F + SR_WIN - 1) / SR_WIN;
+    MM_LAUNCH(ctx, "schur_rows_kernel", schur_rows_kernel, dim3(pb->F, nwin), dim3(256), 0, *pb, cams, pts, Bd, Cinv, gc,
+              gp, S, v);
+    return MM_OK;
+}

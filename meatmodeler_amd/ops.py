@@ -157,12 +157,20 @@ def ba_build_index(F, P, fi, pi):
 class BADevice:
     """Device-resident BA problem: observation arrays, CSR indices and the mm_ba_problem descriptor."""
 
-    def __init__(self, K, fi, pi, obs, F, P, device, ctx=None):
+    def __init__(self, K, fi, pi, obs, F, P, device, ctx=None, pairs=True, max_band_span=192):
         self.ctx = ctx or default_context()
         self.F, self.P, self.O = int(F), int(P), int(len(fi))
         fi = np.ascontiguousarray(fi, np.int32)
         pi = np.ascontiguousarray(pi, np.int32)
         pt_ptr, pt_obs, cam_ptr, cam_obs = ba_build_index(self.F, self.P, fi, pi)
+        # widest camera span of any point: cameras further apart never share a point, so the reduced camera system
+        # is block banded with this half-width (tracks from consecutive-keyframe matching span a few frames only)
+        self.cam_span = 0
+        if self.O:
+            fs = fi[pt_obs]
+            nz = np.flatnonzero(np.diff(pt_ptr) > 0)
+            starts = pt_ptr[:-1][nz]
+            self.cam_span = int((np.maximum.reduceat(fs, starts) - np.minimum.reduceat(fs, starts)).max())
         dev = device
         self.K = torch.as_tensor(np.ascontiguousarray(K, np.float64).reshape(9)).to(dev)
         self.fi = torch.as_tensor(fi).to(dev)
@@ -174,9 +182,38 @@ class BADevice:
         self.cam_obs = torch.as_tensor(np.ascontiguousarray(cam_obs)).to(dev)
         self.device = dev
         self.pb = BAProblem(self.F, self.P, self.O, ptr(self.K), ptr(self.fi), ptr(self.pi), ptr(self.obs),
-                            ptr(self.pt_ptr), ptr(self.pt_obs), ptr(self.cam_ptr), ptr(self.cam_obs))
+                            ptr(self.pt_ptr), ptr(self.pt_obs), ptr(self.cam_ptr), ptr(self.cam_obs),
+                            self.cam_span, 0, 0, None, None, None, None)
+        # banded problems (tracks from consecutive-keyframe matching): co-observation pair list for the atomic-free,
+        # bitwise reproducible Schur kernel; wide spans keep the general kernel
+        self.n_pairs = 0
+        if pairs and self.O and self.cam_span <= max_band_span and self.cam_span < self.F:
+            i32p, i64p = _lib.c_i32p, _lib.c_i64p
+            nseg = self.F * (self.cam_span + 1)
+            seg_ptr = np.zeros(nseg + 1, np.int64)
+            args = (self.F, self.P, self.O, fi.ctypes.data_as(i32p), pi.ctypes.data_as(i32p),
+                    pt_ptr.ctypes.data_as(i32p), np.ascontiguousarray(pt_obs).ctypes.data_as(i32p),
+                    cam_ptr.ctypes.data_as(i32p), np.ascontiguousarray(cam_obs).ctypes.data_as(i32p), self.cam_span,
+                    seg_ptr.ctypes.data_as(i64p))
+            n = lib.mm_ba_build_pairs(*args, None, None, 0)
+            if n < 0:
+                raise _lib.MMError(f"mm_ba_build_pairs failed ({n})")
+            po = np.empty(max(n, 1), np.int32)
+            po2 = np.empty(max(n, 1), np.int32)
+            n2 = lib.mm_ba_build_pairs(*args, po.ctypes.data_as(i32p), po2.ctypes.data_as(i32p), n)
+            assert n2 == n
+            ne = np.flatnonzero(np.diff(seg_ptr) > 0)
+            self.seg_ids = torch.as_tensor(ne.astype(np.int32)).to(dev)
+            self.seg_ptr = torch.as_tensor(np.concatenate([seg_ptr[ne], seg_ptr[-1:]]).astype(np.int64)).to(dev)
+            self.pair_o = torch.as_tensor(po[:n]).to(dev)
+            self.pair_o2 = torch.as_tensor(po2[:n]).to(dev)
+            self.n_pairs = int(n)
+            self.pb.n_seg = len(ne)
+            self.pb.seg_ids, self.pb.seg_ptr = ptr(self.seg_ids), ptr(self.seg_ptr)
+            self.pb.pair_o, self.pb.pair_o2 = ptr(self.pair_o), ptr(self.pair_o2)
         self._ws = torch.empty(2048 * 8, dtype=torch.uint8, device=dev)
         self._cost2 = torch.zeros(1, dtype=torch.float64, device=dev)
+        self._S = None  # reduced camera system, allocated once (6F x 6F doubles)
 
     def residual(self, cams, pts, want_res=False):
         """-> (sum of squared residuals as a 1-element device tensor, res [O,2] or None)."""
@@ -210,8 +247,12 @@ class BADevice:
         return out
 
     def schur(self, cams, pts, Bd, Cd, gc, gp):
+        """Reduced camera system.  With a pair list (banded problems) only the LOWER block band of S is produced
+        (deterministically) and the rest of S is zero; otherwise all of S is filled."""
         n = 6 * self.F
-        S = torch.empty((n, n), dtype=torch.float64, device=self.device)
+        if self._S is None:
+            self._S = torch.empty((n, n), dtype=torch.float64, device=self.device)
+        S = self._S
         v = torch.empty(n, dtype=torch.float64, device=self.device)
         Cinv = torch.empty((self.P, 6), dtype=torch.float64, device=self.device)
         self.ctx.check(lib.mm_ba_schur(self.ctx.h, C.byref(self.pb), ptr(cams), ptr(pts), ptr(Bd), ptr(Cd), ptr(gc),
@@ -225,9 +266,9 @@ class BADevice:
         return dp
 
 
-def chol_solve(A, b, ctx=None):
+def chol_solve(A, b, ctx=None, half_bandwidth=None):
     """In place: A [n,n] f64 SPD (lower triangle used, overwritten by L), b [n] or [nrhs,n] overwritten by x.
-    Returns the device int32 info tensor (0 = ok)."""
+    half_bandwidth: A[i][j] == 0 for i - j > half_bandwidth (None = dense).  Returns the device int32 info (0 = ok)."""
     ctx = ctx or default_context()
     n = A.shape[0]
     assert A.dtype == torch.float64 and A.is_contiguous() and b.is_contiguous() and b.shape[-1] == n
@@ -235,5 +276,6 @@ def chol_solve(A, b, ctx=None):
     info = torch.zeros(1, dtype=torch.int32, device=A.device)
     wsb = lib.mm_chol_workspace_bytes(n)
     ws = torch.empty(wsb, dtype=torch.uint8, device=A.device)
-    ctx.check(lib.mm_chol_solve(ctx.h, ptr(A), n, ptr(b), nrhs, ptr(info), ptr(ws), wsb), "mm_chol_solve")
+    hb = n if half_bandwidth is None else int(min(half_bandwidth, n))
+    ctx.check(lib.mm_chol_solve(ctx.h, ptr(A), n, ptr(b), nrhs, hb, ptr(info), ptr(ws), wsb), "mm_chol_solve")
     return info

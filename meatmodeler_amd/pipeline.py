@@ -202,6 +202,6 @@ class ClipPipeline:
         cams_d = torch.as_tensor(cams0).to(self.device)
         res = solver.solve(cams_d, pts0, ftol=ftol, verbose=verbose if rank == 0 else 0)
         toc("ba")
-        out.update(ba=res, n_obs_local=pb.O)
+        out.update(ba=res, n_obs_local=pb.O, cam_span=pb.cam_span, n_pairs=pb.n_pairs)
         T.pop("_open", None)
         return out

@@ -304,7 +304,15 @@ def test_ba_normal_equations_jvp_schur_backsub_consistent():
     Hcc, Hcp, Hpp = Hd[:6 * F, :6 * F], Hd[:6 * F, 6 * F:], Hd[6 * F:, 6 * F:]
     So = Hcc - Hcp @ np.linalg.solve(Hpp, Hcp.T)
     np.testing.assert_allclose(Sfull, So, rtol=1e-9, atol=1e-6 * np.abs(So).max())
-    info = ops.chol_solve(S, v)
+    # the general (LDS-atomic) kernel fills all of S and agrees with the pair-list kernel
+    pb2 = ops.BADevice(pr["K"], pr["fi"], pr["pi"], pr["obs"], F, P, DEV, pairs=False)
+    assert pb.n_pairs > 0 and pb2.n_pairs == 0
+    S2, v2, _ = pb2.schur(cd, pd, Bd, Cd, gc, gp)
+    np.testing.assert_allclose(S2.cpu().numpy(), So, rtol=1e-9, atol=1e-6 * np.abs(So).max())
+    np.testing.assert_allclose(v2.cpu().numpy(), v.cpu().numpy(), rtol=1e-10, atol=1e-9 * float(v.abs().max()))
+    S_again, _, _ = pb.schur(cd, pd, Bd, Cd, gc, gp)
+    assert torch.equal(S_again, S)          # the pair-list kernel is bitwise reproducible
+    info = ops.chol_solve(S, v, half_bandwidth=6 * pb.cam_span + 5)
     assert int(info) == 0
     dc = v.reshape(F, 6)
     dp = pb.backsub(cd, pd, Cinv, gp, dc)
@@ -324,6 +332,20 @@ def test_chol_solve_random_spd(n):
     np.testing.assert_allclose(bd.cpu().numpy(), np.linalg.solve(A, b), rtol=1e-9, atol=1e-12)
     L = np.tril(Ad.cpu().numpy())
     np.testing.assert_allclose(L @ L.T, A, rtol=1e-10, atol=1e-9 * n)
+
+
+@pytest.mark.parametrize("n,hb", [(500, 40), (1000, 130), (770, 63), (320, 5)])
+def test_chol_solve_banded(n, hb):
+    rng = np.random.default_rng(n + hb)
+    M = np.tril(np.triu(rng.normal(size=(n, n)), -hb // 2))     # banded factor -> banded SPD product
+    A = M @ M.T + n * np.eye(n)
+    i, j = np.indices((n, n))
+    assert (A[np.abs(i - j) > hb] == 0).all()
+    b = rng.normal(size=n)
+    Ad, bd = dev(A), dev(b)
+    info = ops.chol_solve(Ad, bd, half_bandwidth=hb)
+    assert int(info) == 0
+    np.testing.assert_allclose(bd.cpu().numpy(), np.linalg.solve(A, b), rtol=1e-9, atol=1e-12)
 
 
 def test_chol_reports_non_spd():

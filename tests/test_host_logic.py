@@ -173,6 +173,41 @@ def test_ba_build_index_stable_csr():
         ops.ba_build_index(F, P, np.array([F], np.int32), np.array([0], np.int32))
 
 
+def test_ba_build_pairs_matches_brute_force():
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    F, P, O = 9, 30, 160
+    fi = rng.integers(0, F, O).astype(np.int32)          # arbitrary order, repeated (camera, point) pairs included
+    pi = rng.integers(0, P, O).astype(np.int32)
+    pt_ptr, pt_obs, cam_ptr, cam_obs = ops.ba_build_index(F, P, fi, pi)
+    span = F - 1
+    seg_ptr = np.zeros(F * (span + 1) + 1, np.int64)
+    i32p, i64p = c_i32p, c_i64p
+    args = (F, P, O, fi.ctypes.data_as(i32p), pi.ctypes.data_as(i32p), pt_ptr.ctypes.data_as(i32p),
+            np.ascontiguousarray(pt_obs).ctypes.data_as(i32p), cam_ptr.ctypes.data_as(i32p),
+            np.ascontiguousarray(cam_obs).ctypes.data_as(i32p), span, seg_ptr.ctypes.data_as(i64p))
+    n = lib.mm_ba_build_pairs(*args, None, None, 0)
+    want = [(int(fi[o]) * (span + 1) + int(fi[o] - fi[o2]), o, o2) for o in range(O) for o2 in range(O)
+            if pi[o] == pi[o2] and fi[o2] <= fi[o]]
+    assert n == len(want)
+    po, po2 = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    assert lib.mm_ba_build_pairs(*args, po.ctypes.data_as(i32p), po2.ctypes.data_as(i32p), n) == n
+    got = []
+    for s_ in range(F * (span + 1)):
+        for e in range(seg_ptr[s_], seg_ptr[s_ + 1]):
+            got.append((s_, int(po[e]), int(po2[e])))
+    assert sorted(got) == sorted(want)
+    # canonical order inside a segment: camera-CSR order of o, then point-CSR order of o2
+    rank_cam = np.empty(O, np.int64)
+    rank_cam[cam_obs] = np.arange(O)
+    rank_pt = np.empty(O, np.int64)
+    rank_pt[pt_obs] = np.arange(O)
+    for s_ in range(F * (span + 1)):
+        seg = [(rank_cam[po[e]], rank_pt[po2[e]]) for e in range(seg_ptr[s_], seg_ptr[s_ + 1])]
+        assert seg == sorted(seg)
+    assert lib.mm_ba_build_pairs(*args[:9], 2, seg_ptr.ctypes.data_as(i64p), None, None, 0) == -1   # span too small
+
+
 @pytest.mark.parametrize("hw,nf", [((1080, 1920), 4000), ((480, 640), 1000), ((2160, 3840), 8000), ((364, 652), 300),
                                    ((1080, 1920), 20000)])
 def test_orb_level_geometry_matches_oracle(hw, nf):
