@@ -314,7 +314,7 @@ class SchurTRF:
                         f = torch.arange(pb.F, device=dev)
                         blk[f, :, f, :] -= (ws - 1) * Bd
                         v -= (ws - 1) * gc.reshape(-1)
-                info = ops.chol_solve(S, v, pb.ctx, half_bandwidth=half_bw)
+                info = pb.chol_solve(S, v, half_bandwidth=half_bw)
                 if int(info.item()) == 0:
                     break
                 reg_eff *= 100.0

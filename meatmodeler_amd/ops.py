@@ -259,6 +259,10 @@ class BADevice:
                                        ptr(gp), ptr(S), ptr(v), ptr(Cinv)), "mm_ba_schur")
         return S, v, Cinv
 
+    def chol_solve(self, S, v, half_bandwidth=None):
+        """In-place banded Cholesky solve of the reduced camera system (see ops.chol_solve)."""
+        return chol_solve(S, v, self.ctx, half_bandwidth=half_bandwidth)
+
     def backsub(self, cams, pts, Cinv, gp, dc):
         dp = torch.empty((self.P, 3), dtype=torch.float64, device=self.device)
         self.ctx.check(lib.mm_ba_backsub(self.ctx.h, C.byref(self.pb), ptr(cams), ptr(pts), ptr(Cinv), ptr(gp), ptr(dc),
