@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--verbose", type=int, default=0)
+    ap.add_argument("--no-profile", action="store_true", help="no per-launch HIP events in the timed steps")
     return ap.parse_args()
 
 
@@ -82,8 +83,8 @@ def algorithmic_work(name, cfg):
         return it * (O * (4 + 4 + 16 + 24) + Fc * 42 * 8), 0, 0
     if name == "ba_jvp_kernel":
         return 2 * it * O * (48 + 16 + 24), 0, 0
-    if name == "schur_accum_kernel":
-        return it * (O * 28 + P * 72), 0, 0
+    if name == "schur_pairs_kernel":   # per co-observation pair: 2 idx + 2 obs + point + Cinv; ~600 f64 instr-lanes
+        return it * cfg.get("n_pairs", 0) * (8 + 4 + 32 + 24 + 48), it * cfg.get("n_pairs", 0) * 600.0, 0
     if name == "schur_init_kernel":
         return it * (6 * Fc) ** 2 * 8, 0, 0
     if name == "chol_update_kernel":
@@ -136,7 +137,9 @@ def main():
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
-    ctx.profile(True)
+    # level 2: HIP events around every launch of >= 64 workgroups (the sweeps); the Cholesky's chains of 1..45-workgroup
+    # launches are left alone — bracketing all ~26k launches of a step with events inflates the step by ~25 %
+    ctx.profile(0 if a.no_profile else 2)
     timers = {}
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -147,13 +150,21 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     prof = ctx.profile_report()
-    ctx.profile(False)
-    el = torch.tensor([elapsed] + [timers.get(k, 0.0) for k in ("detect", "match", "link", "triangulate", "ba")],
+    ctx.profile(0)
+    # one extra, untimed step with events on EVERY launch for the complete per-kernel table
+    prof_full = {}
+    if not a.no_profile:
+        ctx.profile(1)
+        step()
+        prof_full = ctx.profile_report()
+        ctx.profile(0)
+    STAGES = ("detect", "match", "link", "triangulate", "ba", "ba_solve")
+    el = torch.tensor([elapsed] + [timers.get(k, 0.0) for k in STAGES],
                       dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el[0])
-    stage_ms = {k: float(v) / a.steps for k, v in zip(("detect", "match", "link", "triangulate", "ba"), el[1:])}
+    stage_ms = {k: float(v) / a.steps for k, v in zip(STAGES, el[1:])}
 
     kp_count = out["kp_count"]
     pair_evals = float(np.sum(kp_count[:-1].astype(np.float64) * kp_count[1:].astype(np.float64)))
@@ -170,7 +181,24 @@ def main():
     cfg = dict(frames=F, frames_local=f_hi - f_lo, nfeatures=N, levels=list(zip(lv_w.tolist(), lv_h.tolist())),
                pairs_local=p_hi - p_lo, pair_evals_local=float(np.sum(kpl[:-1] * kpl[1:])) if len(kpl) > 1 else 0.0,
                kp_total_local=float(kpl.sum()), n_obs_local=out.get("n_obs_local", n_obs),
-               n_points_local=out["n_tracks"] // world, ba_iters=res.njev if res is not None else 0, ba_nfev=nfev)
+               n_points_local=out["n_tracks"] // world, ba_iters=res.njev if res is not None else 0, ba_nfev=nfev,
+               n_pairs=out.get("n_pairs", 0))
+    def table(prof_, steps_):
+        rows = []
+        for name, (cnt, ms) in sorted(prof_.items(), key=lambda kv: -kv[1][1]):
+            by, lops, fl = algorithmic_work(name, cfg)
+            per = ms / steps_
+            row = dict(kernel=name, launches_per_step=cnt / steps_, ms_per_step=per, avg_us=1e3 * ms / max(cnt, 1))
+            if by:
+                row["algorithmic_GBps"] = by / (per * 1e-3) / 1e9
+            if lops:
+                row["valu_Tlops"] = lops / (per * 1e-3) / 1e12
+            if fl:
+                row["mfma_f64_TFLOPs"] = fl / (per * 1e-3) / 1e12
+            rows.append(row)
+        return rows
+
+    kernels_full = table(prof_full, 1)
     kernels = []
     for name, (cnt, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
         by, lops, fl = algorithmic_work(name, cfg)
@@ -222,6 +250,7 @@ def main():
             "roofline": roofline,
             "bf_knn2": bf,
             "kernels": kernels[:12],
+            "kernels_all_launches_extra_step": kernels_full[:16],
             "cpu_baseline": cpu,
         }
         print(json.dumps(line))

@@ -45,8 +45,9 @@ int mm_timer_start(mm_ctx *ctx, void *timer);
 int mm_timer_stop(mm_ctx *ctx, void *timer);
 int mm_timer_elapsed_ms(mm_ctx *ctx, void *timer, float *ms_out); /* (sync) */
 void mm_timer_destroy(mm_ctx *ctx, void *timer);
-/* Per-launch profiling: while enabled every kernel launched through this context is bracketed by two HIP events on
- * the context's stream.  mm_profile_report (sync) writes one line per kernel name, "name launches total_ms\n", and
+/* Per-launch profiling: on = 1 brackets every kernel launched through this context with two HIP events on the
+ * context's stream (~2.5 us of device time and ~5 us of host time per launch); on = 2 only launches of >= 64
+ * workgroups, leaving the micro-launch chains of the Cholesky untouched; on = 0 stops collecting.  mm_profile_report (sync) writes one line per kernel name, "name launches total_ms\n", and
  * returns the number of lines.  Enabling clears earlier records. */
 int mm_profile_enable(mm_ctx *ctx, int on);
 int mm_profile_report(mm_ctx *ctx, char *buf, size_t buf_len);
@@ -147,12 +148,16 @@ typedef struct mm_ba_problem {
     const int32_t *pt_ptr, *pt_obs;   /* dev CSR by point  (mm_ba_build_index) */
     const int32_t *cam_ptr, *cam_obs; /* dev CSR by camera */
     /* optional co-observation pair list (mm_ba_build_pairs) for the banded, bitwise reproducible Schur kernel;
-     * n_seg == 0 / NULL pointers select the general kernel */
+     * n_seg == 0 / NULL pointers select the general kernel.  Segments are cut into chunks of at most 256 pairs: one
+     * wave sums a chunk, a second pass adds the chunks of a segment in order. */
     int32_t cam_span;                 /* max over points of (largest - smallest observing camera index) */
     int32_t reserved;
     int64_t n_seg;                    /* number of NON-EMPTY block segments */
     const int32_t *seg_ids;           /* dev [n_seg]   segment id = camera * (cam_span + 1) + (camera - camera2) */
-    const int64_t *seg_ptr;           /* dev [n_seg+1] offsets into the pair arrays */
+    const int32_t *seg_chunk_ptr;     /* dev [n_seg+1] first chunk of each segment */
+    int64_t n_chunks;
+    const int32_t *chunk_seg;         /* dev [n_chunks] index into seg_ids */
+    const int32_t *chunk_begin, *chunk_end; /* dev [n_chunks] pair range */
     const int32_t *pair_o, *pair_o2;  /* dev [n_pairs] */
 } mm_ba_problem;
 
@@ -178,7 +183,17 @@ int mm_ba_jvp(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, const do
  * is computed by an atomic-free, bitwise reproducible kernel and the rest of S is zero; otherwise a general kernel
  * fills all of S (LDS f64 atomics, last bits vary from run to run). */
 int mm_ba_schur(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, const double *pts, const double *Bd,
-                const double *Cd, const double *gc, const double *gp, double *S, double *v, double *Cinv);
+                const double *Cd, const double *gc, const double *gp, double *S, double *v, double *Cinv, void *ws,
+                size_t ws_bytes);
+size_t mm_ba_schur_workspace_bytes(const mm_ba_problem *pb); /* 42 doubles per chunk (0 without a pair list) */
+/* Device-side construction of the pair list (needs fi, pi and the CSR by point in *pb):
+ *   count: cnt[o] = number of observations o2 of o's point with camera(o2) <= camera(o); span_out[0] = widest camera
+ *          distance inside a point (= cam_span);
+ *   emit : after an exclusive scan of cnt (offsets), writes key = camera(o)*(span+1) + camera(o) - camera(o2) and the
+ *          pair (o, o2) at offsets[o]...; a STABLE sort by key then yields the segments in a fixed order. */
+int mm_ba_pairs_count(mm_ctx *ctx, const mm_ba_problem *pb, int32_t *cnt /*dev [O]*/, int32_t *span_out /*dev [1]*/);
+int mm_ba_pairs_emit(mm_ctx *ctx, const mm_ba_problem *pb, const int64_t *offsets /*dev [O]*/, int span,
+                     int32_t *key /*dev [n]*/, int32_t *pair_o /*dev [n]*/, int32_t *pair_o2 /*dev [n]*/);
 /* dp [P,3] = Cinv (gp - E^T dc). */
 int mm_ba_backsub(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, const double *pts, const double *Cinv,
                   const double *gp, const double *dc /*dev [F,6]*/, double *dp);

@@ -32,7 +32,8 @@ class BAProblem(C.Structure):
     _fields_ = [("F", C.c_int32), ("P", C.c_int32), ("O", C.c_int64), ("K", vp), ("fi", vp), ("pi", vp),
                 ("obs", vp), ("pt_ptr", vp), ("pt_obs", vp), ("cam_ptr", vp), ("cam_obs", vp),
                 ("cam_span", C.c_int32), ("reserved", C.c_int32), ("n_seg", C.c_int64), ("seg_ids", vp),
-                ("seg_ptr", vp), ("pair_o", vp), ("pair_o2", vp)]
+                ("seg_chunk_ptr", vp), ("n_chunks", C.c_int64), ("chunk_seg", vp), ("chunk_begin", vp),
+                ("chunk_end", vp), ("pair_o", vp), ("pair_o2", vp)]
 
 
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header.
@@ -68,7 +69,10 @@ SIGNATURES = {
     "mm_ba_jacobian": (C.c_int, [vp, C.POINTER(BAProblem), vp, vp, vp, vp]),
     "mm_ba_normal_eq": (C.c_int, [vp, C.POINTER(BAProblem), vp, vp, vp, vp, vp, vp]),
     "mm_ba_jvp": (C.c_int, [vp, C.POINTER(BAProblem), vp, vp, vp, vp, vp]),
-    "mm_ba_schur": (C.c_int, [vp, C.POINTER(BAProblem), vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "mm_ba_schur": (C.c_int, [vp, C.POINTER(BAProblem), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t]),
+    "mm_ba_schur_workspace_bytes": (C.c_size_t, [C.POINTER(BAProblem)]),
+    "mm_ba_pairs_count": (C.c_int, [vp, C.POINTER(BAProblem), vp, vp]),
+    "mm_ba_pairs_emit": (C.c_int, [vp, C.POINTER(BAProblem), vp, C.c_int, vp, vp, vp]),
     "mm_ba_backsub": (C.c_int, [vp, C.POINTER(BAProblem), vp, vp, vp, vp, vp, vp]),
     "mm_chol_workspace_bytes": (C.c_size_t, [C.c_int]),
     "mm_chol_solve": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, C.c_size_t]),
@@ -126,8 +130,9 @@ class Context:
     def sync(self):
         self.check(lib.mm_ctx_sync(self.h), "mm_ctx_sync")
 
-    def profile(self, on):
-        self.check(lib.mm_profile_enable(self.h, 1 if on else 0), "mm_profile_enable")
+    def profile(self, level):
+        """0 off, 1 every launch, 2 launches of >= 64 workgroups only."""
+        self.check(lib.mm_profile_enable(self.h, int(level)), "mm_profile_enable")
 
     def profile_report(self):
         """{kernel name: (launches, total_ms)} of the launches recorded since profile(True)."""

@@ -195,7 +195,11 @@ class SchurTRF:
     """SciPy's trf_no_bounds (tr_solver='lsmr', x_scale='jac', linear loss) with the Gauss-Newton system solved by
     the Schur complement.  `allreduce` (optional) sums partial block quantities across ranks for the sharded path
     (points partitioned over GPUs, cameras replicated): it is called on every tensor that is a sum over
-    observations."""
+    observations.
+
+    The parameter vector lives in ONE flat device buffer x = [cams (6F) | points (3P)] (views are handed to the sweeps),
+    so every axpy / dot of the iteration is a single launch, and the host reads device scalars three times per
+    iteration (before the damping is known, after the step basis is built, after each trial step)."""
 
     def __init__(self, pb, allreduce=None, timers=None, min_damping=1e-9):
         self.pb = pb
@@ -209,49 +213,73 @@ class SchurTRF:
             for t in tensors:
                 self.allreduce(t)
 
+    def _cost_dev(self, x):
+        c2, _ = self.pb.residual(self._cams(x), self._pts(x))
+        self._ar(c2)
+        return c2
+
     def _cost(self, cams, pts):
         c2, _ = self.pb.residual(cams, pts)
         self._ar(c2)
         return 0.5 * float(c2.item())
 
-    def _normal(self, cams, pts):
-        B, gc, C, gp = self.pb.normal_eq(cams, pts)
+    def _cams(self, v):
+        return v[:self.nc].view(self.pb.F, 6)
+
+    def _pts(self, v):
+        return v[self.nc:].view(self.pb.P, 3)
+
+    def _dots(self, pairs):
+        """[<a, b> for (a, b) in pairs] as a device vector; the camera part of the parameter vector is replicated on
+        every rank, the point part is sharded."""
+        if self.allreduce is None:
+            return torch.stack([torch.dot(a, b) for a, b in pairs])
+        nc = self.nc
+        cam = torch.stack([torch.dot(a[:nc], b[:nc]) for a, b in pairs])
+        pts = torch.stack([torch.dot(a[nc:], b[nc:]) for a, b in pairs])
+        self.allreduce(pts)
+        return cam + pts
+
+    def _normal(self, x, g):
+        """Block normal equations at x; the gradient goes straight into the flat buffer g."""
+        B, gc, C, gp = self.pb.normal_eq(self._cams(x), self._pts(x))
         self._ar(B, gc)          # camera blocks are sums over all observations; point blocks are local
-        return B, gc, C, gp
+        g[:self.nc] = gc.reshape(-1)
+        g[self.nc:] = gp.reshape(-1)
+        return B, C
+
+    def _scale_inv(self, B, C, old=None):
+        si = torch.cat([torch.diagonal(B, dim1=1, dim2=2).reshape(-1), C[:, self.diag_idx].reshape(-1)]).sqrt_()
+        if old is None:
+            si[si == 0] = 1.0
+            return si
+        return torch.maximum(si, old)
 
     def solve(self, cams0, pts0, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None, verbose=0, local_points_norm=None):
         pb = self.pb
         dev = pb.device
-        cams = cams0.clone()
-        pts = pts0.clone()
-        n = cams.numel() + pts.numel()
+        F, P = pb.F, pb.P
+        self.nc = nc = 6 * F
+        n = nc + 3 * P
+        f64 = dict(dtype=torch.float64, device=dev)
+        x = torch.cat([cams0.reshape(-1), pts0.reshape(-1)]).to(**f64).contiguous()
+        g = torch.empty(n, **f64)
+        self.diag_idx = torch.tensor([0, 3, 5], device=dev)
 
-        def vdot(ac, ap, bc, bp):
-            """<a, b> over the full parameter vector (camera part replicated, point part sharded)."""
-            s = torch.stack([(ac * bc).sum(), (ap * bp).sum()])
-            if self.allreduce is not None:
-                t = s[1:2].clone()
-                self.allreduce(t)
-                s = torch.stack([s[0], t[0]])
-            return s
-
-        cost = self._cost(cams, pts)
+        c2 = self._cost_dev(x)
+        cost = 0.5 * float(c2.item())
         if not np.isfinite(cost):
             raise ValueError("Residuals are not finite in the initial point.")
         # band of the reduced camera system: |camera i - camera j| <= span  ->  |row - col| <= 6 span + 5
-        span = torch.tensor([float(pb.cam_span)], dtype=torch.float64, device=dev)
+        span = torch.tensor([float(pb.cam_span)], **f64)
         if self.allreduce is not None:
             self.allreduce(span, op="max")
-        span_cams = int(span.item())
-        half_bw = 6 * span_cams + 5
+        half_bw = 6 * int(span.item()) + 5
         nfev, njev = 1, 1
-        B, gc, C, gp = self._normal(cams, pts)
-        diag_idx = torch.tensor([0, 3, 5], device=dev)
-        sic = torch.sqrt(torch.diagonal(B, dim1=1, dim2=2)).clone()
-        sip = torch.sqrt(C[:, diag_idx])
-        sic[sic == 0] = 1.0
-        sip[sip == 0] = 1.0
-        Delta = float(torch.sqrt(vdot(cams * sic, pts * sip, cams * sic, pts * sip).sum()).item())
+        B, C = self._normal(x, g)
+        si = self._scale_inv(B, C)
+        xs = x * si
+        Delta = float(torch.sqrt(self._dots([(xs, xs)])[0]).item())
         if Delta == 0:
             Delta = 1.0
         if max_nfev is None:
@@ -264,26 +292,25 @@ class SchurTRF:
         if verbose == 2:
             _print_header()
         while True:
-            gmax = torch.stack([gc.abs().max() if gc.numel() else torch.zeros((), dtype=torch.float64, device=dev),
-                                gp.abs().max() if gp.numel() else torch.zeros((), dtype=torch.float64, device=dev)])
+            # ---- host sync 1: |g|_inf, |g_h|, |J_h g_h|^2 (needed for the damping before the system can be built) ----
+            gh = g / si                                   # g_h = d * g, d = 1 / scale_inv
+            u1 = pb.jvp(self._cams(x), self._pts(x), self._cams(gh / si), self._pts(gh / si))   # J (d g_h)
+            gmax = g.abs().max().reshape(1)
+            d11 = torch.dot(u1.reshape(-1), u1.reshape(-1)).reshape(1)
             if self.allreduce is not None:
                 self.allreduce(gmax, op="max")
-            g_norm = float(gmax.max().item())
+                self.allreduce(d11)
+            g_norm, gh2, d11 = torch.cat([gmax, self._dots([(gh, gh)]), d11]).tolist()
+            gh_norm = np.sqrt(gh2)
             if g_norm < gtol:
                 termination = 1
             if verbose == 2:
                 _print_iteration(iteration, nfev, cost, actual, step_norm, g_norm)
             if termination is not None or nfev == max_nfev:
                 break
-            # scaled gradient g_h = d * g, d = 1 / scale_inv
-            ghc, ghp = gc / sic, gp / sip
-            gh_norm = float(torch.sqrt(vdot(ghc, ghp, ghc, ghp).sum()).item())
             # Cauchy-derived regulariser (trf.py:473-477): a = 0.5 |J_h g_h|^2, b = -|g_h|^2
-            u1 = pb.jvp(cams, pts, ghc / sic, ghp / sip)
-            d11 = (u1 * u1).sum().reshape(1)
-            self._ar(d11)
-            a_q = 0.5 * float(d11.item())
-            b_q = -gh_norm ** 2
+            a_q = 0.5 * d11
+            b_q = -gh2
             to_tr = Delta / gh_norm
             ts = [0.0, to_tr]
             if a_q != 0:
@@ -298,57 +325,53 @@ class SchurTRF:
             # LSMR copes with a singular system, a Cholesky factorisation needs `reg` to stay above rounding:
             # a floor of 1e-9 (relative to the unit diagonal of the scaled system) and x100 retries on a bad pivot.
             reg_eff = max(reg, self.min_damping)
+            sic2 = (si[:nc] * si[:nc]).view(F, 6)
+            sip2 = (si[nc:] * si[nc:]).view(P, 3)
+            gc, gp = self._cams(g), self._pts(g)
             for attempt in range(6):
                 Bd = B.clone()
-                Bd.diagonal(dim1=1, dim2=2).add_(reg_eff * sic * sic)
+                Bd.diagonal(dim1=1, dim2=2).add_(sic2, alpha=reg_eff)
                 Cd = C.clone()
-                Cd[:, diag_idx] += reg_eff * sip * sip
-                S, v, Cinv = pb.schur(cams, pts, Bd, Cd, gc, gp)
+                Cd[:, self.diag_idx] += reg_eff * sip2
+                S, v, Cinv = pb.schur(self._cams(x), self._pts(x), Bd, Cd, gc, gp)
                 if self.allreduce is not None:
                     # every rank added the full blockdiag(Bd) and gc: remove the duplicates after the sum
                     ws = self.allreduce.world_size
                     self.allreduce(S)
                     self.allreduce(v)
                     if ws > 1:
-                        blk = S.reshape(pb.F, 6, pb.F, 6)
-                        f = torch.arange(pb.F, device=dev)
+                        blk = S.reshape(F, 6, F, 6)
+                        f = torch.arange(F, device=dev)
                         blk[f, :, f, :] -= (ws - 1) * Bd
                         v -= (ws - 1) * gc.reshape(-1)
                 info = pb.chol_solve(S, v, half_bandwidth=half_bw)
-                if int(info.item()) == 0:
+                q = torch.empty(n, **f64)                 # q = (J^T J + reg D^-2)^-1 g  (unscaled Gauss-Newton step)
+                q[:nc] = v
+                q[nc:] = pb.backsub(self._cams(x), self._pts(x), Cinv, gp, v.view(F, 6)).reshape(-1)
+                # orthonormal basis of span{g_h, gn_h} (trf.py:481-482), all on the device
+                gn = q * si                               # gn_h = q * scale_inv
+                q1 = gh / gh_norm
+                sc = self._dots([(q1, gn)])[0]
+                w = gn - sc * q1
+                wn2, gn2 = self._dots([(w, w), (gn, gn)])
+                q2 = w / torch.sqrt(wn2)
+                s1, s2 = q1 / si, q2 / si                 # unscaled basis steps d * q
+                Jq1 = u1.reshape(-1) / gh_norm            # J_h q1 = J (d q1)
+                Jq2 = pb.jvp(self._cams(x), self._pts(x), self._cams(s2), self._pts(s2)).reshape(-1)
+                bs = torch.stack([torch.dot(Jq1, Jq1), torch.dot(Jq1, Jq2), torch.dot(Jq2, Jq2)])
+                self._ar(bs)
+                nn = self._dots([(s1, s1), (s1, s2), (s2, s2), (q2, gh), (x, x)])
+                # ---- host sync 2 ----
+                vals = torch.cat([info.to(torch.float64), wn2.reshape(1), gn2.reshape(1), bs, nn]).tolist()
+                if int(vals[0]) == 0:
                     break
                 reg_eff *= 100.0
             else:
-                raise MMError(f"reduced camera system is not positive definite (pivot {int(info.item())})")
-            dc = v.reshape(pb.F, 6)
-            dp = pb.backsub(cams, pts, Cinv, gp, dc)
-            gnc, gnp = dc * sic, dp * sip          # gn_h = q * scale_inv
-            # orthonormal basis of span{g_h, gn_h} (trf.py:481-482)
-            q1c, q1p = ghc / gh_norm, ghp / gh_norm
-            sc = vdot(q1c, q1p, gnc, gnp).sum()
-            wc, wp = gnc - sc * q1c, gnp - sc * q1p
-            wn = float(torch.sqrt(vdot(wc, wp, wc, wp).sum()).item())
-            gn_norm = float(torch.sqrt(vdot(gnc, gnp, gnc, gnp).sum()).item())
-            if wn <= 1e-14 * max(gn_norm, 1e-300):
-                q2c, q2p = torch.zeros_like(q1c), torch.zeros_like(q1p)
-                degenerate = True
-            else:
-                q2c, q2p = wc / wn, wp / wn
-                degenerate = False
-            # J_h q1 = u1 / |g_h| ;  J_h q2 = J (q2 / scale_inv)
-            s1c, s1p = q1c / sic, q1p / sip        # unscaled basis steps d * q
-            s2c, s2p = q2c / sic, q2p / sip
-            Jq1 = u1 / gh_norm
-            Jq2 = pb.jvp(cams, pts, s2c, s2p)
-            bs = torch.stack([(Jq1 * Jq1).sum(), (Jq1 * Jq2).sum(), (Jq2 * Jq2).sum()])
-            self._ar(bs)
-            nn = torch.stack([vdot(s1c, s1p, s1c, s1p).sum(), vdot(s1c, s1p, s2c, s2p).sum(),
-                              vdot(s2c, s2p, s2c, s2p).sum(), vdot(q2c, q2p, ghc, ghp).sum(),
-                              vdot(cams, pts, cams, pts).sum()])
-            b11, b12, b22 = bs.tolist()
-            n11, n12, n22, g2, xx = nn.tolist()
-            if degenerate:
-                b22 = 1.0
+                raise MMError(f"reduced camera system is not positive definite (pivot {int(vals[0])})")
+            _, wn2, gn2, b11, b12, b22, n11, n12, n22, g2, xx = vals
+            if not (wn2 > 1e-28 * max(gn2, 1e-300)):       # gn_h parallel to g_h: the subspace is one-dimensional
+                s2 = torch.zeros_like(s1)
+                b12, b22, n12, n22, g2 = 0.0, 1.0, 0.0, 0.0, 0.0
             B_S = np.array([[b11, b12], [b12, b22]])
             g_S = np.array([gh_norm, g2])
             x_norm = np.sqrt(xx)
@@ -356,9 +379,8 @@ class SchurTRF:
             while actual <= 0 and nfev < max_nfev:
                 p_S, _ = _solve_trust_region_2d(B_S, g_S, Delta)
                 predicted = -(0.5 * p_S @ B_S @ p_S + g_S @ p_S)
-                cams_new = cams + p_S[0] * s1c + p_S[1] * s2c
-                pts_new = pts + p_S[0] * s1p + p_S[1] * s2p
-                cost_new = self._cost(cams_new, pts_new)
+                x_new = torch.add(x, s1, alpha=float(p_S[0])).add_(s2, alpha=float(p_S[1]))
+                cost_new = 0.5 * float(self._cost_dev(x_new).item())      # ---- host sync 3 (per trial step) ----
                 nfev += 1
                 step_h_norm = float(_norm(p_S))
                 if not np.isfinite(cost_new):
@@ -373,19 +395,18 @@ class SchurTRF:
                 alpha *= Delta / Delta_new
                 Delta = Delta_new
             if actual > 0:
-                cams, pts, cost = cams_new, pts_new, cost_new
-                B, gc, C, gp = self._normal(cams, pts)
+                x, cost = x_new, cost_new
+                B, C = self._normal(x, g)
                 njev += 1
-                sic = torch.maximum(torch.sqrt(torch.diagonal(B, dim1=1, dim2=2)), sic)
-                sip = torch.maximum(torch.sqrt(C[:, diag_idx]), sip)
+                si = self._scale_inv(B, C, si)
             else:
                 step_norm = 0
                 actual = 0
             iteration += 1
         if termination is None:
             termination = 0
-        return BAResult(cams=cams, pts=pts, cost=cost, optimality=g_norm, nfev=nfev, njev=njev, status=termination,
-                        message=_MESSAGES[termination], success=termination > 0)
+        return BAResult(cams=self._cams(x).clone(), pts=self._pts(x).clone(), cost=cost, optimality=g_norm, nfev=nfev,
+                        njev=njev, status=termination, message=_MESSAGES[termination], success=termination > 0)
 
 
 def _finish_verbose(res, cost0, verbose):
@@ -446,3 +467,153 @@ def adjustPoints(frame_extrinsic_matrices, camera_intrinsic_matrix, points_3D, p
                       point_indices, ftol=1e-4, verbose=2)
     F = len(frame_extrinsic_matrices)
     return reformatPointResult(res, F, len(np.asarray(points_3D).reshape(-1, 3)))
+
+
+# ----------------------------------------------------------------------------------------------- pose-only refinement
+
+def _solve_lsq_trust_region_eig(lam, vg, V, Delta, m, initial_alpha, rtol=0.01, max_iter=10):
+    """scipy/optimize/_lsq/common.py:solve_lsq_trust_region expressed through the eigen-decomposition of J^T J.
+    The pose-only Jacobian is block diagonal (one 2n x 6 block per camera), so its SVD is the union of the per-camera
+    SVDs: singular values s = sqrt(eig(B_f)), right vectors V_f, and s*U^T f = V^T g.
+    lam [F,6] eigenvalues, vg [F,6] = V^T g, V [F,6,6]."""
+    s2 = np.maximum(lam, 0.0).ravel()
+    s = np.sqrt(s2)
+    suf = vg.ravel()
+    n = s.size
+
+    def phi_and_derivative(alpha):
+        denom = s2 + alpha
+        p_norm = _norm(suf / denom)
+        return p_norm - Delta, -np.sum(suf ** 2 / denom ** 3) / p_norm
+
+    def back(coef):
+        return -np.einsum("fij,fj->fi", V, coef.reshape(V.shape[0], 6))
+
+    full_rank = (m >= n) and (s.min() > EPS * m * s.max())
+    if full_rank:
+        p = back(suf / s2)
+        if _norm(p) <= Delta:
+            return p, 0.0, 0
+    alpha_upper = _norm(suf) / Delta
+    if full_rank:
+        phi, phi_prime = phi_and_derivative(0.0)
+        alpha_lower = -phi / phi_prime
+    else:
+        alpha_lower = 0.0
+    if initial_alpha is None or (not full_rank and initial_alpha == 0):
+        alpha = max(0.001 * alpha_upper, (alpha_lower * alpha_upper) ** 0.5)
+    else:
+        alpha = initial_alpha
+    it = 0
+    for it in range(max_iter):
+        if alpha < alpha_lower or alpha > alpha_upper:
+            alpha = max(0.001 * alpha_upper, (alpha_lower * alpha_upper) ** 0.5)
+        phi, phi_prime = phi_and_derivative(alpha)
+        if phi < 0:
+            alpha_upper = alpha
+        ratio = phi / phi_prime
+        alpha_lower = max(alpha_lower, alpha - ratio)
+        alpha -= (phi + Delta) * ratio / Delta
+        if np.abs(phi) < rtol * Delta:
+            break
+    p = back(suf / (s2 + alpha))
+    p *= Delta / _norm(p)
+    return p, alpha, it + 1
+
+
+def solvePose(frame_extrinsic_matrices, camera_intrinsic_matrix, points_2D, ftol=1e-4, xtol=1e-8, gtol=1e-8,
+              max_nfev=None, verbose=2):
+    """adjustPose with the optimiser exposed.  The reference calls least_squares(poseFun, ..., ftol=1e-4) with every
+    other setting at its default (bundleAdjuster.py:232-241): TRF, dense 2-point Jacobian, tr_solver='exact' (SVD),
+    x_scale=1.  Same iteration here; the camera blocks B_f = J_f^T J_f and g_f come from the HIP sweep with the
+    points held fixed, and the 'exact' trust-region solve works on their 6x6 eigen-decompositions."""
+    ctx = default_context()
+    dev = ctx.device
+    ext = np.asarray(frame_extrinsic_matrices, float)
+    F = len(ext)
+    pattern_size = int(len(points_2D) / F)
+    pts3 = np.zeros((pattern_size, 3), np.float32)           # the (4,3) chessboard of side 2, bundleAdjuster.py:220-223
+    grid = np.mgrid[0:4, 0:3].T.reshape(-1, 2) * 2
+    pts3[:, 0] = grid[:, 0]
+    pts3[:, 2] = grid[:, 1]
+    fi = np.repeat(np.arange(F), pattern_size)
+    pi = np.repeat([np.arange(pattern_size)], F, axis=0).reshape(pattern_size * F)
+    with np.errstate(all="ignore"):
+        x = frameParameters(ext).reshape(F, 6)
+    pb = ops.BADevice(camera_intrinsic_matrix, fi, pi, points_2D, F, pattern_size, dev, ctx, pairs=False)
+    pts_d = _dev(pts3.astype(np.float64), dev)
+    m, n = 2 * len(fi), 6 * F
+
+    def fun(xc):
+        c2, _ = pb.residual(_dev(xc, dev), pts_d)
+        return 0.5 * float(c2.item())
+
+    def blocks(xc):
+        B, g, _, _ = pb.normal_eq(_dev(xc, dev), pts_d, want_cams=True, want_pts=False)
+        return B.cpu().numpy(), g.cpu().numpy()
+
+    cost = fun(x)
+    cost0 = cost
+    if not np.isfinite(cost):
+        raise ValueError("Residuals are not finite in the initial point.")
+    nfev, njev = 1, 1
+    B, g = blocks(x)
+    Delta = _norm(x)          # x_scale = 1  (trf.py:427-430)
+    if Delta == 0:
+        Delta = 1.0
+    if max_nfev is None:
+        max_nfev = n * 100
+    alpha = 0.0
+    termination, iteration, step_norm, actual = None, 0, None, None
+    if verbose == 2:
+        _print_header()
+    while True:
+        g_norm = float(np.abs(g).max())
+        if g_norm < gtol:
+            termination = 1
+        if verbose == 2:
+            _print_iteration(iteration, nfev, cost, actual, step_norm, g_norm)
+        if termination is not None or nfev == max_nfev:
+            break
+        lam, V = np.linalg.eigh(B)
+        vg = np.einsum("fji,fj->fi", V, g)
+        actual = -1.0
+        while actual <= 0 and nfev < max_nfev:
+            step, alpha, _ = _solve_lsq_trust_region_eig(lam, vg, V, Delta, m, alpha)
+            predicted = -(0.5 * np.einsum("fi,fij,fj->", step, B, step) + np.sum(g * step))
+            x_new = x + step
+            cost_new = fun(x_new)
+            nfev += 1
+            step_h_norm = _norm(step)
+            if not np.isfinite(cost_new):
+                Delta = 0.25 * step_h_norm
+                continue
+            actual = cost - cost_new
+            Delta_new, ratio = _update_tr_radius(Delta, actual, predicted, step_h_norm, step_h_norm > 0.95 * Delta)
+            step_norm = step_h_norm
+            termination = _check_termination(actual, cost, step_norm, _norm(x), ratio, ftol, xtol)
+            if termination is not None:
+                break
+            alpha *= Delta / Delta_new
+            Delta = Delta_new
+        if actual > 0:
+            x, cost = x_new, cost_new
+            B, g = blocks(x)
+            njev += 1
+        else:
+            step_norm = 0
+            actual = 0
+        iteration += 1
+    if termination is None:
+        termination = 0
+    res = BAResult(x=x.reshape(-1), cost=cost, optimality=g_norm, nfev=nfev, njev=njev, status=termination,
+                   message=_MESSAGES[termination], success=termination > 0)
+    if verbose >= 1:
+        _finish_verbose(res, cost0, verbose)
+    return res
+
+
+def adjustPose(frame_extrinsic_matrices, camera_intrinsic_matrix, points_2D):
+    """Pose-only refinement against the fixed chessboard (bundleAdjuster.py:214-243) -> list of F 3x4 extrinsics."""
+    res = solvePose(frame_extrinsic_matrices, camera_intrinsic_matrix, points_2D, ftol=1e-4, verbose=2)
+    return reformatPoseResult(res, len(frame_extrinsic_matrices))

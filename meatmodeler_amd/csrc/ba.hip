@@ -25,13 +25,16 @@ __global__ __launch_bounds__(256) void ba_residual_kernel(mm_ba_problem pb, cons
                                                           double *__restrict__ partial) {
     __shared__ double sm[4];
     __shared__ double Ks[9];
+    __shared__ CamCoef ctab[COEF_MAX_F];
     if (threadIdx.x < 9) Ks[threadIdx.x] = pb.K[threadIdx.x];
+    const bool use_tab = coef_table_fill(ctab, cams, pb.F);
     __syncthreads();
     double acc = 0;
     for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < pb.O; o += (int64_t)gridDim.x * 256) {
         Proj pr;
-        ba_eval<false, false>(cams + (size_t)pb.fi[o] * 6, pts + (size_t)pb.pi[o] * 3, Ks, pb.obs[2 * o],
-                              pb.obs[2 * o + 1], pr);
+        const int f = pb.fi[o];
+        ba_eval_cc<false, false>(cams + (size_t)f * 6, use_tab ? ctab[f] : cam_coef_of(cams + (size_t)f * 6),
+                                 pts + (size_t)pb.pi[o] * 3, Ks, pb.obs[2 * o], pb.obs[2 * o + 1], pr);
         if (res) {
             res[2 * o] = pr.r0;
             res[2 * o + 1] = pr.r1;
@@ -56,13 +59,16 @@ __global__ __launch_bounds__(256) void ba_jacobian_kernel(mm_ba_problem pb, cons
                                                           const double *__restrict__ pts, double *__restrict__ Jc,
                                                           double *__restrict__ Jp) {
     __shared__ double Ks[9];
+    __shared__ CamCoef ctab[COEF_MAX_F];
     if (threadIdx.x < 9) Ks[threadIdx.x] = pb.K[threadIdx.x];
+    const bool use_tab = coef_table_fill(ctab, cams, pb.F);
     __syncthreads();
     int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (o >= pb.O) return;
     Proj pr;
-    ba_eval<true, true>(cams + (size_t)pb.fi[o] * 6, pts + (size_t)pb.pi[o] * 3, Ks, pb.obs[2 * o], pb.obs[2 * o + 1],
-                        pr);
+    const int f = pb.fi[o];
+    ba_eval_cc<true, true>(cams + (size_t)f * 6, use_tab ? ctab[f] : cam_coef_of(cams + (size_t)f * 6),
+                           pts + (size_t)pb.pi[o] * 3, Ks, pb.obs[2 * o], pb.obs[2 * o + 1], pr);
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
         Jc[o * 12 + k] = pr.Jc[0][k];
@@ -80,7 +86,9 @@ __global__ __launch_bounds__(256) void ba_point_blocks_kernel(mm_ba_problem pb, 
                                                               const double *__restrict__ pts, double *__restrict__ C,
                                                               double *__restrict__ gp) {
     __shared__ double Ks[9];
+    __shared__ CamCoef ctab[COEF_MAX_F];
     if (threadIdx.x < 9) Ks[threadIdx.x] = pb.K[threadIdx.x];
+    const bool use_tab = coef_table_fill(ctab, cams, pb.F);
     __syncthreads();
     int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= pb.P) return;
@@ -89,7 +97,9 @@ __global__ __launch_bounds__(256) void ba_point_blocks_kernel(mm_ba_problem pb, 
     for (int e = pb.pt_ptr[p]; e < pb.pt_ptr[p + 1]; ++e) {
         int o = pb.pt_obs[e];
         Proj pr;
-        ba_eval<false, true>(cams + (size_t)pb.fi[o] * 6, Xp, Ks, pb.obs[2 * (size_t)o], pb.obs[2 * (size_t)o + 1], pr);
+        const int f = pb.fi[o];
+        ba_eval_cc<false, true>(cams + (size_t)f * 6, use_tab ? ctab[f] : cam_coef_of(cams + (size_t)f * 6), Xp, Ks,
+                                pb.obs[2 * (size_t)o], pb.obs[2 * (size_t)o + 1], pr);
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             const double j0 = pr.Jp[m][0], j1 = pr.Jp[m][1], j2 = pr.Jp[m][2];
@@ -108,20 +118,22 @@ __global__ __launch_bounds__(256) void ba_point_blocks_kernel(mm_ba_problem pb, 
 __global__ __launch_bounds__(256) void ba_camera_blocks_kernel(mm_ba_problem pb, const double *__restrict__ cams,
                                                                const double *__restrict__ pts, double *__restrict__ B,
                                                                double *__restrict__ gc) {
-    __shared__ double sm[4];
+    __shared__ double smn[4 * 27];
     __shared__ double Ks[9];
     __shared__ double cs[6];
     const int f = blockIdx.x;
     if (threadIdx.x < 9) Ks[threadIdx.x] = pb.K[threadIdx.x];
     if (threadIdx.x < 6) cs[threadIdx.x] = cams[(size_t)f * 6 + threadIdx.x];
     __syncthreads();
+    const CamCoef ccf = cam_coef_of(cs);
     double acc[27];
 #pragma unroll
     for (int i = 0; i < 27; ++i) acc[i] = 0;
     for (int e = pb.cam_ptr[f] + threadIdx.x; e < pb.cam_ptr[f + 1]; e += 256) {
         int o = pb.cam_obs[e];
         Proj pr;
-        ba_eval<true, false>(cs, pts + (size_t)pb.pi[o] * 3, Ks, pb.obs[2 * (size_t)o], pb.obs[2 * (size_t)o + 1], pr);
+        ba_eval_cc<true, false>(cs, ccf, pts + (size_t)pb.pi[o] * 3, Ks, pb.obs[2 * (size_t)o], pb.obs[2 * (size_t)o + 1],
+                                pr);
         int t = 0;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
@@ -133,23 +145,19 @@ __global__ __launch_bounds__(256) void ba_camera_blocks_kernel(mm_ba_problem pb,
             acc[21 + i] += pr.Jc[0][i] * pr.r0 + pr.Jc[1][i] * pr.r1;
         }
     }
-    int t = 0;
+    block_sum_n<27, 256>(acc, smn);
+    if (threadIdx.x == 0) {
+        int t = 0;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+        for (int i = 0; i < 6; ++i) {
 #pragma unroll
-        for (int j = i; j < 6; ++j) {
-            double s = block_sum<256>(acc[t], sm);
-            if (threadIdx.x == 0) {
-                B[(size_t)f * 36 + i * 6 + j] = s;
-                B[(size_t)f * 36 + j * 6 + i] = s;
+            for (int j = i; j < 6; ++j) {
+                B[(size_t)f * 36 + i * 6 + j] = acc[t];
+                B[(size_t)f * 36 + j * 6 + i] = acc[t];
+                ++t;
             }
-            ++t;
+            gc[(size_t)f * 6 + i] = acc[21 + i];
         }
-    }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        double s = block_sum<256>(acc[21 + i], sm);
-        if (threadIdx.x == 0) gc[(size_t)f * 6 + i] = s;
     }
 }
 
@@ -158,13 +166,16 @@ __global__ __launch_bounds__(256) void ba_jvp_kernel(mm_ba_problem pb, const dou
                                                      const double *__restrict__ pts, const double *__restrict__ wc,
                                                      const double *__restrict__ wp, double *__restrict__ out) {
     __shared__ double Ks[9];
+    __shared__ CamCoef ctab[COEF_MAX_F];
     if (threadIdx.x < 9) Ks[threadIdx.x] = pb.K[threadIdx.x];
+    const bool use_tab = coef_table_fill(ctab, cams, pb.F);
     __syncthreads();
     int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (o >= pb.O) return;
     const int f = pb.fi[o], p = pb.pi[o];
     Proj pr;
-    ba_eval<true, true>(cams + (size_t)f * 6, pts + (size_t)p * 3, Ks, pb.obs[2 * o], pb.obs[2 * o + 1], pr);
+    ba_eval_cc<true, true>(cams + (size_t)f * 6, use_tab ? ctab[f] : cam_coef_of(cams + (size_t)f * 6),
+                           pts + (size_t)p * 3, Ks, pb.obs[2 * o], pb.obs[2 * o + 1], pr);
     double y0 = 0, y1 = 0;
     if (wc) {
 #pragma unroll
@@ -192,7 +203,9 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(mm_ba_problem pb, const
                                                          const double *__restrict__ Cinv, const double *__restrict__ gp,
                                                          const double *__restrict__ dc, double *__restrict__ dp) {
     __shared__ double Ks[9];
+    __shared__ CamCoef ctab[COEF_MAX_F];
     if (threadIdx.x < 9) Ks[threadIdx.x] = pb.K[threadIdx.x];
+    const bool use_tab = coef_table_fill(ctab, cams, pb.F);
     __syncthreads();
     int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= pb.P) return;
@@ -202,7 +215,8 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(mm_ba_problem pb, const
         int o = pb.pt_obs[e];
         int f = pb.fi[o];
         Proj pr;
-        ba_eval<true, true>(cams + (size_t)f * 6, Xp, Ks, pb.obs[2 * (size_t)o], pb.obs[2 * (size_t)o + 1], pr);
+        ba_eval_cc<true, true>(cams + (size_t)f * 6, use_tab ? ctab[f] : cam_coef_of(cams + (size_t)f * 6), Xp, Ks,
+                               pb.obs[2 * (size_t)o], pb.obs[2 * (size_t)o + 1], pr);
         double s0 = 0, s1 = 0;
 #pragma unroll
         for (int k = 0; k < 6; ++k) {

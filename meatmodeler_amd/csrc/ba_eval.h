@@ -11,34 +11,52 @@ struct Proj {
     double Jp[2][3];        // d r / d X
 };
 
-template <bool WANT_JC, bool WANT_JP>
-__device__ __forceinline__ void ba_eval(const double *__restrict__ cam, const double *__restrict__ Xp,
-                                        const double *__restrict__ K, double ox, double oy, Proj &o) {
+// Rotation coefficients of one camera: they depend on the camera only, so the sweeps take them from a per-workgroup
+// LDS table (or compute them once per wave) instead of paying a sincos, a sqrt and four divisions per observation.
+struct CamCoef {
+    double c, a, b, a1, b1;  // cos, sin/th, (1-cos)/th^2, (th cos - sin)/th^3, (th sin - 2(1-cos))/th^4
+};
+
+__device__ __forceinline__ CamCoef cam_coef_of(const double *__restrict__ cam) {
     const double rx = cam[0], ry = cam[1], rz = cam[2];
-    const double X0 = Xp[0], X1 = Xp[1], X2 = Xp[2];
     const double th2 = rx * rx + ry * ry + rz * rz;
-    double c, a, b, a1 = 0, b1 = 0;
+    CamCoef k;
     if (th2 < 1e-4) {
-        c = cos(sqrt(th2));
-        a = 1.0 + th2 * (-1.0 / 6 + th2 * (1.0 / 120 - th2 * (1.0 / 5040)));
-        b = 0.5 + th2 * (-1.0 / 24 + th2 * (1.0 / 720 - th2 * (1.0 / 40320)));
-        if (WANT_JC) {
-            a1 = -1.0 / 3 + th2 * (1.0 / 30 + th2 * (-1.0 / 840 + th2 * (1.0 / 45360)));
-            b1 = -1.0 / 12 + th2 * (1.0 / 180 + th2 * (-1.0 / 6720 + th2 * (1.0 / 453600)));
-        }
+        k.c = cos(sqrt(th2));
+        k.a = 1.0 + th2 * (-1.0 / 6 + th2 * (1.0 / 120 - th2 * (1.0 / 5040)));
+        k.b = 0.5 + th2 * (-1.0 / 24 + th2 * (1.0 / 720 - th2 * (1.0 / 40320)));
+        k.a1 = -1.0 / 3 + th2 * (1.0 / 30 + th2 * (-1.0 / 840 + th2 * (1.0 / 45360)));
+        k.b1 = -1.0 / 12 + th2 * (1.0 / 180 + th2 * (-1.0 / 6720 + th2 * (1.0 / 453600)));
     } else {
         const double th = sqrt(th2);
         double s;
-        sincos(th, &s, &c);
+        sincos(th, &s, &k.c);
         const double sh = sin(0.5 * th);
         const double omc = 2.0 * sh * sh;  // 1 - cos, without cancellation
-        a = s / th;
-        b = omc / th2;
-        if (WANT_JC) {
-            a1 = (th * c - s) / (th2 * th);
-            b1 = (th * s - 2.0 * omc) / (th2 * th2);
-        }
+        k.a = s / th;
+        k.b = omc / th2;
+        k.a1 = (th * k.c - s) / (th2 * th);
+        k.b1 = (th * s - 2.0 * omc) / (th2 * th2);
     }
+    return k;
+}
+
+constexpr int COEF_MAX_F = 1024;  // cameras whose coefficients fit the per-workgroup LDS table (40 KB)
+
+// All threads of the workgroup call this, then __syncthreads().  Returns false (table unused) for F > COEF_MAX_F.
+__device__ __forceinline__ bool coef_table_fill(CamCoef *tab, const double *__restrict__ cams, int F) {
+    if (F > COEF_MAX_F) return false;
+    for (int f = threadIdx.x; f < F; f += blockDim.x) tab[f] = cam_coef_of(cams + (size_t)f * 6);
+    return true;
+}
+
+template <bool WANT_JC, bool WANT_JP>
+__device__ __forceinline__ void ba_eval_cc(const double *__restrict__ cam, const CamCoef &cc,
+                                           const double *__restrict__ Xp, const double *__restrict__ K, double ox,
+                                           double oy, Proj &o) {
+    const double rx = cam[0], ry = cam[1], rz = cam[2];
+    const double X0 = Xp[0], X1 = Xp[1], X2 = Xp[2];
+    const double c = cc.c, a = cc.a, b = cc.b, a1 = cc.a1, b1 = cc.b1;
     // r x X and r.X
     const double cx0 = ry * X2 - rz * X1, cx1 = rz * X0 - rx * X2, cx2 = rx * X1 - ry * X0;
     const double rdx = rx * X0 + ry * X1 + rz * X2;
@@ -49,11 +67,11 @@ __device__ __forceinline__ void ba_eval(const double *__restrict__ cam, const do
     const double u0 = K[0] * Y0 + K[1] * Y1 + K[2] * Y2;
     const double u1 = K[3] * Y0 + K[4] * Y1 + K[5] * Y2;
     const double u2 = K[6] * Y0 + K[7] * Y1 + K[8] * Y2;
-    const double p0 = u0 / u2, p1 = u1 / u2;
+    const double iz = 1.0 / u2;
+    const double p0 = u0 * iz, p1 = u1 * iz;
     o.r0 = p0 - ox;
     o.r1 = p1 - oy;
     if (!WANT_JC && !WANT_JP) return;
-    const double iz = 1.0 / u2;
     double M[2][3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -96,10 +114,53 @@ __device__ __forceinline__ void ba_eval(const double *__restrict__ cam, const do
     }
 }
 
+template <bool WANT_JC, bool WANT_JP>
+__device__ __forceinline__ void ba_eval(const double *__restrict__ cam, const double *__restrict__ Xp,
+                                        const double *__restrict__ K, double ox, double oy, Proj &o) {
+    ba_eval_cc<WANT_JC, WANT_JP>(cam, cam_coef_of(cam), Xp, K, ox, oy, o);
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     return v;
+}
+
+// N independent wave sums at once: all N shuffles of a tree level are issued back to back, so their ~100-cycle
+// latencies overlap (N separate wave_sum calls serialise 6 N dependent LDS round trips: 10 us for N = 42).
+template <int N>
+__device__ __forceinline__ void wave_sum_n(double (&v)[N]) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        double t[N];
+#pragma unroll
+        for (int q = 0; q < N; ++q) t[q] = __shfl_down(v[q], off, 64);
+#pragma unroll
+        for (int q = 0; q < N; ++q) v[q] += t[q];
+    }
+}
+
+// N workgroup sums at once (fixed tree: lanes by shuffles, then waves in index order); results valid in thread 0.
+// sm must hold (THREADS / 64) * N doubles.
+template <int N, int THREADS>
+__device__ __forceinline__ void block_sum_n(double (&v)[N], double *sm) {
+    wave_sum_n<N>(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < N; ++q) sm[w * N + q] = v[q];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int q = 0; q < N; ++q) {
+            double t = 0;
+#pragma unroll
+            for (int i = 0; i < THREADS / 64; ++i) t += sm[i * N + q];
+            v[q] = t;
+        }
+    }
 }
 
 // Deterministic workgroup sum (fixed tree); result valid in thread 0.

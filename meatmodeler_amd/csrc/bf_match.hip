@@ -127,6 +127,129 @@ __global__ __launch_bounds__(BF_THREADS) void bf_knn2_kernel(
     }
 }
 
+// LDS-fed variant.  Measured on MI355X (profiles/r01_valu_issue_rates.txt): v_xor_b32 issues in 2 cycles per wave with
+// VGPR operands but in 4 with an SGPR operand; v_bcnt_u32_b32 / v_min / v_med3 / v_lshl_or take 4.  Feeding the train
+// descriptor from VGPRs (two same-address ds_read_b128 = LDS broadcast, on the LDS pipe, not the VALU) makes the eight
+// xors half price: 8*2 + 8*4 + 3*4 = 60 cycles per descriptor pair instead of ~82.  The workgroup stages BF_TCHUNK train
+// descriptors at a time (registers -> LDS, double buffered: the next chunk's global loads fly during the current
+// chunk's compute); all four waves read the same chunk.
+constexpr int BF_TCHUNK = 128;  // trains per LDS stage: 4 KB, one 16-byte piece per thread
+
+__device__ __forceinline__ void top2_insert_med3(uint32_t key, uint32_t &b0, uint32_t &b1) {
+    uint32_t m;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(m) : "v"(b0), "v"(b1), "v"(key));  // middle of three = new second smallest
+    b0 = min(b0, key);
+    b1 = m;
+}
+
+template <int BF_QPL>
+__global__ __launch_bounds__(BF_THREADS) void bf_knn2_lds_kernel(
+    const uint8_t *__restrict__ q, const int32_t *__restrict__ nq_dev, int nq_cap, size_t q_stride,
+    const uint8_t *__restrict__ t, const int32_t *__restrict__ nt_dev, int nt_cap, size_t t_stride, int n_splits,
+    uint32_t *__restrict__ part, int32_t *__restrict__ idx, int32_t *__restrict__ dist) {
+    __shared__ uint4 tl[2][BF_TCHUNK * 2];
+    const int pair = blockIdx.z;
+    const int split = blockIdx.y;
+    int nq = nq_dev ? min(nq_dev[pair], nq_cap) : nq_cap;
+    int nt = nt_dev ? min(nt_dev[pair], nt_cap) : nt_cap;
+    constexpr int BF_QTILE = BF_THREADS * BF_QPL;
+    const int qbase = blockIdx.x * BF_QTILE;
+    if (qbase >= nq) return;  // workgroup-uniform
+
+    uint32_t qa[BF_QPL][8];
+    const uint8_t *qp = q + (size_t)pair * q_stride;
+#pragma unroll
+    for (int u = 0; u < BF_QPL; ++u) {
+        int qi = qbase + u * BF_THREADS + threadIdx.x;
+        uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
+        if (qi < nq) {
+            const uint4 *p = reinterpret_cast<const uint4 *>(qp + (size_t)qi * 32);
+            lo = p[0];
+            hi = p[1];
+        }
+        qa[u][0] = lo.x; qa[u][1] = lo.y; qa[u][2] = lo.z; qa[u][3] = lo.w;
+        qa[u][4] = hi.x; qa[u][5] = hi.y; qa[u][6] = hi.z; qa[u][7] = hi.w;
+    }
+    int chunk = (nt + n_splits - 1) / n_splits;
+    chunk = (chunk + 3) & ~3;
+    const int j0 = split * chunk;
+    const int j1 = min(nt, j0 + chunk);
+    uint32_t b0[BF_QPL], b1[BF_QPL];
+#pragma unroll
+    for (int u = 0; u < BF_QPL; ++u) b0[u] = b1[u] = BF_NONE;
+
+    const uint4 *__restrict__ tp = reinterpret_cast<const uint4 *>(t + (size_t)pair * t_stride);
+    // stage 0
+    uint4 stage = make_uint4(0, 0, 0, 0);
+    if (2 * j0 + (int)threadIdx.x < 2 * j1) stage = tp[2 * j0 + threadIdx.x];
+    tl[0][threadIdx.x] = stage;
+    __syncthreads();
+    int buf = 0;
+    for (int c0 = j0; c0 < j1; c0 += BF_TCHUNK) {
+        const int cn = min(BF_TCHUNK, j1 - c0);
+        const int nxt = c0 + BF_TCHUNK;
+        if (nxt < j1) {  // prefetch the next chunk into registers (in flight during the compute below)
+            stage = make_uint4(0, 0, 0, 0);
+            if (2 * nxt + (int)threadIdx.x < 2 * j1) stage = tp[2 * nxt + threadIdx.x];
+        }
+        const uint4 *tb = tl[buf];
+        int k = 0;
+        for (; k + 4 <= cn; k += 4) {
+            uint4 tv[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) tv[r] = tb[2 * k + r];  // same address in every lane: LDS broadcast
+            uint32_t d[4][BF_QPL];
+            bool hit = false;
+#pragma unroll
+            for (int u = 0; u < BF_QPL; ++u) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) d[r][u] = ham256(qa[u], tv[2 * r], tv[2 * r + 1]);
+                // train indices only grow, so a candidate enters the two smallest keys iff its DISTANCE is strictly
+                // below the current second-best distance; test the group's minimum and skip the bookkeeping otherwise
+                const uint32_t m = min(min(d[0][u], d[1][u]), min(d[2][u], d[3][u]));
+                hit |= m < (b1[u] >> BF_IDX_BITS);
+            }
+            if (__builtin_amdgcn_ballot_w64(hit) != 0) {  // wave-uniform branch, rarely taken after the first trains
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                    for (int u = 0; u < BF_QPL; ++u)
+                        top2_insert_med3((d[r][u] << BF_IDX_BITS) | (uint32_t)(c0 + k + r), b0[u], b1[u]);
+                }
+            }
+        }
+        for (; k < cn; ++k) {
+            const uint4 t0 = tb[2 * k], t1 = tb[2 * k + 1];
+#pragma unroll
+            for (int u = 0; u < BF_QPL; ++u) {
+                uint32_t d = ham256(qa[u], t0, t1);
+                top2_insert_med3((d << BF_IDX_BITS) | (uint32_t)(c0 + k), b0[u], b1[u]);
+            }
+        }
+        if (nxt < j1) {
+            tl[buf ^ 1][threadIdx.x] = stage;
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < BF_QPL; ++u) {
+        int qi = qbase + u * BF_THREADS + threadIdx.x;
+        if (qi >= nq) continue;
+        if (n_splits == 1) {
+            size_t o = ((size_t)pair * nq_cap + qi) * 2;
+            idx[o] = b0[u] == BF_NONE ? -1 : (int32_t)(b0[u] & ((1u << BF_IDX_BITS) - 1));
+            idx[o + 1] = b1[u] == BF_NONE ? -1 : (int32_t)(b1[u] & ((1u << BF_IDX_BITS) - 1));
+            dist[o] = b0[u] == BF_NONE ? -1 : (int32_t)(b0[u] >> BF_IDX_BITS);
+            dist[o + 1] = b1[u] == BF_NONE ? -1 : (int32_t)(b1[u] >> BF_IDX_BITS);
+        } else {
+            size_t o = (((size_t)pair * n_splits + split) * nq_cap + qi) * 2;
+            part[o] = b0[u];
+            part[o + 1] = b1[u];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void bf_merge_kernel(const uint32_t *__restrict__ part,
                                                        const int32_t *__restrict__ nq_dev, int nq_cap, int n_splits,
                                                        int32_t *__restrict__ idx, int32_t *__restrict__ dist) {
@@ -194,11 +317,11 @@ int bf_variant(int n_pairs, int nq_cap) {
     const char *e = getenv("MM_BF_VARIANT");
     const int forced = e ? atoi(e) : 0;
     if (forced) return forced;
-    return ((long)n_pairs * nq_cap >= 262144) ? 24 : 14;
+    return 114;  // LDS-fed, one query per lane, skip-branch bookkeeping: fastest of the measured variants (profiles/r01_bf_variants.txt)
 }
 
 int bf_choose_splits(int n_pairs, int nq_cap, int nt_cap) {
-    const int BF_QTILE = BF_THREADS * (bf_variant(n_pairs, nq_cap) / 10);
+    const int BF_QTILE = BF_THREADS * ((bf_variant(n_pairs, nq_cap) / 10) % 10);
     long waves = (long)n_pairs * ((nq_cap + BF_QTILE - 1) / BF_QTILE) * (BF_THREADS / 64);
     if (waves <= 0) return 1;
     long s = (2048 + waves - 1) / waves;  // aim for >= 2 waves per SIMD on 256 CUs
@@ -234,7 +357,7 @@ int mm_bf_knn2_batched(mm_ctx *ctx, const uint8_t *q, const int32_t *nq, int nq_
     if (s > 1 && (!ws || ws_bytes < mm_bf_workspace_bytes(n_pairs, nq_cap, nt_cap)))
         return mm_fail(ctx, MM_ERR_WORKSPACE, "mm_bf_knn2_batched: workspace too small");
     const int var = bf_variant(n_pairs, nq_cap);
-    const int qtile = BF_THREADS * (var / 10);
+    const int qtile = BF_THREADS * ((var / 10) % 10);
     dim3 grid((nq_cap + qtile - 1) / qtile, s, n_pairs);
 #define BF_GO(Q, U)                                                                                              \
     MM_LAUNCH(ctx, "bf_knn2_kernel", (bf_knn2_kernel<Q, U>), grid, dim3(BF_THREADS), 0, q, nq, nq_cap, q_set_stride, t, \
@@ -247,6 +370,14 @@ int mm_bf_knn2_batched(mm_ctx *ctx, const uint8_t *q, const int32_t *nq, int nq_
         case 34: BF_GO(3, 4); break;
         case 44: BF_GO(4, 4); break;
         case 48: BF_GO(4, 8); break;
+#define BF_GO_LDS(Q)                                                                                             \
+    MM_LAUNCH(ctx, "bf_knn2_kernel", (bf_knn2_lds_kernel<Q>), grid, dim3(BF_THREADS), 0, q, nq, nq_cap, q_set_stride, t, \
+              nt, nt_cap, t_set_stride, s, (uint32_t *)ws, idx, dist)
+        case 114: BF_GO_LDS(1); break;
+        case 124: BF_GO_LDS(2); break;
+        case 134: BF_GO_LDS(3); break;
+        case 144: BF_GO_LDS(4); break;
+#undef BF_GO_LDS
         default: return mm_fail(ctx, MM_ERR_ARG, "mm_bf_knn2_batched: unknown MM_BF_VARIANT %d", var);
     }
 #undef BF_GO

@@ -11,7 +11,9 @@
 // The O(M*T) scan of the reference becomes a hash join on the coordinate bit patterns: observations are nodes of
 // per-track singly linked lists in one pool, the live list is rebuilt per keyframe, the join table is open-addressed.
 #include <cstdint>
+#include <atomic>
 #include <cstring>
+#include <thread>
 #include <vector>
 #include "../../include/meatmodeler.h"
 
@@ -166,22 +168,41 @@ int64_t mm_ba_build_pairs(int F, int P, int64_t O, const int32_t *fi, const int3
     if (O > 0 && (!fi || !pi || !pt_ptr || !pt_obs || !cam_ptr || !cam_obs)) return MM_ERR_ARG;
     const int64_t nseg = (int64_t)F * (span + 1);
     for (int64_t s = 0; s <= nseg; ++s) seg_ptr[s] = 0;
-    for (int i = 0; i < F; ++i)
+    // Both passes are independent per camera i (its segments i*(span+1)+d are touched by no other camera), so they
+    // run on a few host threads over contiguous camera ranges; the result does not depend on the thread count.
+    const int nthreads = F >= 64 ? 8 : 1;
+    std::atomic<int> bad{0};
+    auto for_cameras = [&](auto &&body) {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthreads; ++t) {
+            const int lo = (int)((int64_t)F * t / nthreads), hi = (int)((int64_t)F * (t + 1) / nthreads);
+            pool.emplace_back([&, lo, hi] {
+                for (int i = lo; i < hi; ++i) body(i);
+            });
+        }
+        for (auto &th : pool) th.join();
+    };
+    for_cameras([&](int i) {
         for (int e = cam_ptr[i]; e < cam_ptr[i + 1]; ++e) {
             const int p = pi[cam_obs[e]];
             for (int e2 = pt_ptr[p]; e2 < pt_ptr[p + 1]; ++e2) {
                 const int d = i - fi[pt_obs[e2]];
                 if (d < 0) continue;
-                if (d > span) return MM_ERR_ARG;  // span too small for this problem
+                if (d > span) {
+                    bad = 1;  // span too small for this problem
+                    continue;
+                }
                 ++seg_ptr[(int64_t)i * (span + 1) + d + 1];
             }
         }
+    });
+    if (bad) return MM_ERR_ARG;
     for (int64_t s = 0; s < nseg; ++s) seg_ptr[s + 1] += seg_ptr[s];
     const int64_t n = seg_ptr[nseg];
     if (!pair_o || !pair_o2) return n;
     if (n > max_pairs) return MM_ERR_WORKSPACE;
     std::vector<int64_t> cur(seg_ptr, seg_ptr + nseg);
-    for (int i = 0; i < F; ++i)
+    for_cameras([&](int i) {
         for (int e = cam_ptr[i]; e < cam_ptr[i + 1]; ++e) {
             const int o = cam_obs[e];
             const int p = pi[o];
@@ -194,6 +215,7 @@ int64_t mm_ba_build_pairs(int F, int P, int64_t O, const int32_t *fi, const int3
                 pair_o2[w] = o2;
             }
         }
+    });
     return n;
 }
 

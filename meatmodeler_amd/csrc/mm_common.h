@@ -17,7 +17,7 @@ struct mm_ctx {
     hipStream_t stream;
     char err[512];
     // optional per-launch HIP-event profiling (mm_profile_*): bench.py's live roofline measurement
-    bool prof = false;
+    int prof = 0;  // 0 off, 1 every launch, 2 only launches of >= 64 workgroups (micro-launch chains stay untouched)
     std::vector<mm_prof_rec> recs;
     std::vector<hipEvent_t> pool;
 };
@@ -37,13 +37,15 @@ static inline hipEvent_t mm_prof_event(mm_ctx *c) {
 #define MM_LAUNCH(ctx, name, kernel, grid, block, shmem, ...)                                          \
     do {                                                                                               \
         hipEvent_t ea_ = nullptr, eb_ = nullptr;                                                       \
-        if ((ctx)->prof) {                                                                             \
+        const dim3 g_ = (grid);                                                                        \
+        const bool p_ = (ctx)->prof == 1 || ((ctx)->prof == 2 && (size_t)g_.x * g_.y * g_.z >= 64);    \
+        if (p_) {                                                                                      \
             ea_ = mm_prof_event(ctx);                                                                  \
             eb_ = mm_prof_event(ctx);                                                                  \
             (void)hipEventRecord(ea_, (ctx)->stream);                                                  \
         }                                                                                              \
-        hipLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, __VA_ARGS__);                    \
-        if ((ctx)->prof) {                                                                             \
+        hipLaunchKernelGGL(kernel, g_, block, shmem, (ctx)->stream, __VA_ARGS__);                      \
+        if (p_) {                                                                                      \
             (void)hipEventRecord(eb_, (ctx)->stream);                                                  \
             (ctx)->recs.push_back(mm_prof_rec{name, ea_, eb_});                                        \
         }                                                                                              \

@@ -41,7 +41,7 @@ int mm_profile_enable(mm_ctx *ctx, int on) {
         }
         ctx->recs.clear();
     }
-    ctx->prof = on != 0;
+    ctx->prof = on < 0 ? 0 : on;
     return MM_OK;
 }
 

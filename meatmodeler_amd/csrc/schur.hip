@@ -116,33 +116,32 @@ __global__ __launch_bounds__(256) void schur_rows_kernel(mm_ba_problem pb, const
 // S is summed in the same order on every run — the trust-region iteration, which is chaotic on outlier-laden matches,
 // then repeats bit for bit.  No atomics; only the LOWER block triangle is produced (S is zero-filled first).
 constexpr int SP_WAVES = 4;
-__global__ __launch_bounds__(64 * SP_WAVES) void schur_pairs_kernel(mm_ba_problem pb, const double *__restrict__ cams,
+// launch bound 2 waves per SIMD: 256 VGPRs (68 B of scratch) instead of 271 -> twice the waves to hide the f64 latency
+__global__ __launch_bounds__(64 * SP_WAVES, 2) void schur_pairs_kernel(mm_ba_problem pb, const double *__restrict__ cams,
                                                                     const double *__restrict__ pts,
-                                                                    const double *__restrict__ Bd,
                                                                     const double *__restrict__ Cinv,
-                                                                    const double *__restrict__ gc,
-                                                                    const double *__restrict__ gp, double *__restrict__ S,
-                                                                    double *__restrict__ v) {
+                                                                    const double *__restrict__ gp,
+                                                                    double *__restrict__ partial) {
     __shared__ double Ks[9];
     if (threadIdx.x < 9) Ks[threadIdx.x] = pb.K[threadIdx.x];
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int64_t sidx = (int64_t)blockIdx.x * SP_WAVES + (threadIdx.x >> 6);
-    if (sidx >= pb.n_seg) return;  // wave-uniform; no workgroup barriers below
-    const int seg = pb.seg_ids[sidx];
+    const int64_t c = (int64_t)blockIdx.x * SP_WAVES + (threadIdx.x >> 6);
+    if (c >= pb.n_chunks) return;  // wave-uniform; no workgroup barriers below
+    const int seg = pb.seg_ids[pb.chunk_seg[c]];
     const int i = seg / (pb.cam_span + 1), d = seg % (pb.cam_span + 1);
     const int f2 = i - d;
-    const size_t n = (size_t)pb.F * 6;
     const double *ci_cam = cams + (size_t)i * 6, *c2_cam = cams + (size_t)f2 * 6;
+    const CamCoef cc_i = cam_coef_of(ci_cam), cc_2 = cam_coef_of(c2_cam);  // two cameras per chunk, not per pair
     double acc[42];
 #pragma unroll
     for (int q = 0; q < 42; ++q) acc[q] = 0.0;
-    for (int64_t e = pb.seg_ptr[sidx] + lane; e < pb.seg_ptr[sidx + 1]; e += 64) {
+    for (int e = pb.chunk_begin[c] + lane; e < pb.chunk_end[c]; e += 64) {
         const int o = pb.pair_o[e], o2 = pb.pair_o2[e];
         const int p = pb.pi[o];
         const double *Xp = pts + (size_t)p * 3;
         Proj pr;
-        ba_eval<true, true>(ci_cam, Xp, Ks, pb.obs[2 * (size_t)o], pb.obs[2 * (size_t)o + 1], pr);
+        ba_eval_cc<true, true>(ci_cam, cc_i, Xp, Ks, pb.obs[2 * (size_t)o], pb.obs[2 * (size_t)o + 1], pr);
         const double *ci = Cinv + (size_t)p * 6;
         const double q00 = ci[0], q01 = ci[1], q02 = ci[2], q11 = ci[3], q12 = ci[4], q22 = ci[5];
         double Y[6][3];
@@ -161,7 +160,7 @@ __global__ __launch_bounds__(64 * SP_WAVES) void schur_pairs_kernel(mm_ba_proble
             for (int a = 0; a < 6; ++a) acc[36 + a] += Y[a][0] * g0 + Y[a][1] * g1 + Y[a][2] * g2;
         }
         Proj p2;
-        ba_eval<true, true>(c2_cam, Xp, Ks, pb.obs[2 * (size_t)o2], pb.obs[2 * (size_t)o2 + 1], p2);
+        ba_eval_cc<true, true>(c2_cam, cc_2, Xp, Ks, pb.obs[2 * (size_t)o2], pb.obs[2 * (size_t)o2 + 1], p2);
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
             const double x0 = p2.Jc[0][b] * p2.Jp[0][0] + p2.Jc[1][b] * p2.Jp[1][0];
@@ -171,21 +170,34 @@ __global__ __launch_bounds__(64 * SP_WAVES) void schur_pairs_kernel(mm_ba_proble
             for (int a = 0; a < 6; ++a) acc[a * 6 + b] += Y[a][0] * x0 + Y[a][1] * x1 + Y[a][2] * x2;
         }
     }
-    const int nred = d == 0 ? 42 : 36;
+    wave_sum_n<42>(acc);
+    if (lane == 0) {
 #pragma unroll
-    for (int q = 0; q < 42; ++q) {
-        if (q < nred) {
-            const double s = wave_sum(acc[q]);
-            if (lane == 0) {
-                if (q < 36) {
-                    double val = -s;
-                    if (d == 0) val += Bd[(size_t)i * 36 + q];
-                    S[((size_t)i * 6 + q / 6) * n + (size_t)f2 * 6 + q % 6] = val;
-                } else {
-                    v[(size_t)i * 6 + (q - 36)] = gc[(size_t)i * 6 + (q - 36)] - s;
-                }
-            }
-        }
+        for (int q = 0; q < 42; ++q) partial[c * 42 + q] = acc[q];
+    }
+}
+
+// Second pass: entry q of segment sidx = sum of its chunks' partials in chunk order (fixed order -> reproducible).
+__global__ __launch_bounds__(256) void schur_pairs_reduce_kernel(mm_ba_problem pb, const double *__restrict__ partial,
+                                                                 const double *__restrict__ Bd,
+                                                                 const double *__restrict__ gc, double *__restrict__ S,
+                                                                 double *__restrict__ v) {
+    const int q = threadIdx.x & 63;
+    const int64_t sidx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (sidx >= pb.n_seg || q >= 42) return;
+    const int seg = pb.seg_ids[sidx];
+    const int i = seg / (pb.cam_span + 1), d = seg % (pb.cam_span + 1);
+    const int f2 = i - d;
+    if (q >= 36 && d != 0) return;
+    double s = 0.0;
+    for (int c = pb.seg_chunk_ptr[sidx]; c < pb.seg_chunk_ptr[sidx + 1]; ++c) s += partial[(size_t)c * 42 + q];
+    const size_t n = (size_t)pb.F * 6;
+    if (q < 36) {
+        double val = -s;
+        if (d == 0) val += Bd[(size_t)i * 36 + q];
+        S[((size_t)i * 6 + q / 6) * n + (size_t)f2 * 6 + q % 6] = val;
+    } else {
+        v[(size_t)i * 6 + (q - 36)] = gc[(size_t)i * 6 + (q - 36)] - s;
     }
 }
 
@@ -199,11 +211,77 @@ __global__ void schur_diag_fill_kernel(mm_ba_problem pb, const double *__restric
     if (threadIdx.x < 6) v[(size_t)i * 6 + threadIdx.x] = gc[(size_t)i * 6 + threadIdx.x];
 }
 
+// ---- device-side construction of the co-observation pair list ------------------------------------------------------
+// cnt[o] = number of observations o2 of the same point with camera(o2) <= camera(o); span = max camera distance.
+__global__ __launch_bounds__(256) void pairs_count_kernel(mm_ba_problem pb, int32_t *__restrict__ cnt,
+                                                          int32_t *__restrict__ span_out) {
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int dmax = 0;
+    if (o < pb.O) {
+        const int f = pb.fi[o], p = pb.pi[o];
+        int c = 0;
+        for (int e = pb.pt_ptr[p]; e < pb.pt_ptr[p + 1]; ++e) {
+            const int d = f - pb.fi[pb.pt_obs[e]];
+            c += d >= 0;
+            dmax = max(dmax, d);
+        }
+        cnt[o] = c;
+    }
+    for (int off = 32; off > 0; off >>= 1) dmax = max(dmax, __shfl_down(dmax, off, 64));
+    if ((threadIdx.x & 63) == 0 && dmax > 0) atomicMax(span_out, dmax);
+}
+
+// writes the pairs of observation o at offsets[o]..: key = camera(o) * (span + 1) + camera(o) - camera(o2)
+__global__ __launch_bounds__(256) void pairs_emit_kernel(mm_ba_problem pb, const int64_t *__restrict__ offsets, int span,
+                                                         int32_t *__restrict__ key, int32_t *__restrict__ po,
+                                                         int32_t *__restrict__ po2) {
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= pb.O) return;
+    const int f = pb.fi[o], p = pb.pi[o];
+    int64_t w = offsets[o];
+    for (int e = pb.pt_ptr[p]; e < pb.pt_ptr[p + 1]; ++e) {
+        const int o2 = pb.pt_obs[e];
+        const int d = f - pb.fi[o2];
+        if (d < 0) continue;
+        key[w] = f * (span + 1) + d;
+        po[w] = (int32_t)o;
+        po2[w] = o2;
+        ++w;
+    }
+}
+
 }  // namespace
+
+extern "C" int mm_ba_pairs_count(mm_ctx *ctx, const mm_ba_problem *pb, int32_t *cnt, int32_t *span_out) {
+    if (!ctx) return MM_ERR_ARG;
+    if (!pb || !cnt || !span_out || (pb->O > 0 && (!pb->fi || !pb->pi || !pb->pt_ptr || !pb->pt_obs)))
+        return mm_fail(ctx, MM_ERR_ARG, "mm_ba_pairs_count: bad argument");
+    MM_HIP(ctx, hipMemsetAsync(span_out, 0, sizeof(int32_t), ctx->stream));
+    if (pb->O == 0) return MM_OK;
+    MM_LAUNCH(ctx, "pairs_count_kernel", pairs_count_kernel, dim3((unsigned)((pb->O + 255) / 256)), dim3(256), 0, *pb, cnt,
+              span_out);
+    return MM_OK;
+}
+
+extern "C" int mm_ba_pairs_emit(mm_ctx *ctx, const mm_ba_problem *pb, const int64_t *offsets, int span, int32_t *key,
+                                int32_t *pair_o, int32_t *pair_o2) {
+    if (!ctx) return MM_ERR_ARG;
+    if (!pb || !offsets || !key || !pair_o || !pair_o2 || span < 0) return mm_fail(ctx, MM_ERR_ARG, "mm_ba_pairs_emit: bad argument");
+    if (pb->O == 0) return MM_OK;
+    if ((int64_t)pb->F * (span + 1) > 0x7fffffffLL) return mm_fail(ctx, MM_ERR_ARG, "mm_ba_pairs_emit: F * (span + 1) overflows the key");
+    MM_LAUNCH(ctx, "pairs_emit_kernel", pairs_emit_kernel, dim3((unsigned)((pb->O + 255) / 256)), dim3(256), 0, *pb, offsets,
+              span, key, pair_o, pair_o2);
+    return MM_OK;
+}
+
+extern "C" size_t mm_ba_schur_workspace_bytes(const mm_ba_problem *pb) {
+    if (!pb || pb->n_chunks <= 0) return 0;
+    return mm_align_up((size_t)pb->n_chunks * 42 * sizeof(double), 256);
+}
 
 extern "C" int mm_ba_schur(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, const double *pts,
                            const double *Bd, const double *Cd, const double *gc, const double *gp, double *S, double *v,
-                           double *Cinv) {
+                           double *Cinv, void *ws, size_t ws_bytes) {
     if (!ctx) return MM_ERR_ARG;
     if (!pb || pb->F < 0 || pb->P < 0 || pb->O < 0 || !pb->K) return mm_fail(ctx, MM_ERR_ARG, "mm_ba_schur: bad problem");
     if (!cams || !pts || !Bd || !Cd || !gc || !gp || !S || !v || !Cinv || !pb->pt_ptr || !pb->cam_ptr ||
@@ -213,13 +291,17 @@ extern "C" int mm_ba_schur(mm_ctx *ctx, const mm_ba_problem *pb, const double *c
     if (pb->P > 0)
         MM_LAUNCH(ctx, "point_inverse_kernel", point_inverse_kernel, dim3((pb->P + 255) / 256), dim3(256), 0, pb->P, Cd,
                   Cinv);
-    if (pb->n_seg > 0 && pb->seg_ids && pb->seg_ptr && pb->pair_o && pb->pair_o2) {
+    if (pb->n_seg > 0 && pb->n_chunks > 0 && pb->seg_ids && pb->seg_chunk_ptr && pb->chunk_seg && pb->chunk_begin &&
+        pb->chunk_end && pb->pair_o && pb->pair_o2) {
+        if (!ws || ws_bytes < mm_ba_schur_workspace_bytes(pb)) return mm_fail(ctx, MM_ERR_WORKSPACE, "mm_ba_schur: workspace too small");
         // banded + deterministic: zero S (the Cholesky touches whole 64-blocks of the band), then the lower blocks
         MM_HIP(ctx, hipMemsetAsync(S, 0, (size_t)pb->F * 6 * pb->F * 6 * sizeof(double), ctx->stream));
         MM_LAUNCH(ctx, "schur_diag_fill_kernel", schur_diag_fill_kernel, dim3(pb->F), dim3(64), 0, *pb, Bd, gc, S, v);
-        const int64_t wgs = (pb->n_seg + SP_WAVES - 1) / SP_WAVES;
+        const int64_t wgs = (pb->n_chunks + SP_WAVES - 1) / SP_WAVES;
         MM_LAUNCH(ctx, "schur_pairs_kernel", schur_pairs_kernel, dim3((unsigned)wgs), dim3(64 * SP_WAVES), 0, *pb, cams,
-                  pts, Bd, Cinv, gc, gp, S, v);
+                  pts, Cinv, gp, (double *)ws);
+        MM_LAUNCH(ctx, "schur_pairs_reduce_kernel", schur_pairs_reduce_kernel, dim3((unsigned)((pb->n_seg + 3) / 4)),
+                  dim3(256), 0, *pb, (const double *)ws, Bd, gc, S, v);
         return MM_OK;
     }
     const int nwin = (pb->F + SR_WIN - 1) / SR_WIN;

@@ -158,62 +158,98 @@ class BADevice:
     """Device-resident BA problem: observation arrays, CSR indices and the mm_ba_problem descriptor."""
 
     def __init__(self, K, fi, pi, obs, F, P, device, ctx=None, pairs=True, max_band_span=192):
+        """fi, pi: int [O] (numpy or device tensors), obs [O,2] f64 (numpy or device tensor).  All index structures
+        (CSR by point, CSR by camera, co-observation pair list and its chunk table) are built on the device: torch
+        provides the sorts / scans (index plumbing), two HIP kernels enumerate the pairs."""
         self.ctx = ctx or default_context()
-        self.F, self.P, self.O = int(F), int(P), int(len(fi))
-        fi = np.ascontiguousarray(fi, np.int32)
-        pi = np.ascontiguousarray(pi, np.int32)
-        pt_ptr, pt_obs, cam_ptr, cam_obs = ba_build_index(self.F, self.P, fi, pi)
-        # widest camera span of any point: cameras further apart never share a point, so the reduced camera system
-        # is block banded with this half-width (tracks from consecutive-keyframe matching span a few frames only)
-        self.cam_span = 0
-        if self.O:
-            fs = fi[pt_obs]
-            nz = np.flatnonzero(np.diff(pt_ptr) > 0)
-            starts = pt_ptr[:-1][nz]
-            self.cam_span = int((np.maximum.reduceat(fs, starts) - np.minimum.reduceat(fs, starts)).max())
         dev = device
-        self.K = torch.as_tensor(np.ascontiguousarray(K, np.float64).reshape(9)).to(dev)
-        self.fi = torch.as_tensor(fi).to(dev)
-        self.pi = torch.as_tensor(pi).to(dev)
-        self.obs = torch.as_tensor(np.ascontiguousarray(obs, np.float64).reshape(-1, 2)).to(dev)
-        self.pt_ptr = torch.as_tensor(pt_ptr).to(dev)
-        self.pt_obs = torch.as_tensor(np.ascontiguousarray(pt_obs)).to(dev)
-        self.cam_ptr = torch.as_tensor(cam_ptr).to(dev)
-        self.cam_obs = torch.as_tensor(np.ascontiguousarray(cam_obs)).to(dev)
         self.device = dev
-        self.pb = BAProblem(self.F, self.P, self.O, ptr(self.K), ptr(self.fi), ptr(self.pi), ptr(self.obs),
+        self.F, self.P, self.O = int(F), int(P), int(len(fi))
+        F, P, O = self.F, self.P, self.O
+
+        def to_dev(a, dtype):
+            if isinstance(a, torch.Tensor):
+                return a.to(device=dev, dtype=dtype).contiguous()
+            return torch.as_tensor(np.ascontiguousarray(a)).to(device=dev, dtype=dtype).contiguous()
+
+        self.K = to_dev(np.asarray(K, np.float64).reshape(9), torch.float64)
+        self.fi = to_dev(fi, torch.int32).reshape(-1)
+        self.pi = to_dev(pi, torch.int32).reshape(-1)
+        self.obs = to_dev(obs, torch.float64).reshape(-1, 2)
+        i64 = dict(dtype=torch.int64, device=dev)
+        if O:
+            lim = torch.stack([self.fi.min(), self.fi.max(), self.pi.min(), self.pi.max(),
+                               (self.pi[1:] >= self.pi[:-1]).all().to(torch.int32)]).tolist()
+            if lim[0] < 0 or lim[1] >= F or lim[2] < 0 or lim[3] >= P:
+                raise ValueError("frame / point index out of range")
+            point_major = bool(lim[4])
+        else:
+            point_major = True
+        # CSR by point (identity permutation when the observations are already point-major, as managePoints emits them)
+        if point_major:
+            self.pt_obs = torch.arange(O, dtype=torch.int32, device=dev)
+        else:
+            self.pt_obs = torch.sort(self.pi, stable=True)[1].to(torch.int32)
+        self.pt_ptr = torch.zeros(P + 1, dtype=torch.int32, device=dev)
+        self.cam_ptr = torch.zeros(F + 1, dtype=torch.int32, device=dev)
+        if O:
+            self.pt_ptr[1:] = torch.cumsum(torch.bincount(self.pi, minlength=P), 0).to(torch.int32)
+            self.cam_ptr[1:] = torch.cumsum(torch.bincount(self.fi, minlength=F), 0).to(torch.int32)
+            self.cam_obs = torch.sort(self.fi, stable=True)[1].to(torch.int32)      # stable: observation order kept
+        else:
+            self.cam_obs = torch.zeros(0, dtype=torch.int32, device=dev)
+        self.cam_span = 0
+        self.pb = BAProblem(F, P, O, ptr(self.K), ptr(self.fi), ptr(self.pi), ptr(self.obs),
                             ptr(self.pt_ptr), ptr(self.pt_obs), ptr(self.cam_ptr), ptr(self.cam_obs),
-                            self.cam_span, 0, 0, None, None, None, None)
-        # banded problems (tracks from consecutive-keyframe matching): co-observation pair list for the atomic-free,
-        # bitwise reproducible Schur kernel; wide spans keep the general kernel
+                            0, 0, 0, None, None, 0, None, None, None, None, None)
         self.n_pairs = 0
-        if pairs and self.O and self.cam_span <= max_band_span and self.cam_span < self.F:
-            i32p, i64p = _lib.c_i32p, _lib.c_i64p
-            nseg = self.F * (self.cam_span + 1)
-            seg_ptr = np.zeros(nseg + 1, np.int64)
-            args = (self.F, self.P, self.O, fi.ctypes.data_as(i32p), pi.ctypes.data_as(i32p),
-                    pt_ptr.ctypes.data_as(i32p), np.ascontiguousarray(pt_obs).ctypes.data_as(i32p),
-                    cam_ptr.ctypes.data_as(i32p), np.ascontiguousarray(cam_obs).ctypes.data_as(i32p), self.cam_span,
-                    seg_ptr.ctypes.data_as(i64p))
-            n = lib.mm_ba_build_pairs(*args, None, None, 0)
-            if n < 0:
-                raise _lib.MMError(f"mm_ba_build_pairs failed ({n})")
-            po = np.empty(max(n, 1), np.int32)
-            po2 = np.empty(max(n, 1), np.int32)
-            n2 = lib.mm_ba_build_pairs(*args, po.ctypes.data_as(i32p), po2.ctypes.data_as(i32p), n)
-            assert n2 == n
-            ne = np.flatnonzero(np.diff(seg_ptr) > 0)
-            self.seg_ids = torch.as_tensor(ne.astype(np.int32)).to(dev)
-            self.seg_ptr = torch.as_tensor(np.concatenate([seg_ptr[ne], seg_ptr[-1:]]).astype(np.int64)).to(dev)
-            self.pair_o = torch.as_tensor(po[:n]).to(dev)
-            self.pair_o2 = torch.as_tensor(po2[:n]).to(dev)
-            self.n_pairs = int(n)
-            self.pb.n_seg = len(ne)
-            self.pb.seg_ids, self.pb.seg_ptr = ptr(self.seg_ids), ptr(self.seg_ptr)
-            self.pb.pair_o, self.pb.pair_o2 = ptr(self.pair_o), ptr(self.pair_o2)
+        if O:
+            # widest camera span of any point: cameras further apart never share a point, so the reduced camera system
+            # is block banded with this half-width (tracks from consecutive-keyframe matching span a few frames only)
+            cnt = torch.empty(O, dtype=torch.int32, device=dev)
+            span_t = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.ctx.check(lib.mm_ba_pairs_count(self.ctx.h, C.byref(self.pb), ptr(cnt), ptr(span_t)),
+                           "mm_ba_pairs_count")
+            offs = torch.cumsum(cnt, 0, dtype=torch.int64)
+            span, n = torch.stack([span_t[0].to(torch.int64), offs[-1]]).tolist()
+            self.cam_span = int(span)
+            self.pb.cam_span = self.cam_span
+            # banded problems: co-observation pair list for the atomic-free, bitwise reproducible Schur kernel;
+            # wide spans keep the general kernel
+            if pairs and self.cam_span <= max_band_span and self.cam_span < F and F * (self.cam_span + 1) < 2 ** 31:
+                key = torch.empty(n, dtype=torch.int32, device=dev)
+                po = torch.empty(n, dtype=torch.int32, device=dev)
+                po2 = torch.empty(n, dtype=torch.int32, device=dev)
+                offs_ex = (offs - cnt).contiguous()
+                self.ctx.check(lib.mm_ba_pairs_emit(self.ctx.h, C.byref(self.pb), ptr(offs_ex), self.cam_span, ptr(key),
+                                                    ptr(po), ptr(po2)), "mm_ba_pairs_emit")
+                key_s, perm = torch.sort(key, stable=True)          # fixed order inside every segment
+                self.pair_o, self.pair_o2 = po[perm].contiguous(), po2[perm].contiguous()
+                seg_ids, counts = torch.unique_consecutive(key_s, return_counts=True)
+                seg_hi = torch.cumsum(counts, 0)
+                seg_lo = seg_hi - counts
+                CH = 256                                             # pairs per chunk (one wave, four lane strides)
+                cntc = (counts + (CH - 1)) // CH
+                first_hi = torch.cumsum(cntc, 0)
+                first = first_hi - cntc
+                nchunks = int(first_hi[-1].item())
+                chunk_seg = torch.repeat_interleave(torch.arange(len(seg_ids), **i64), cntc, output_size=nchunks)
+                chunk_begin = seg_lo[chunk_seg] + CH * (torch.arange(nchunks, **i64) - first[chunk_seg])
+                chunk_end = torch.minimum(chunk_begin + CH, seg_hi[chunk_seg])
+                i32 = lambda t: t.to(torch.int32).contiguous()
+                self.seg_ids = i32(seg_ids)
+                self.seg_chunk_ptr = i32(torch.cat([first, first_hi[-1:]]))
+                self.chunk_seg, self.chunk_begin, self.chunk_end = i32(chunk_seg), i32(chunk_begin), i32(chunk_end)
+                self.n_pairs = int(n)
+                self.pb.n_seg = len(seg_ids)
+                self.pb.n_chunks = nchunks
+                self.pb.seg_ids, self.pb.seg_chunk_ptr = ptr(self.seg_ids), ptr(self.seg_chunk_ptr)
+                self.pb.chunk_seg, self.pb.chunk_begin, self.pb.chunk_end = ptr(self.chunk_seg), ptr(self.chunk_begin), ptr(self.chunk_end)
+                self.pb.pair_o, self.pb.pair_o2 = ptr(self.pair_o), ptr(self.pair_o2)
         self._ws = torch.empty(2048 * 8, dtype=torch.uint8, device=dev)
         self._cost2 = torch.zeros(1, dtype=torch.float64, device=dev)
         self._S = None  # reduced camera system, allocated once (6F x 6F doubles)
+        self._schur_ws = None
 
     def residual(self, cams, pts, want_res=False):
         """-> (sum of squared residuals as a 1-element device tensor, res [O,2] or None)."""
@@ -255,8 +291,12 @@ class BADevice:
         S = self._S
         v = torch.empty(n, dtype=torch.float64, device=self.device)
         Cinv = torch.empty((self.P, 6), dtype=torch.float64, device=self.device)
+        if self._schur_ws is None:
+            nb = lib.mm_ba_schur_workspace_bytes(C.byref(self.pb))
+            self._schur_ws = torch.empty(max(nb, 256), dtype=torch.uint8, device=self.device)
         self.ctx.check(lib.mm_ba_schur(self.ctx.h, C.byref(self.pb), ptr(cams), ptr(pts), ptr(Bd), ptr(Cd), ptr(gc),
-                                       ptr(gp), ptr(S), ptr(v), ptr(Cinv)), "mm_ba_schur")
+                                       ptr(gp), ptr(S), ptr(v), ptr(Cinv), ptr(self._schur_ws),
+                                       self._schur_ws.numel()), "mm_ba_schur")
         return S, v, Cinv
 
     def chol_solve(self, S, v, half_bandwidth=None):

@@ -42,6 +42,20 @@ def partition_points(fi, pi, n_points, rank, world):
     return lo, hi, mask
 
 
+def partition_tracks(track_ptr, rank, world):
+    """Same split for CSR tracks (point-major observations): -> (p_lo, p_hi, o_lo, o_hi) — the rank's points and
+    the contiguous observation range that belongs to them."""
+    track_ptr = np.asarray(track_ptr)
+    P = len(track_ptr) - 1
+    total = int(track_ptr[-1])
+    bounds = [int(np.searchsorted(track_ptr, total * r / world, side="left")) for r in range(world)] + [P]
+    bounds[0] = 0
+    for r in range(1, world + 1):
+        bounds[r] = min(max(bounds[r], bounds[r - 1]), P)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    return lo, hi, int(track_ptr[lo]), int(track_ptr[hi])
+
+
 class AllReduce:
     """Callable all-reduce over a torch.distributed process group (in place)."""
 

@@ -185,22 +185,27 @@ class ClipPipeline:
         if not ba or len(obs_frame) == 0:
             return out
         tic("ba")
-        coords, fi, pi = self.flatten(track_ptr, obs_frame, obs_kp, xy_h)
         P = len(track_ptr) - 1
         with np.errstate(all="ignore"):
             cams0 = frameParameters(ext).reshape(F, 6)
-        X_h = None
+        # managePoints order (point-major, insertion order inside a track), assembled on the device
+        d = self.device
         if world > 1:
-            lo, hi, mask = parallel.partition_points(fi, pi, P, rank, world)
-            pb = ops.BADevice(K, fi[mask], pi[mask] - lo, coords[mask], F, hi - lo, self.device, self.ctx)
-            pts0 = X[lo:hi].contiguous()
-            solver = SchurTRF(pb, allreduce=parallel.AllReduce())
+            lo, hi, o_lo, o_hi = parallel.partition_tracks(track_ptr, rank, world)
         else:
-            pb = ops.BADevice(K, fi, pi, coords, F, P, self.device, self.ctx)
-            pts0 = X
-            solver = SchurTRF(pb)
+            lo, hi, o_lo, o_hi = 0, P, 0, len(obs_frame)
+        of_d = torch.as_tensor(np.ascontiguousarray(obs_frame[o_lo:o_hi])).to(d)
+        ok_d = torch.as_tensor(np.ascontiguousarray(obs_kp[o_lo:o_hi])).to(d)
+        lens = torch.as_tensor(np.diff(track_ptr[lo:hi + 1])).to(d)
+        pi_d = torch.repeat_interleave(torch.arange(hi - lo, dtype=torch.int32, device=d), lens, output_size=o_hi - o_lo)
+        coords_d = xy_dev[of_d.long(), ok_d.long()].to(torch.float64)
+        pb = ops.BADevice(K, of_d, pi_d, coords_d, F, hi - lo, d, self.ctx)
+        pts0 = X[lo:hi].contiguous()
+        solver = SchurTRF(pb, allreduce=parallel.AllReduce() if world > 1 else None)
         cams_d = torch.as_tensor(cams0).to(self.device)
+        tic("ba_solve")
         res = solver.solve(cams_d, pts0, ftol=ftol, verbose=verbose if rank == 0 else 0)
+        toc("ba_solve")
         toc("ba")
         out.update(ba=res, n_obs_local=pb.O, cam_span=pb.cam_span, n_pairs=pb.n_pairs)
         T.pop("_open", None)

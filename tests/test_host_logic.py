@@ -273,3 +273,29 @@ def test_brief_pattern_is_fixed_and_inside_the_disc():
 
 
 PATTERN_SHA1 = "12fa8b026f52705ed79d4c58f8d8ff7fe21aba5a"
+
+
+def test_exact_trust_region_on_block_diagonal_matches_scipy():
+    """adjustPose's trust-region solve on per-camera 6x6 eigen-decompositions == SciPy's SVD-based
+    solve_lsq_trust_region on the dense block-diagonal Jacobian."""
+    from scipy.optimize._lsq.common import solve_lsq_trust_region
+    from scipy.linalg import svd
+    rng = np.random.default_rng(4)
+    F, rows = 5, 24
+    blocks = rng.normal(size=(F, rows, 6)) * rng.uniform(0.1, 30, size=(F, 1, 6))
+    J = np.zeros((F * rows, F * 6))
+    for f in range(F):
+        J[f * rows:(f + 1) * rows, f * 6:(f + 1) * 6] = blocks[f]
+    r = rng.normal(size=F * rows) * 5
+    U, s, Vt = svd(J, full_matrices=False)
+    uf = U.T @ r
+    B = np.einsum("fri,frj->fij", blocks, blocks)
+    g = np.einsum("fri,fr->fi", blocks, r.reshape(F, rows))
+    lam, V = np.linalg.eigh(B)
+    vg = np.einsum("fji,fj->fi", V, g)
+    for Delta in (1e-3, 0.05, 0.5, 1e3):
+        for a0 in (0.0, 0.7):
+            p_ref, alpha_ref, it_ref = solve_lsq_trust_region(F * 6, F * rows, uf, s, Vt.T, Delta, initial_alpha=a0)
+            p, alpha, it = bundleAdjuster._solve_lsq_trust_region_eig(lam, vg, V, Delta, F * rows, a0)
+            np.testing.assert_allclose(p.ravel(), p_ref, rtol=1e-9, atol=1e-12)
+            assert it == it_ref and abs(alpha - alpha_ref) <= 1e-9 * max(1.0, abs(alpha_ref))

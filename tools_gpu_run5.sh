@@ -3,7 +3,7 @@ mkdir -p gpurun_out
 make -C meatmodeler_amd/csrc -j8 > gpurun_out/make.log 2>&1 || { tail gpurun_out/make.log; exit 1; }
 
 
-timeout -k 10 900 python -m pytest tests -m gpu -q --timeout 300 -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
+timeout -k 10 900 python -m pytest tests -m gpu -q -s --timeout 300 -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
 rc=$?
 echo "pytest rc=$rc"; tail -8 gpurun_out/pytest_gpu.log
 if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "pytest timed out - stopping"; exit 1; fi
