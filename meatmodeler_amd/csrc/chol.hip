@@ -189,21 +189,29 @@ __device__ __forceinline__ void tile_gemm_nt(const double (*As)[LDT], const doub
 }
 
 __device__ __forceinline__ void load_tile(double (*T)[LDT], const double *__restrict__ src, int ld, int rows, int cols) {
-    // 64 x 64 doubles as 16-byte pieces; zero fill outside (rows, cols)
-    for (int e = threadIdx.x; e < NB * (NB / 2); e += 256) {
-        int r = e / (NB / 2), c = (e % (NB / 2)) * 2;
-        double v0 = 0.0, v1 = 0.0;
+    // 64 x 64 doubles as 16-byte pieces, 8 per thread; all eight global loads are issued before the first LDS write
+    // (a rolled loop with a guarded load per trip serialises eight memory latencies); zero fill outside (rows, cols)
+    double2 v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int e = threadIdx.x + 256 * q;
+        const int r = e / (NB / 2), c = (e % (NB / 2)) * 2;
+        double2 t = make_double2(0.0, 0.0);
         if (r < rows) {
             if (c + 1 < cols) {
-                const double2 v = *reinterpret_cast<const double2 *>(src + (size_t)r * ld + c);
-                v0 = v.x;
-                v1 = v.y;
+                t = *reinterpret_cast<const double2 *>(src + (size_t)r * ld + c);
             } else if (c < cols) {
-                v0 = src[(size_t)r * ld + c];
+                t.x = src[(size_t)r * ld + c];
             }
         }
-        T[r][c] = v0;
-        T[r][c + 1] = v1;
+        v[q] = t;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int e = threadIdx.x + 256 * q;
+        const int r = e / (NB / 2), c = (e % (NB / 2)) * 2;
+        T[r][c] = v[q].x;
+        T[r][c + 1] = v[q].y;
     }
 }
 
@@ -329,12 +337,21 @@ __global__ __launch_bounds__(256) void bwd_step_kernel(const double *__restrict_
     block_gemv64(Linv, vin, xk, 1);
     __syncthreads();
     if (blockIdx.x == 0 && threadIdx.x < kr) x[k0 + threadIdx.x] = xk[threadIdx.x];
-    const int col = col_begin + blockIdx.x * 256 + threadIdx.x;
+    // 64 columns per workgroup, 4 row groups of 16: sixteen independent loads per thread instead of a 64-long chain
+    __shared__ double part[4][NB];
+    const int col = col_begin + blockIdx.x * NB + (threadIdx.x & 63);
+    const int rg = threadIdx.x >> 6;
+    double s = 0.0;
     if (col < k0) {
-        double s = 0.0;
-        for (int r = 0; r < kr; ++r) s += A[(size_t)(k0 + r) * n + col] * xk[r];
-        y[col] -= s;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int r = rg * 16 + q;
+            if (r < kr) s += A[(size_t)(k0 + r) * n + col] * xk[r];
+        }
     }
+    part[rg][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rg == 0 && col < k0) y[col] -= (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
 }  // namespace
@@ -388,7 +405,7 @@ int mm_chol_solve(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int half_b
             long cb = (long)k0 - (long)bwb * NB;
             const int col_begin = cb < 0 ? 0 : (int)cb;
             const int left = k0 - col_begin;
-            const int grid = left > 0 ? (left + 255) / 256 : 1;
+            const int grid = left > 0 ? (left + NB - 1) / NB : 1;
             MM_LAUNCH(ctx, "bwd_step_kernel", bwd_step_kernel, dim3(grid), dim3(256), 0, (const double *)A,
                       (const double *)(Linv + (size_t)k * NB * NB), ytmp, bc, n, k0, col_begin);
         }
