@@ -118,6 +118,15 @@ int64_t mm_link_tracks_clip(int n_frames, int cap, const int32_t *kp_count, cons
                             const int32_t *match_count, const int32_t *matches, int64_t max_tracks,
                             int64_t max_obs, int64_t *track_ptr /*[max_tracks+1]*/, int32_t *obs_frame,
                             int32_t *obs_kp, int64_t *n_obs_out);
+/* The same linking ON THE DEVICE (one resident workgroup walks the clip; scatter-min / scatter-max / prefix sums per
+ * keyframe pair): all pointers are DEVICE pointers, nothing is copied to the host, no synchronisation.
+ * kp_xy [n_frames, cap, 2] f32, matches [n_frames-1, cap, 2] i32 (queryIdx, trainIdx), cap <= 8192.
+ * Outputs sized for the worst case: track_ptr [(n_frames-1)*cap + 1] i32, obs_frame / obs_kp [2*(n_frames-1)*cap] i32;
+ * counts [3] i64 = (n_tracks, n_obs, 1 if a malformed match was skipped).  Same result as mm_link_tracks_clip. */
+size_t mm_link_workspace_bytes(int n_frames, int cap);
+int mm_link_tracks_device(mm_ctx *ctx, int n_frames, int cap, const int32_t *kp_count, const float *kp_xy,
+                          const int32_t *match_count, const int32_t *matches, void *ws, size_t ws_bytes,
+                          int32_t *track_ptr, int32_t *obs_frame, int32_t *obs_kp, int64_t *counts /*dev[3]*/);
 /* Host: co-observation pairs (o, o2) of one point with camera(o2) <= camera(o), grouped by block segment
  * camera(o) * (span + 1) + camera(o) - camera(o2) in a fixed canonical order.  seg_ptr [F*(span+1)+1].  Call with
  * pair_o == NULL to get the pair count.  Returns the count or a negative error (MM_ERR_ARG if span is too small). */
@@ -200,7 +209,10 @@ int mm_ba_backsub(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, cons
 /* SPD solve A x = b by blocked Cholesky (f64 MFMA trailing updates).  A [n,n] row-major, lower triangle is
  * overwritten by L; b [nrhs,n] is overwritten by x.  half_bandwidth: A[i][j] == 0 whenever i - j > half_bandwidth
  * (pass n for a dense matrix); the factorisation and the substitutions skip blocks outside the band.
- * info [1] dev int32: 0 ok, k>0 = non-positive pivot at column k. */
+ * info [1] dev int32: 0 ok, k>0 = non-positive pivot at column k, -1 = the single-launch banded factorisation gave up
+ * waiting for a block (never seen; its spin loops are bounded so that a scheduling surprise cannot hang the GPU).
+ * Narrow bands (<= 15 blocks of 64) are factored by ONE data-flow scheduled launch, everything else by three launches
+ * per block column; MM_CHOL_FUSED=0 in the environment forces the latter. */
 size_t mm_chol_workspace_bytes(int n);
 int mm_chol_solve(mm_ctx *ctx, double *A /*dev*/, int n, double *b /*dev*/, int nrhs, int half_bandwidth,
                   int32_t *info /*dev*/, void *ws, size_t ws_bytes);

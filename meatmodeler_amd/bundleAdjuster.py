@@ -365,6 +365,8 @@ class SchurTRF:
                 vals = torch.cat([info.to(torch.float64), wn2.reshape(1), gn2.reshape(1), bs, nn]).tolist()
                 if int(vals[0]) == 0:
                     break
+                if int(vals[0]) < 0:
+                    raise MMError("mm_chol_solve: the fused banded factorisation was abandoned (info = -1)")
                 reg_eff *= 100.0
             else:
                 raise MMError(f"reduced camera system is not positive definite (pivot {int(vals[0])})")

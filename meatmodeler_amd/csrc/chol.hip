@@ -14,6 +14,7 @@
 // MFMA fragment maps for f64 16x16x4 (guide §3): A lane l -> A[l&15][l>>4], B lane l -> B[l>>4][l&15],
 // D reg i of lane l -> D[(l>>4) + 4 i][l&15].
 #include "mm_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -35,64 +36,300 @@ __device__ __forceinline__ double readlane_f64(double x, int src_lane /*wave-uni
 }
 
 // ---- (1) diagonal block ------------------------------------------------------------------------------------------------
-// ONE wave; lane = row.  A lone wave is issue-latency bound (~4+ cycles per instruction), so the kernel is written to
-// minimise INSTRUCTIONS per FMA: everything is fully unrolled with static register indices, the lane keeps its own row
-// of L in registers, other rows come from LDS as same-address (broadcast) reads with immediate offsets, and pivots /
-// panel columns travel through v_readlane instead of LDS.  16-column panels: left-looking update of the panel from the
-// finished columns (1536 FMAs per lane in total), then the panel is factored in registers (4 x 120 FMAs).  L^-1 by
-// forward substitution, lane = column, x in registers (2016 FMAs).  (The rolled LDS-resident version took ~95 us.)
-// Panel pb (columns c0 = 16 pb ..): wave w updates rows 16w..16w+15 of the panel from the finished columns with f64
-// MFMA (K = c0), then wave 0 factors the 64 x 16 panel in registers (lane = row; pivots and panel columns travel by
-// v_readlane).  A lone wave is issue-latency bound, so the point is to minimise instructions per FMA.
+// Panel pb (columns c0 = 16 pb ..) of the 64 x 64 block in LDS.  update: wave w brings rows 16w..16w+15 of the panel
+// up to date from the finished columns with f64 MFMA (K = c0).  factor (ONE wave): the 64 x 16 panel in registers,
+// lane = row; pivots and panel columns travel by v_readlane.  A lone wave is issue-latency bound, so the point is to
+// minimise instructions per FMA: fully unrolled, static register indices, 1/sqrt by v_rsq_f64 + two Newton steps (one
+// transcendental and ~8 FMAs per pivot instead of a sqrt and a division); the reciprocals 1/L_jj are kept in R for
+// the inverse.
 template <int PB>
-__device__ __forceinline__ void chol_panel16(double (*M)[NB + 1], int k0, int &bad) {
+__device__ __forceinline__ void panel16_update(double (*M)[NB + 1]) {
     constexpr int c0 = PB * 16;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (PB > 0) {
-        if (16 * w + 15 >= c0) {  // rows above the panel hold final entries / structural zeros
-            double4_t acc = {0, 0, 0, 0};
-            const int lr = lane & 15, lk = lane >> 4;
+    if (16 * w + 15 >= c0) {  // rows above the panel hold final entries / structural zeros
+        double4_t acc = {0, 0, 0, 0};
+        const int lr = lane & 15, lk = lane >> 4;
 #pragma unroll
-            for (int ks = 0; ks < c0 / 4; ++ks) {
-                const double av = M[16 * w + lr][4 * ks + lk];
-                const double bv = M[c0 + lr][4 * ks + lk];
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) M[16 * w + (lane >> 4) + 4 * i][c0 + (lane & 15)] -= acc[i];
-        }
-        __syncthreads();
-    }
-    if (w == 0) {
-        double a[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) a[q] = M[lane][c0 + q];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            double piv = readlane_f64(a[q], c0 + q);
-            const bool ok = piv > 0.0;
-            bad = (!ok && bad == 0) ? k0 + c0 + q + 1 : bad;
-            piv = ok ? piv : 1.0;
-            // 1/sqrt by v_rsq_f64 + two Newton steps (full f64 accuracy): one transcendental and ~8 FMAs per pivot
-            // instead of a sqrt and a division (~50 instructions) on the sequential path
-            double r = __builtin_amdgcn_rsq(piv);
-            r = r * (1.5 - 0.5 * piv * r * r);
-            r = r * (1.5 - 0.5 * piv * r * r);
-            const double d = piv * r;
-            const double lq = lane > c0 + q ? a[q] * r : (lane == c0 + q ? d : 0.0);
-            a[q] = lq;
-#pragma unroll
-            for (int r = q + 1; r < 16; ++r) a[r] -= lq * readlane_f64(lq, c0 + r);
+        for (int ks = 0; ks < c0 / 4; ++ks) {
+            const double av = M[16 * w + lr][4 * ks + lk];
+            const double bv = M[c0 + lr][4 * ks + lk];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
         }
 #pragma unroll
-        for (int q = 0; q < 16; ++q) M[lane][c0 + q] = a[q];
+        for (int i = 0; i < 4; ++i) M[16 * w + (lane >> 4) + 4 * i][c0 + (lane & 15)] -= acc[i];
     }
     __syncthreads();
+}
+
+// a[j] -= x * src[lane SRC + j], j < N <= 4: the broadcasts go through fixed SGPR pairs inside ONE asm statement.
+// (Left to the scheduler, the 2 x 120 v_readlane of a panel are hoisted ahead of their FMAs and the scalar registers
+// spill.)  gfx950 hazards the assembler does not see inside asm: a VALU reading an SGPR written by v_readlane needs
+// 2 wait states, v_readlane reading a VGPR written by the previous VALU needs 1 -- covered by the instruction order
+// for N >= 3 and by s_nop otherwise; FRESH = the source was produced by the instruction right before.
+template <int SRC, int N, bool FRESH>
+__device__ __forceinline__ void fnma_bcast(double &a0, double &a1, double &a2, double &a3, double src, double x) {
+    if constexpr (FRESH) asm volatile("s_nop 1" : "+v"(src));  // tied to src: stays between its producer and the readlanes
+    const unsigned long long u = __double_as_longlong(src);
+    const unsigned lo = (unsigned)u, hi = (unsigned)(u >> 32);
+    if constexpr (N == 4)
+        asm volatile(
+            "v_readlane_b32 s88, %4, %7\n\tv_readlane_b32 s89, %5, %7\n\t"
+            "v_readlane_b32 s90, %4, %7+1\n\tv_readlane_b32 s91, %5, %7+1\n\t"
+            "v_readlane_b32 s92, %4, %7+2\n\tv_readlane_b32 s93, %5, %7+2\n\t"
+            "v_readlane_b32 s94, %4, %7+3\n\tv_readlane_b32 s95, %5, %7+3\n\t"
+            "v_fma_f64 %0, -%6, s[88:89], %0\n\tv_fma_f64 %1, -%6, s[90:91], %1\n\t"
+            "v_fma_f64 %2, -%6, s[92:93], %2\n\tv_fma_f64 %3, -%6, s[94:95], %3"
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)
+            : "v"(lo), "v"(hi), "v"(x), "n"(SRC)
+            : "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95");
+    if constexpr (N == 3)
+        asm volatile(
+            "v_readlane_b32 s88, %3, %6\n\tv_readlane_b32 s89, %4, %6\n\t"
+            "v_readlane_b32 s90, %3, %6+1\n\tv_readlane_b32 s91, %4, %6+1\n\t"
+            "v_readlane_b32 s92, %3, %6+2\n\tv_readlane_b32 s93, %4, %6+2\n\t"
+            "v_fma_f64 %0, -%5, s[88:89], %0\n\tv_fma_f64 %1, -%5, s[90:91], %1\n\t"
+            "v_fma_f64 %2, -%5, s[92:93], %2"
+            : "+v"(a0), "+v"(a1), "+v"(a2)
+            : "v"(lo), "v"(hi), "v"(x), "n"(SRC)
+            : "s88", "s89", "s90", "s91", "s92", "s93");
+    if constexpr (N == 2)
+        asm volatile(
+            "v_readlane_b32 s88, %2, %5\n\tv_readlane_b32 s89, %3, %5\n\t"
+            "v_readlane_b32 s90, %2, %5+1\n\tv_readlane_b32 s91, %3, %5+1\n\t"
+            "s_nop 1\n\t"
+            "v_fma_f64 %0, -%4, s[88:89], %0\n\tv_fma_f64 %1, -%4, s[90:91], %1\n\t"
+            "s_nop 0"
+            : "+v"(a0), "+v"(a1)
+            : "v"(lo), "v"(hi), "v"(x), "n"(SRC)
+            : "s88", "s89", "s90", "s91");
+    if constexpr (N == 1)
+        asm volatile(
+            "v_readlane_b32 s88, %1, %4\n\tv_readlane_b32 s89, %2, %4\n\t"
+            "s_nop 1\n\t"
+            "v_fma_f64 %0, -%3, s[88:89], %0\n\t"
+            "s_nop 0"
+            : "+v"(a0)
+            : "v"(lo), "v"(hi), "v"(x), "n"(SRC)
+            : "s88", "s89");
+}
+
+// updates of columns Q + 1 + G .. of the panel by column Q (value lq), four at a time
+template <int C0, int Q, int G>
+__device__ __forceinline__ void panel16_update_cols(double (&a)[16], double lq) {
+    constexpr int first = Q + 1 + G;
+    constexpr int left = 16 - first;
+    if constexpr (left > 0) {
+        constexpr int n = left >= 4 ? 4 : left;
+        constexpr int i1 = first + 1 < 16 ? first + 1 : 15, i2 = first + 2 < 16 ? first + 2 : 15,
+                      i3 = first + 3 < 16 ? first + 3 : 15;
+        fnma_bcast<C0 + first, n, G == 0>(a[first], a[i1], a[i2], a[i3], lq, lq);
+        panel16_update_cols<C0, Q, G + 4>(a, lq);
+    }
+}
+
+template <int C0, int Q>
+__device__ __forceinline__ void panel16_column(double (&a)[16], double &piv, double &myr, int lane) {
+    // 1 / sqrt(piv): v_rsq_f64 + two Newton steps
+    double r = __builtin_amdgcn_rsq(piv);
+    r = r * (1.5 - 0.5 * piv * r * r);
+    r = r * (1.5 - 0.5 * piv * r * r);
+    if constexpr (Q < 15) {
+        // the next pivot on the side: what lane C0+Q+1 is about to compute for its diagonal entry, bit for bit,
+        // without waiting for the column below to travel through the lanes
+        const double l = readlane_f64(a[Q], C0 + Q + 1) * r;
+        piv = __builtin_fma(-l, l, readlane_f64(a[Q + 1], C0 + Q + 1));
+    }
+    const double lq = a[Q] * r;  // rows above the diagonal carry zeros (or garbage that never reaches the lower part)
+    a[Q] = lq;
+    myr = lane == C0 + Q ? r : myr;
+    panel16_update_cols<C0, Q, 0>(a, lq);
+}
+
+// A non-positive pivot is not handled on the sequential path: rsq turns it into NaN, which spreads to every later
+// column, and block_first_bad() finds the first damaged diagonal entry afterwards.
+template <int PB>
+__device__ __forceinline__ void panel16_factor(double (*M)[NB + 1], double *R) {
+    constexpr int c0 = PB * 16;
+    const int lane = threadIdx.x & 63;
+    double a[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const double v = M[lane][c0 + q];
+        a[q] = lane >= c0 + q ? v : 0.0;
+    }
+    double piv = readlane_f64(a[0], c0), myr = 0.0;
+    panel16_column<c0, 0>(a, piv, myr, lane);
+    panel16_column<c0, 1>(a, piv, myr, lane);
+    panel16_column<c0, 2>(a, piv, myr, lane);
+    panel16_column<c0, 3>(a, piv, myr, lane);
+    panel16_column<c0, 4>(a, piv, myr, lane);
+    panel16_column<c0, 5>(a, piv, myr, lane);
+    panel16_column<c0, 6>(a, piv, myr, lane);
+    panel16_column<c0, 7>(a, piv, myr, lane);
+    panel16_column<c0, 8>(a, piv, myr, lane);
+    panel16_column<c0, 9>(a, piv, myr, lane);
+    panel16_column<c0, 10>(a, piv, myr, lane);
+    panel16_column<c0, 11>(a, piv, myr, lane);
+    panel16_column<c0, 12>(a, piv, myr, lane);
+    panel16_column<c0, 13>(a, piv, myr, lane);
+    panel16_column<c0, 14>(a, piv, myr, lane);
+    panel16_column<c0, 15>(a, piv, myr, lane);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) M[lane][c0 + q] = lane >= c0 + q ? a[q] : 0.0;
+    if (lane >= c0 && lane < c0 + 16) R[lane] = myr;
+}
+
+// first column (1-based, offset by k0) whose diagonal entry of L is not a positive number, 0 if none; call with one
+// full wave after the factorisation
+__device__ __forceinline__ int block_first_bad(const double (*M)[NB + 1], int k0) {
+    const int lane = threadIdx.x & 63;
+    const double d = M[lane][lane];
+    const unsigned long long m = __ballot(!(d > 0.0 && d < 1.0e300));
+    return m ? k0 + (int)__builtin_ctzll(m) + 1 : 0;
+}
+
+// L^-1 by 16 x 16 blocks, one block row per call (ONE wave): the diagonal block by forward substitution in registers
+// (lane = column, 120 FMAs, reciprocal pivots from R), the blocks left of it on f64 MFMA:
+//   X_ij = -X_ii * sum_{k=j}^{i-1} L_ik X_kj
+// Block row i only needs L rows <= 16 i + 15 and X rows < 16 i, so it runs on an idle wave while wave 0 factors the
+// next panel; only the last row is left for the end.
+// x[i] -= L[i][K] * x[K] for the rows i > K of one 16 x 16 block; lane i holds L[i][K] in lcol
+template <int K, int G>
+__device__ __forceinline__ void inv_update_rows(double (&x)[16], double lcol, double xk) {
+    constexpr int first = K + 1 + G;
+    constexpr int left = 16 - first;
+    if constexpr (left > 0) {
+        constexpr int n = left >= 4 ? 4 : left;
+        constexpr int i1 = first + 1 < 16 ? first + 1 : 15, i2 = first + 2 < 16 ? first + 2 : 15,
+                      i3 = first + 3 < 16 ? first + 3 : 15;
+        fnma_bcast<first, n, false>(x[first], x[i1], x[i2], x[i3], lcol, xk);
+        inv_update_rows<K, G + 4>(x, lcol, xk);
+    }
+}
+
+template <int K>
+__device__ __forceinline__ void inv_diag16_step(double (&x)[16], const double (&Lrow)[16], double Rv) {
+    x[K] *= readlane_f64(Rv, K);
+    inv_update_rows<K, 0>(x, Lrow[K], x[K]);
+}
+
+__device__ __forceinline__ void inv_diag16(const double (*M)[NB + 1], double (*X)[NB + 1], const double *R, int bi) {
+    // Column `lane` of the inverse of one diagonal 16 x 16 block, right-looking forward substitution.  The block sits
+    // in registers (lane i keeps row i) and its entries reach the FMAs as scalars through v_readlane, like the panel
+    // factorisation: no LDS access and no accumulation chain inside the 16 dependent steps.  (Reading L[i][k] from
+    // LDS as needed, the compiler serialised ~120 load-wait-FMA triples: 2.5 us instead of ~1.)
+    const int lane = threadIdx.x & 63;
+    const int o = 16 * bi;
+    double Lrow[16], x[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) Lrow[q] = M[o + (lane & 15)][o + q];
+    const double Rv = R[o + (lane & 15)];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = (i == lane) ? 1.0 : 0.0;
+    inv_diag16_step<0>(x, Lrow, Rv);
+    inv_diag16_step<1>(x, Lrow, Rv);
+    inv_diag16_step<2>(x, Lrow, Rv);
+    inv_diag16_step<3>(x, Lrow, Rv);
+    inv_diag16_step<4>(x, Lrow, Rv);
+    inv_diag16_step<5>(x, Lrow, Rv);
+    inv_diag16_step<6>(x, Lrow, Rv);
+    inv_diag16_step<7>(x, Lrow, Rv);
+    inv_diag16_step<8>(x, Lrow, Rv);
+    inv_diag16_step<9>(x, Lrow, Rv);
+    inv_diag16_step<10>(x, Lrow, Rv);
+    inv_diag16_step<11>(x, Lrow, Rv);
+    inv_diag16_step<12>(x, Lrow, Rv);
+    inv_diag16_step<13>(x, Lrow, Rv);
+    inv_diag16_step<14>(x, Lrow, Rv);
+    inv_diag16_step<15>(x, Lrow, Rv);
+    if (lane < 16) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) X[o + i][o + lane] = x[i];   // zero above the diagonal by construction
+    }
+    wave_lds_sync();
+}
+
+__device__ __forceinline__ void inv_offdiag16(const double (*M)[NB + 1], double (*X)[NB + 1], double (*Tw)[17], int bi,
+                                              int bj) {
+    const int lane = threadIdx.x & 63;
+    const int lr = lane & 15, lk = lane >> 4;
+    double4_t acc = {0, 0, 0, 0};
+    for (int bk = bj; bk < bi; ++bk) {
+#pragma unroll
+        for (int ss = 0; ss < 4; ++ss) {
+            const double av = M[16 * bi + lr][16 * bk + 4 * ss + lk];   // L_ik
+            const double bv = X[16 * bk + 4 * ss + lk][16 * bj + lr];   // X_kj
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Tw[lk + 4 * i][lr] = acc[i];
+    wave_lds_sync();
+    double4_t acc2 = {0, 0, 0, 0};
+#pragma unroll
+    for (int ss = 0; ss < 4; ++ss) {
+        const double av = X[16 * bi + lr][16 * bi + 4 * ss + lk];       // X_ii
+        const double bv = Tw[4 * ss + lk][lr];
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc2, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) X[16 * bi + lk + 4 * i][16 * bj + lr] = -acc2[i];
+    wave_lds_sync();
+}
+
+// L (in place, lower triangle of M), the reciprocal pivots R and the four 16 x 16 diagonal blocks of X = L^-1 (the
+// rest of X zeroed); 256 threads.  The diagonal inverses ride on an idle wave while wave 0 factors the next panel.
+__device__ __forceinline__ void factor_block_lds(double (*M)[NB + 1], double (*X)[NB + 1], double *R, int k0, int &bad) {
+    const int w = threadIdx.x >> 6;
+    if (w == 0) {
+        panel16_factor<0>(M, R);
+    } else {
+        for (int e = threadIdx.x - 64; e < NB * NB; e += 192) X[e / NB][e % NB] = 0.0;
+    }
+    __syncthreads();
+    panel16_update<1>(M);
+    if (w == 0) panel16_factor<1>(M, R);
+    if (w == 1) inv_diag16(M, X, R, 0);
+    __syncthreads();
+    panel16_update<2>(M);
+    if (w == 0) panel16_factor<2>(M, R);
+    if (w == 1) inv_diag16(M, X, R, 1);
+    __syncthreads();
+    panel16_update<3>(M);
+    if (w == 0) panel16_factor<3>(M, R);
+    if (w == 1) inv_diag16(M, X, R, 2);
+    __syncthreads();
+    if (w == 0) inv_diag16(M, X, R, 3);
+    if (w == 1) bad = block_first_bad(M, k0);
+    __syncthreads();
+}
+
+// the blocks of X below the diagonal, level by level (block (w + d, w) on wave w), after factor_block_lds
+__device__ __forceinline__ void inverse_offdiag_lds(const double (*M)[NB + 1], double (*X)[NB + 1], double (*T)[16][17]) {
+    const int w = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 4; ++d) {
+        if (w + d < 4) inv_offdiag16(M, X, T[w], w + d, w);
+        __syncthreads();
+    }
+}
+
+// smallest failing column wins (several diagonal blocks may report in the fused kernel)
+__device__ __forceinline__ void report_bad(int32_t *info, int bad) {
+    int old = __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (old == 0 || bad < old) {
+        const int prev = atomicCAS(info, old, bad);
+        if (prev == old) break;
+        old = prev;
+    }
 }
 
 __global__ __launch_bounds__(256) void chol_diag_kernel(double *__restrict__ A, int n, int k0, double *__restrict__ Linv,
                                                         int32_t *__restrict__ info) {
     __shared__ double M[NB][NB + 1];
+    __shared__ double X[NB][NB + 1];
+    __shared__ double T[4][16][17];
+    __shared__ double R[NB];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nb = min(NB, n - k0);
     {   // wave w loads rows 16w..16w+15, lane = column: coalesced rows, 16 loads in flight per lane
@@ -108,67 +345,14 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(double *__restrict__ A, 
     }
     __syncthreads();
     int bad = 0;
-    chol_panel16<0>(M, k0, bad);
-    chol_panel16<1>(M, k0, bad);
-    chol_panel16<2>(M, k0, bad);
-    chol_panel16<3>(M, k0, bad);
-    if (bad && threadIdx.x == 0 && info[0] == 0) info[0] = bad;
-    for (int e = threadIdx.x; e < NB * NB; e += 256) {  // write L back (posted stores)
+    factor_block_lds(M, X, R, k0, bad);
+    if (bad && threadIdx.x == 64) report_bad(info, bad);
+    inverse_offdiag_lds(M, X, T);
+    for (int e = threadIdx.x; e < NB * NB; e += 256) {
         const int r = e / NB, c = e % NB;
         if (r < nb && c < nb && c <= r) A[(size_t)(k0 + r) * n + k0 + c] = M[r][c];
+        Linv[e] = X[r][c];
     }
-    // ---- L^-1 by 16x16 blocks: the four diagonal blocks are inverted by the four waves in parallel (forward
-    // substitution in registers, 120 FMAs), then the off-diagonal blocks level by level on f64 MFMA:
-    //   X_ij = -X_ii * sum_{k=j}^{i-1} L_ik X_kj          (i - j = 1, 2, 3)
-    // ~5 us instead of ~9.5 us for the 2016-FMA single-wave substitution this replaces.
-    __shared__ double X[NB][NB + 1];
-    __shared__ double T[4][16][17];
-    for (int e = threadIdx.x; e < NB * NB; e += 256) X[e / NB][e % NB] = 0.0;
-    __syncthreads();
-    if (lane < 16) {
-        const int o = 16 * w;
-        double x[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            double s = (i == lane) ? 1.0 : 0.0;
-#pragma unroll
-            for (int k = 0; k < i; ++k) s -= M[o + i][o + k] * x[k];
-            x[i] = s / M[o + i][o + i];
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) X[o + i][o + lane] = x[i];   // zero above the diagonal by construction
-    }
-    __syncthreads();
-    const int lr = lane & 15, lk = lane >> 4;
-#pragma unroll
-    for (int d = 1; d < 4; ++d) {
-        const int bi = w + d, bj = w;  // wave w computes block (w + d, w) of this level
-        if (bi < 4) {
-            double4_t acc = {0, 0, 0, 0};
-            for (int bk = bj; bk < bi; ++bk) {
-#pragma unroll
-                for (int ss = 0; ss < 4; ++ss) {
-                    const double av = M[16 * bi + lr][16 * bk + 4 * ss + lk];   // L_ik
-                    const double bv = X[16 * bk + 4 * ss + lk][16 * bj + lr];   // X_kj
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) T[w][lk + 4 * i][lr] = acc[i];
-            wave_lds_sync();
-            double4_t acc2 = {0, 0, 0, 0};
-#pragma unroll
-            for (int ss = 0; ss < 4; ++ss) {
-                const double av = X[16 * bi + lr][16 * bi + 4 * ss + lk];       // X_ii
-                const double bv = T[w][4 * ss + lk][lr];
-                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc2, 0, 0, 0);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) X[16 * bi + lk + 4 * i][16 * bj + lr] = -acc2[i];
-        }
-        __syncthreads();
-    }
-    for (int e = threadIdx.x; e < NB * NB; e += 256) Linv[e] = X[e / NB][e % NB];
 }
 
 // 64x64 tile product  acc += As (64 x 64, rows) * Bs^T  on f64 MFMA; wave w owns the 32x32 quadrant (w>>1, w&1).
@@ -280,6 +464,336 @@ __global__ __launch_bounds__(256) void chol_update_kernel(double *__restrict__ A
             }
 }
 
+// ---- fused banded factorisation: ONE launch ----------------------------------------------------------------------------
+// The launch-per-step scheme above pays three dependent kernels per block column (~37 us) although a column holds a
+// few MFLOP.  For a narrow band the whole factorisation runs as one grid of resident workgroups that hand blocks to
+// each other through flags in global memory (left-looking per block, data-flow scheduled):
+//   * block (r, c) of L has ONE owner workgroup, which keeps  sum_k L_rk L_ck^T  in its MFMA accumulators while the
+//     columns k = r - bwb .. c - 1 become available, then finishes the block (x L_cc^-T, or the diagonal factorisation)
+//     and publishes it: no block is ever read-modified-written by two workgroups;
+//   * the owner of the diagonal block (r, r) also owns (r, r - 1): the critical chain
+//     L_cc^-1 -> L_{c+1,c} -> S_{c+1,c+1} -> L_{c+1,c+1}^-1 stays inside one workgroup (LDS, no flag hop);
+//   * block (c + d, c) is alive for bwb - d + 1 columns, so that many workgroups per offset d (round robin over c) keep
+//     every live block resident: (bwb + 1) + bwb (bwb - 1) / 2 workgroups in total (46 for bwb = 9).
+// Every workgroup walks its blocks in increasing column order and waits only for blocks of smaller (column, offset)
+// rank, so the unfinished block of smallest rank always has a running owner: no deadlock while all workgroups are
+// resident (the host only takes this path for grids far below one workgroup per CU).  Spins are bounded anyway: a
+// workgroup that gives up raises the abort flag, everybody leaves and the call reports MM_ERR_HIP.
+constexpr long SPIN_LIMIT = 1L << 23;
+constexpr size_t FUSED_LDS_BYTES = (size_t)(2 * NB * LDT + 4 * 16 * 17 + 3 * NB) * sizeof(double);
+
+// Coherence between the workgroups (they sit on different XCDs, each with its own L2).  MODE 1: plain loads / stores
+// of the blocks, bracketed by agent-scope release / acquire fences (L2 write-back + invalidate per hand-over).
+// MODE 2: every shared block is written and read with agent-scope relaxed atomics (write-through stores, cache-bypassing
+// loads: `global_* ... sc1`), the writer drains its stores (s_waitcnt) before raising the flag: no cache maintenance.
+template <int MODE>
+__device__ __forceinline__ double ld_shared(const double *p) {
+    if (MODE == 2) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+template <int MODE>
+__device__ __forceinline__ void st_shared(double *p, double v) {
+    if (MODE == 2)
+        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+        *p = v;
+}
+
+// 64 x 64 tile of a published block -> LDS (zero rows >= rows); 16 coalesced 8-byte loads per thread, all in flight
+template <int MODE>
+__device__ __forceinline__ void load_tile_shared(double (*T)[LDT], const double *src, int ld, int rows) {
+    double v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int e = threadIdx.x + 256 * q;
+        const int r = e / NB, c = e % NB;
+        v[q] = r < rows ? ld_shared<MODE>(src + (size_t)r * ld + c) : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int e = threadIdx.x + 256 * q;
+        T[e / NB][e % NB] = v[q];
+    }
+}
+
+__device__ __forceinline__ bool spin_until_set(const int32_t *flag, int32_t *abort_flag) {
+    for (long it = 0; it < SPIN_LIMIT; ++it) {
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return true;
+        if ((it & 255) == 255 && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return false;
+}
+
+// all 256 threads; returns false (uniformly) when the grid is being abandoned
+template <int MODE>
+__device__ __forceinline__ bool wg_wait(const int32_t *f1, const int32_t *f2, int32_t *abort_flag, int *s_ok) {
+    if (threadIdx.x == 0) *s_ok = spin_until_set(f1, abort_flag) && (f2 == nullptr || spin_until_set(f2, abort_flag));
+    __syncthreads();
+    const bool ok = *s_ok != 0;
+    __syncthreads();
+    if (MODE == 1)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop stale cache lines before reading the published block
+    else
+        asm volatile("" ::: "memory");
+    return ok;
+}
+
+template <int MODE>
+__device__ __forceinline__ void wg_publish(int32_t *flag) {
+    if (MODE == 1)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    else
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this wave's write-through stores have landed
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void zero_acc(double4_t (&acc)[2][2]) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (double4_t){0, 0, 0, 0};
+}
+
+// element (row, col) of accumulator register acc[a][b][i] (tile_gemm_nt layout)
+#define MM_ACC_FOREACH(body)                                                                      \
+    {                                                                                             \
+        const int lane_ = threadIdx.x & 63, w_ = threadIdx.x >> 6;                                \
+        const int r0_ = (w_ >> 1) * 32, c0_ = (w_ & 1) * 32;                                       \
+        _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int b = 0; b < 2; ++b) \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                       \
+            const int row = r0_ + a * 16 + (lane_ >> 4) + 4 * i, col = c0_ + b * 16 + (lane_ & 15); \
+            body                                                                                  \
+        }                                                                                         \
+    }
+
+// out[row] (+)= sign * sum_k Tm[row][k] v[k] for a 64 x 64 tile in LDS (leading dimension LD); 256 threads, 4 per row
+template <int LD>
+__device__ __forceinline__ double tile_matvec(const double (*Tm)[LD], const double *v) {
+    const int r = threadIdx.x >> 2, part = threadIdx.x & 3;
+    double s = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s += Tm[r][part * 16 + q] * v[part * 16 + q];
+    s += __shfl_down(s, 2, 4);
+    s += __shfl_down(s, 1, 4);
+    return s;  // valid in the threads with (threadIdx.x & 3) == 0, row threadIdx.x >> 2
+}
+
+// finish an off-diagonal block: solve P L_cc^T = A0 - acc, written to `tile` (global) and left in As.  The producer
+// publishes L_cc and the four 16 x 16 diagonal blocks X_jj of its inverse as soon as they exist (the rest of L_cc^-1
+// is off the critical path), so the solve runs by 16-column blocks: P_j = (V_j - sum_{k<j} P_k L_jk^T) X_jj^T,
+// wave w on rows 16w..16w+15 (40 MFMA per wave, wave-local LDS traffic only).
+template <int MODE>
+__device__ __forceinline__ void finish_off_block(double (*As)[LDT], double (*Bs)[LDT], double (*Xd)[16][17],
+                                                 const double4_t (&a0)[2][2], const double4_t (&acc)[2][2],
+                                                 const double *Lcc /*diag tile of A*/, const double *Linv_c,
+                                                 double *tile, int n, int rows) {
+    MM_ACC_FOREACH(As[row][col] = a0[a][b][i] - acc[a][b][i];)
+    load_tile_shared<MODE>(Bs, Lcc, n, NB);
+    {
+        double v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = threadIdx.x + 256 * q, blk = e >> 8, rr = (e >> 4) & 15, cc = e & 15;
+            v[q] = ld_shared<MODE>(Linv_c + (size_t)(16 * blk + rr) * NB + 16 * blk + cc);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = threadIdx.x + 256 * q;
+            Xd[e >> 8][(e >> 4) & 15][e & 15] = v[q];
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, row0 = 16 * (threadIdx.x >> 6);
+    const int lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        double4_t s = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < j; ++k)
+#pragma unroll
+            for (int ss = 0; ss < 4; ++ss) {
+                const double av = As[row0 + lr][16 * k + 4 * ss + lk];   // P_k
+                const double bv = Bs[16 * j + lr][16 * k + 4 * ss + lk];  // L_jk
+                s = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, s, 0, 0, 0);
+            }
+        if (j > 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) As[row0 + lk + 4 * i][16 * j + lr] -= s[i];
+            wave_lds_sync();
+        }
+        double4_t pj = {0, 0, 0, 0};
+#pragma unroll
+        for (int ss = 0; ss < 4; ++ss) {
+            const double av = As[row0 + lr][16 * j + 4 * ss + lk];  // W = V_j - sum
+            const double bv = Xd[j][lr][4 * ss + lk];               // X_jj^T
+            pj = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, pj, 0, 0, 0);
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = row0 + lk + 4 * i, col = 16 * j + lr;
+            As[row][col] = pj[i];
+            if (row < rows) st_shared<MODE>(tile + (size_t)row * n + col, pj[i]);
+        }
+        wave_lds_sync();
+    }
+}
+
+#define MM_FUSED_ABANDON                       \
+    {                                          \
+        if (threadIdx.x == 0) info[0] = -1;    \
+        return;                                \
+    }
+
+// Forward substitution L y = b rides along (b_fwd != nullptr): the owner of block (r, c) multiplies it with y_c as
+// soon as that exists and hands the 64-vector to the owner of the diagonal block r, which adds the contributions in
+// a fixed order (deterministic), applies L_rr^-1 and publishes y_r.  The y chain trails the factorisation by a hop or
+// two, so the forward solve costs no extra time.
+template <int MODE>
+__global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, int n, int nblk, int bwb, double *Linv,
+                                                              int32_t *__restrict__ flags, int32_t *__restrict__ info,
+                                                              const double *__restrict__ b_fwd, double *y,
+                                                              double *contrib) {
+    extern __shared__ double smem[];
+    double (*As)[LDT] = reinterpret_cast<double (*)[LDT]>(smem);
+    double (*Bs)[LDT] = reinterpret_cast<double (*)[LDT]>(smem + NB * LDT);
+    double (*M)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(smem);             // aliases As
+    double (*X)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(smem + NB * LDT);  // aliases Bs
+    double (*T)[16][17] = reinterpret_cast<double (*)[16][17]>(smem + 2 * NB * LDT);
+    double *R = smem + 2 * NB * LDT + 4 * 16 * 17;
+    double *ys = R + NB, *rhs = R + 2 * NB;
+    __shared__ int s_ok;
+    const int W = bwb + 1;
+    int32_t *abort_flag = flags + (size_t)nblk * W;
+    auto flag = [&](int r, int d) { return flags + (size_t)r * W + d; };
+    auto yflag = [&](int r) { return flags + (size_t)nblk * W + 1 + r; };
+    auto cflag = [&](int r, int d) { return flags + (size_t)nblk * W + 1 + nblk + (size_t)r * W + d; };
+    // role of this workgroup: offset d (0 = row head: blocks (r, r-1) and (r, r)), first column / row j, period
+    int d = 0, j = blockIdx.x, period = W;
+    if ((int)blockIdx.x >= W) {
+        int b = blockIdx.x - W;
+        d = 2;
+        while (b >= bwb - d + 1) {
+            b -= bwb - d + 1;
+            ++d;
+        }
+        j = b;
+        period = bwb - d + 1;
+    }
+    double4_t acc[2][2], a0[2][2];
+    if (d >= 2) {
+        for (int c = j; c + d < nblk; c += period) {
+            const int r = c + d;
+            const int rows = min(NB, n - r * NB);
+            double *tile = A + (size_t)r * NB * n + (size_t)c * NB;
+            MM_ACC_FOREACH(a0[a][b][i] = row < rows ? tile[(size_t)row * n + col] : 0.0;)
+            zero_acc(acc);
+            for (int k = max(0, r - bwb); k < c; ++k) {
+                if (!wg_wait<MODE>(flag(r, r - k), flag(c, c - k), abort_flag, &s_ok)) MM_FUSED_ABANDON;
+                load_tile_shared<MODE>(As, A + (size_t)r * NB * n + (size_t)k * NB, n, rows);
+                load_tile_shared<MODE>(Bs, A + (size_t)c * NB * n + (size_t)k * NB, n, NB);
+                __syncthreads();
+                tile_gemm_nt(As, Bs, acc);
+            }
+            if (!wg_wait<MODE>(flag(c, 0), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
+            finish_off_block<MODE>(As, Bs, T, a0, acc, A + (size_t)c * NB * n + (size_t)c * NB, Linv + (size_t)c * NB * NB, tile,
+                                   n, rows);
+            wg_publish<MODE>(flag(r, d));
+            if (b_fwd) {  // L_rc y_c for the forward substitution (the block is still in As)
+                if (!wg_wait<MODE>(yflag(c), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
+                if (threadIdx.x < NB) ys[threadIdx.x] = ld_shared<MODE>(y + (size_t)c * NB + threadIdx.x);
+                __syncthreads();
+                const double t = tile_matvec<LDT>(As, ys);
+                if ((threadIdx.x & 3) == 0) st_shared<MODE>(contrib + ((size_t)r * W + d) * NB + (threadIdx.x >> 2), t);
+                wg_publish<MODE>(cflag(r, d));
+            }
+        }
+        return;
+    }
+    double4_t acc1[2][2], a1[2][2];
+    for (int r = j; r < nblk; r += period) {
+        const int nb = min(NB, n - r * NB);
+        const bool has_sub = r >= 1 && bwb >= 1;
+        double *dtile = A + (size_t)r * NB * n + (size_t)r * NB;
+        double *stile = dtile - NB;  // block (r, r - 1)
+        MM_ACC_FOREACH(a0[a][b][i] = (row < nb && col < nb && col <= row) ? dtile[(size_t)row * n + col] : 0.0;)
+        if (has_sub) MM_ACC_FOREACH(a1[a][b][i] = row < nb ? stile[(size_t)row * n + col] : 0.0;)
+        zero_acc(acc);
+        zero_acc(acc1);
+        for (int k = max(0, r - bwb); k + 1 < r; ++k) {
+            if (!wg_wait<MODE>(flag(r, r - k), flag(r - 1, r - 1 - k), abort_flag, &s_ok)) MM_FUSED_ABANDON;
+            load_tile_shared<MODE>(As, A + (size_t)r * NB * n + (size_t)k * NB, n, nb);
+            load_tile_shared<MODE>(Bs, A + (size_t)(r - 1) * NB * n + (size_t)k * NB, n, NB);
+            __syncthreads();
+            tile_gemm_nt(As, Bs, acc1);
+            tile_gemm_nt(As, As, acc);
+        }
+        if (has_sub) {
+            if (!wg_wait<MODE>(flag(r - 1, 0), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
+            finish_off_block<MODE>(As, Bs, T, a1, acc1, dtile - (size_t)NB * n - NB, Linv + (size_t)(r - 1) * NB * NB, stile, n,
+                                   nb);
+            wg_publish<MODE>(flag(r, 1));  // (its barrier also orders the LDS copy of the block)
+            tile_gemm_nt(As, As, acc);
+        }
+        __syncthreads();  // As / Bs are reused as M / X from here
+        MM_ACC_FOREACH(M[row][col] = (row < nb && col < nb && col <= row) ? a0[a][b][i] - acc[a][b][i]
+                                                                          : ((row >= nb && row == col) ? 1.0 : 0.0);)
+        __syncthreads();
+        int bad = 0;
+        factor_block_lds(M, X, R, r * NB, bad);
+        if (bad && threadIdx.x == 64) report_bad(info, bad);
+        // what the blocks below need first: L_rr (into A) and the diagonal 16 x 16 blocks of its inverse
+        {   // the 16 x 16 blocks below the diagonal of L_rr and the diagonal blocks of the inverse
+            double *Lr = Linv + (size_t)r * NB * NB;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = threadIdx.x + 256 * q, blk = e >> 8, rr = 16 * blk + ((e >> 4) & 15), cc = 16 * blk + (e & 15);
+                st_shared<MODE>(Lr + rr * NB + cc, X[rr][cc]);
+            }
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                constexpr int BI[6] = {1, 2, 2, 3, 3, 3}, BJ[6] = {0, 0, 1, 0, 1, 2};
+                const int rr = 16 * BI[q] + (threadIdx.x >> 4), cc = 16 * BJ[q] + (threadIdx.x & 15);
+                if (rr < nb) st_shared<MODE>(dtile + (size_t)rr * n + cc, M[rr][cc]);
+            }
+        }
+        wg_publish<MODE>(flag(r, 0));
+        for (int q = 0; q < 4; ++q) {  // diagonal 16 x 16 blocks of L_rr: only the later kernels read them
+            const int e = threadIdx.x + 256 * q, blk = e >> 8, rr = 16 * blk + ((e >> 4) & 15), cc = 16 * blk + (e & 15);
+            if (rr < nb && cc <= rr) dtile[(size_t)rr * n + cc] = M[rr][cc];
+        }
+        // the rest of L_rr^-1 (for the substitution kernels) is nobody's critical path
+        inverse_offdiag_lds(M, X, T);
+        for (int e = threadIdx.x; e < NB * NB; e += 256) {
+            const int rr = e / NB, cc = e % NB;
+            if ((rr >> 4) != (cc >> 4)) Linv[(size_t)r * NB * NB + e] = X[rr][cc];
+        }
+        if (b_fwd) {  // y_r = L_rr^-1 (b_r - sum_d L_{r,r-d} y_{r-d})
+            if (threadIdx.x < NB) rhs[threadIdx.x] = (int)threadIdx.x < nb ? b_fwd[(size_t)r * NB + threadIdx.x] : 0.0;
+            if (has_sub) {  // this workgroup owns (r, r-1); its LDS copy is gone (M), read the block back
+                if (!wg_wait<MODE>(yflag(r - 1), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
+                load_tile_shared<MODE>(As, stile, n, nb);
+                if (threadIdx.x < NB) ys[threadIdx.x] = ld_shared<MODE>(y + (size_t)(r - 1) * NB + threadIdx.x);
+                __syncthreads();
+                const double t = tile_matvec<LDT>(As, ys);
+                if ((threadIdx.x & 3) == 0) rhs[threadIdx.x >> 2] -= t;
+            }
+            for (int dd = 2; dd <= bwb && dd <= r; ++dd) {
+                if (!wg_wait<MODE>(cflag(r, dd), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
+                if (threadIdx.x < NB) rhs[threadIdx.x] -= ld_shared<MODE>(contrib + ((size_t)r * W + dd) * NB + threadIdx.x);
+            }
+            __syncthreads();
+            const double yr = tile_matvec<NB + 1>(X, rhs);
+            if ((threadIdx.x & 3) == 0 && (int)(threadIdx.x >> 2) < nb) st_shared<MODE>(y + (size_t)r * NB + (threadIdx.x >> 2), yr);
+            wg_publish<MODE>(yflag(r));
+        }
+        __syncthreads();  // M / X are overwritten by the next row's tiles
+    }
+}
+
 // ---- solves -----------------------------------------------------------------------------------------------------------
 // z = Linv * v (transpose = 0) or Linv^T * v into LDS vector `out`; 256 threads, 4 per row.
 __device__ __forceinline__ void block_gemv64(const double *__restrict__ Linv, const double *vin, double *out,
@@ -356,11 +870,15 @@ __global__ __launch_bounds__(256) void bwd_step_kernel(const double *__restrict_
 
 }  // namespace
 
+constexpr int FUSED_MAX_BWB = 15;  // 16 + 105 = 121 resident workgroups at most
+
 extern "C" {
 
 size_t mm_chol_workspace_bytes(int n) {
     size_t nblk = (size_t)(n + NB - 1) / NB;
-    return mm_align_up(nblk * NB * NB * sizeof(double), 256) + mm_align_up((size_t)(n + NB) * sizeof(double), 256);
+    return mm_align_up(nblk * NB * NB * sizeof(double), 256) + mm_align_up((size_t)(n + NB) * sizeof(double), 256) +
+           mm_align_up((2 * nblk * (FUSED_MAX_BWB + 1) + nblk + 64) * sizeof(int32_t), 256) +
+           mm_align_up(nblk * (FUSED_MAX_BWB + 1) * NB * sizeof(double), 256);
 }
 
 int mm_chol_solve(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int half_bandwidth, int32_t *info, void *ws,
@@ -378,20 +896,49 @@ int mm_chol_solve(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int half_b
     // block (bi, bj) can be non-zero iff 64 (bi - bj) - 63 <= half_bandwidth
     long bwb_l = ((long)half_bandwidth + NB - 1) / NB;
     const int bwb = bwb_l > nblk ? nblk : (int)bwb_l;
-    for (int k = 0; k < nblk; ++k) {
-        const int k0 = k * NB;
-        double *Lk = Linv + (size_t)k * NB * NB;
-        MM_LAUNCH(ctx, "chol_diag_kernel", chol_diag_kernel, dim3(1), dim3(256), 0, A, n, k0, Lk, info);
-        int m = nblk - k - 1;
-        if (m > bwb) m = bwb;
-        if (m > 0) {
-            MM_LAUNCH(ctx, "chol_panel_kernel", chol_panel_kernel, dim3(m), dim3(256), 0, A, n, k0, (const double *)Lk);
-            MM_LAUNCH(ctx, "chol_update_kernel", chol_update_kernel, dim3(m * (m + 1) / 2), dim3(256), 0, A, n, k0);
+    bool fwd_done = false;  // forward substitution of right-hand side 0 already done by the fused kernel
+    static const int fused_mode = [] {
+        const char *e = getenv("MM_CHOL_FUSED");
+        return e ? atoi(e) : 2;
+    }();
+    if (fused_mode > 0 && nblk >= 2 && bwb >= 1 && bwb <= FUSED_MAX_BWB) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            MM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(chol_band_fused_kernel<1>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS_BYTES));
+            MM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(chol_band_fused_kernel<2>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS_BYTES));
+            attr_set = true;
+        }
+        int32_t *flags = (int32_t *)((char *)ytmp + mm_align_up((size_t)(n + NB) * sizeof(double), 256));
+        const size_t nflags = 2 * (size_t)nblk * (bwb + 1) + nblk + 1;
+        double *contrib = (double *)((char *)flags + mm_align_up((2 * (size_t)nblk * (FUSED_MAX_BWB + 1) + nblk + 64) * sizeof(int32_t), 256));
+        const double *b_fwd = nrhs >= 1 ? b : nullptr;  // the first right-hand side rides along
+        MM_HIP(ctx, hipMemsetAsync(flags, 0, nflags * sizeof(int32_t), ctx->stream));
+        const int grid = (bwb + 1) + bwb * (bwb - 1) / 2;
+        if (fused_mode == 1)
+            MM_LAUNCH(ctx, "chol_band_fused_kernel", chol_band_fused_kernel<1>, dim3(grid), dim3(256), FUSED_LDS_BYTES, A, n,
+                      nblk, bwb, Linv, flags, info, b_fwd, ytmp, contrib);
+        else
+            MM_LAUNCH(ctx, "chol_band_fused_kernel", chol_band_fused_kernel<2>, dim3(grid), dim3(256), FUSED_LDS_BYTES, A, n,
+                      nblk, bwb, Linv, flags, info, b_fwd, ytmp, contrib);
+        fwd_done = b_fwd != nullptr;
+    } else {
+        for (int k = 0; k < nblk; ++k) {
+            const int k0 = k * NB;
+            double *Lk = Linv + (size_t)k * NB * NB;
+            MM_LAUNCH(ctx, "chol_diag_kernel", chol_diag_kernel, dim3(1), dim3(256), 0, A, n, k0, Lk, info);
+            int m = nblk - k - 1;
+            if (m > bwb) m = bwb;
+            if (m > 0) {
+                MM_LAUNCH(ctx, "chol_panel_kernel", chol_panel_kernel, dim3(m), dim3(256), 0, A, n, k0, (const double *)Lk);
+                MM_LAUNCH(ctx, "chol_update_kernel", chol_update_kernel, dim3(m * (m + 1) / 2), dim3(256), 0, A, n, k0);
+            }
         }
     }
     for (int c = 0; c < nrhs; ++c) {
         double *bc = b + (size_t)c * n;
-        for (int k = 0; k < nblk; ++k) {  // L y = b
+        for (int k = 0; k < nblk && !(c == 0 && fwd_done); ++k) {  // L y = b
             const int k0 = k * NB;
             long re = (long)k0 + NB + (long)bwb * NB;
             const int row_end = re > n ? n : (int)re;

@@ -1,0 +1,317 @@
+// Track linking over a whole clip ON THE DEVICE (gfx950): the data-parallel restatement of processor.pointTracking
+// (reference processor.py:190-243) applied to every consecutive keyframe pair, followed by `popped_tracks += tracks`
+// (processor.py:418) and the flattening order of managePoints (processor.py:264-291).
+//
+// Semantics kept exactly (same as the host linker mm_link_tracks_clip, which stays as the cross-check):
+//   * a match continues the FIRST live track (list order) whose coordinate at the previous keyframe EQUALS the match's
+//     previous-frame point (float equality, processor.py:220)  -> scatter-min of the live position over a canonical
+//     key point id (smallest index with the same coordinates in that frame);
+//   * several matches hitting one track: the last one wins (Track.update overwrites, track.py:17-19) -> scatter-max of
+//     the match index;
+//   * unmatched feature points spawn new tracks after the survivors, in match order; tracks not updated are popped in
+//     list order -> three block-wide prefix sums per keyframe pair.
+// The per-pair work is a handful of scatters / scans over <= 8192 items, strictly sequential over the pairs: ONE
+// resident workgroup walks the clip (no launch per pair, no host round trip); observations are nodes of per-track
+// linked lists, turned into the CSR (track_ptr, obs_frame, obs_kp) by a second kernel.
+#include "mm_common.h"
+#include <climits>
+
+namespace {
+
+constexpr int LK_THREADS = 1024;
+constexpr int LK_IPT = 8;                       // items per thread in the block scans
+constexpr int LK_MAX_CAP = LK_THREADS * LK_IPT;  // key points / matches per frame
+
+// canon[f][i] = smallest j with the same (x, y) in frame f (coordinates compare with ==, so -0.0 == +0.0)
+__global__ __launch_bounds__(256) void link_canon_kernel(int cap, const int32_t *__restrict__ kp_count,
+                                                         const float *__restrict__ kp_xy, int32_t *__restrict__ canon) {
+    __shared__ float2 tile[256];
+    const int f = blockIdx.y;
+    const int n = min(kp_count[f], cap);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const float2 *xy = reinterpret_cast<const float2 *>(kp_xy) + (size_t)f * cap;
+    float2 me = make_float2(0.f, 0.f);
+    if (i < n) me = xy[i];
+    int best = i;
+    const int jend = min(n, blockIdx.x * 256 + 256);  // only j <= i matter
+    for (int j0 = 0; j0 < jend; j0 += 256) {
+        __syncthreads();
+        if (j0 + (int)threadIdx.x < n) tile[threadIdx.x] = xy[j0 + threadIdx.x];
+        __syncthreads();
+        const int cnt = min(256, n - j0);
+        for (int j = 0; j < cnt; ++j) {
+            const int jj = j0 + j;
+            if (jj < best && tile[j].x == me.x && tile[j].y == me.y) best = jj;
+        }
+    }
+    if (i < n) canon[(size_t)f * cap + i] = best;
+}
+
+struct LinkWs {
+    int32_t *canon;                      // [F, cap]
+    int32_t *owner, *lastm, *hitpos;     // [cap]
+    int32_t *live_track[2], *live_kp[2], *live_node[2];  // [cap]
+    int32_t *node_kp, *node_frame, *node_prev;           // [max_nodes]
+    int32_t *track_tail, *track_len, *final_order;       // [max_tracks]
+};
+
+// owner / lastm are written by device-scope atomics: read them past the per-CU vector cache
+__device__ __forceinline__ int ld_agent(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// exclusive ranks of `flag[0..LK_IPT)` (items tid*LK_IPT ...) over the workgroup; returns the total
+__device__ __forceinline__ int block_exscan(const int (&flag)[LK_IPT], int (&rank)[LK_IPT], int *s_wave /*[17]*/) {
+    int local = 0;
+#pragma unroll
+    for (int q = 0; q < LK_IPT; ++q) {
+        rank[q] = local;
+        local += flag[q];
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int incl = local;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    __syncthreads();
+    if (lane == 63) s_wave[w] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int i = 0; i < LK_THREADS / 64; ++i) {
+            const int t = s_wave[i];
+            s_wave[i] = run;
+            run += t;
+        }
+        s_wave[16] = run;
+    }
+    __syncthreads();
+    const int base = s_wave[w] + incl - local;
+#pragma unroll
+    for (int q = 0; q < LK_IPT; ++q) rank[q] += base;
+    return s_wave[16];
+}
+
+__global__ __launch_bounds__(LK_THREADS) void link_kernel(int F, int cap, const int32_t *__restrict__ kp_count,
+                                                          const int32_t *__restrict__ match_count,
+                                                          const int32_t *__restrict__ matches, LinkWs ws,
+                                                          int32_t *__restrict__ track_ptr, int64_t *__restrict__ counts) {
+    __shared__ int s_wave[17];
+    __shared__ int s_T, s_ntracks, s_popbase, s_nodebase, s_bad;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        s_T = 0;
+        s_ntracks = 0;
+        s_popbase = 0;
+        s_nodebase = 0;
+        s_bad = 0;
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int k = 0; k + 1 < F; ++k) {
+        const int T = s_T, n_tracks = s_ntracks, pop_base = s_popbase, node_base = s_nodebase;
+        const int M = min(max(match_count[k], 0), cap);
+        const int nk = min(kp_count[k], cap), nk1 = min(kp_count[k + 1], cap);
+        const int32_t *mk = matches + (size_t)k * cap * 2;
+        const int32_t *ck = ws.canon + (size_t)k * cap;
+        for (int i = tid; i < cap; i += LK_THREADS) {
+            ws.owner[i] = INT_MAX;
+            ws.lastm[i] = -1;
+        }
+        __syncthreads();
+        // A: first live position per canonical key point of frame k
+        for (int pos = tid; pos < T; pos += LK_THREADS) atomicMin(&ws.owner[ck[ws.live_kp[cur][pos]]], pos);
+        __syncthreads();
+        // B: each match finds its track (or none); the last match on a track wins
+        for (int m = tid; m < M; m += LK_THREADS) {
+            const int q = mk[2 * m], t = mk[2 * m + 1];
+            int pos = -1;
+            if (q < 0 || q >= nk || t < 0 || t >= nk1) {
+                s_bad = 1;  // malformed match: ignored (and reported)
+                pos = -2;
+            } else {
+                const int o = ld_agent(&ws.owner[ck[q]]);
+                if (o != INT_MAX) {
+                    pos = o;
+                    atomicMax(&ws.lastm[o], m);
+                }
+            }
+            ws.hitpos[m] = pos;
+        }
+        __syncthreads();
+        // C: ranks of survivors / popped tracks (over live positions) and of new tracks (over matches)
+        int f_surv[LK_IPT], f_pop[LK_IPT], f_new[LK_IPT], r_surv[LK_IPT], r_pop[LK_IPT], r_new[LK_IPT], l_last[LK_IPT];
+#pragma unroll
+        for (int q = 0; q < LK_IPT; ++q) {
+            const int i = tid * LK_IPT + q;
+            const bool live = i < T;
+            const int lm = live ? ld_agent(&ws.lastm[i]) : -1;
+            const bool upd = lm >= 0;
+            l_last[q] = lm;
+            f_surv[q] = upd;
+            f_pop[q] = live && !upd;
+            f_new[q] = (i < M) && ws.hitpos[i] == -1;
+        }
+        const int n_surv = block_exscan(f_surv, r_surv, s_wave);
+        const int n_pop = block_exscan(f_pop, r_pop, s_wave);
+        const int n_new = block_exscan(f_new, r_new, s_wave);
+        // D: next live list, observation nodes, popped tracks
+        const int nxt = cur ^ 1;
+#pragma unroll
+        for (int q = 0; q < LK_IPT; ++q) {
+            const int i = tid * LK_IPT + q;
+            if (f_surv[q]) {
+                const int tr = ws.live_track[cur][i];
+                const int t = mk[2 * l_last[q] + 1];
+                const int nid = node_base + r_surv[q];
+                ws.node_kp[nid] = t;
+                ws.node_frame[nid] = k + 1;
+                ws.node_prev[nid] = ws.live_node[cur][i];
+                ws.live_track[nxt][r_surv[q]] = tr;
+                ws.live_kp[nxt][r_surv[q]] = t;
+                ws.live_node[nxt][r_surv[q]] = nid;
+                ws.track_len[tr] += 1;
+            } else if (f_pop[q]) {
+                const int tr = ws.live_track[cur][i];
+                ws.final_order[pop_base + r_pop[q]] = tr;
+                ws.track_tail[tr] = ws.live_node[cur][i];
+            }
+            if (f_new[q]) {
+                const int tr = n_tracks + r_new[q];
+                const int nid = node_base + n_surv + 2 * r_new[q];
+                ws.node_kp[nid] = mk[2 * i];
+                ws.node_frame[nid] = k;
+                ws.node_prev[nid] = -1;
+                ws.node_kp[nid + 1] = mk[2 * i + 1];
+                ws.node_frame[nid + 1] = k + 1;
+                ws.node_prev[nid + 1] = nid;
+                const int p = n_surv + r_new[q];
+                ws.live_track[nxt][p] = tr;
+                ws.live_kp[nxt][p] = mk[2 * i + 1];
+                ws.live_node[nxt][p] = nid + 1;
+                ws.track_len[tr] = 2;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            s_T = n_surv + n_new;
+            s_ntracks = n_tracks + n_new;
+            s_popbase = pop_base + n_pop;
+            s_nodebase = node_base + n_surv + 2 * n_new;
+        }
+        cur = nxt;
+        __syncthreads();
+    }
+    // the tracks still alive come last (processor.py:418)
+    const int T = s_T, n_tracks = s_ntracks, pop_base = s_popbase;
+    for (int pos = tid; pos < T; pos += LK_THREADS) {
+        const int tr = ws.live_track[cur][pos];
+        ws.final_order[pop_base + pos] = tr;
+        ws.track_tail[tr] = ws.live_node[cur][pos];
+    }
+    __syncthreads();
+    // CSR offsets in final order: chunked block scan with a running base
+    int base = 0;
+    for (int c0 = 0; c0 < n_tracks; c0 += LK_MAX_CAP) {
+        int len[LK_IPT], rk[LK_IPT];
+#pragma unroll
+        for (int q = 0; q < LK_IPT; ++q) {
+            const int i = c0 + tid * LK_IPT + q;
+            len[q] = i < n_tracks ? ws.track_len[ws.final_order[i]] : 0;
+        }
+        const int tot = block_exscan(len, rk, s_wave);
+#pragma unroll
+        for (int q = 0; q < LK_IPT; ++q) {
+            const int i = c0 + tid * LK_IPT + q;
+            if (i < n_tracks) track_ptr[i] = base + rk[q];
+        }
+        base += tot;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        track_ptr[n_tracks] = base;
+        counts[0] = n_tracks;
+        counts[1] = base;
+        counts[2] = s_bad;
+    }
+}
+
+// one thread per track: walk the observation list backwards, fill the CSR forwards
+__global__ __launch_bounds__(256) void link_emit_kernel(LinkWs ws, const int32_t *__restrict__ track_ptr,
+                                                        const int64_t *__restrict__ counts,
+                                                        int32_t *__restrict__ obs_frame, int32_t *__restrict__ obs_kp) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= counts[0]) return;
+    const int tr = ws.final_order[i];
+    int w = track_ptr[i] + ws.track_len[tr] - 1;
+    for (int nid = ws.track_tail[tr]; nid >= 0; nid = ws.node_prev[nid], --w) {
+        obs_frame[w] = ws.node_frame[nid];
+        obs_kp[w] = ws.node_kp[nid];
+    }
+}
+
+size_t carve(LinkWs &w, uint8_t *base, int F, int cap) {
+    size_t off = 0;
+    auto take = [&](int32_t *&p, size_t n) {
+        p = reinterpret_cast<int32_t *>(base + off);
+        off += mm_align_up(n * sizeof(int32_t), 256);
+    };
+    const size_t pairs = F > 1 ? (size_t)(F - 1) : 0;
+    const size_t max_tracks = pairs * cap + 1, max_nodes = 2 * pairs * cap + 2;
+    take(w.canon, (size_t)F * cap);
+    take(w.owner, cap);
+    take(w.lastm, cap);
+    take(w.hitpos, cap);
+    for (int b = 0; b < 2; ++b) {
+        take(w.live_track[b], cap);
+        take(w.live_kp[b], cap);
+        take(w.live_node[b], cap);
+    }
+    take(w.node_kp, max_nodes);
+    take(w.node_frame, max_nodes);
+    take(w.node_prev, max_nodes);
+    take(w.track_tail, max_tracks);
+    take(w.track_len, max_tracks);
+    take(w.final_order, max_tracks);
+    return off;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t mm_link_workspace_bytes(int n_frames, int cap) {
+    if (n_frames < 0 || cap < 0) return 0;
+    LinkWs w;
+    return carve(w, nullptr, n_frames, cap);
+}
+
+int mm_link_tracks_device(mm_ctx *ctx, int n_frames, int cap, const int32_t *kp_count, const float *kp_xy,
+                          const int32_t *match_count, const int32_t *matches, void *ws, size_t ws_bytes,
+                          int32_t *track_ptr, int32_t *obs_frame, int32_t *obs_kp, int64_t *counts) {
+    if (!ctx) return MM_ERR_ARG;
+    if (n_frames < 0 || cap < 0 || !counts) return mm_fail(ctx, MM_ERR_ARG, "mm_link_tracks_device: bad argument");
+    if (cap > LK_MAX_CAP) return mm_fail(ctx, MM_ERR_ARG, "mm_link_tracks_device: cap > %d key points per frame", LK_MAX_CAP);
+    if ((int64_t)(n_frames > 1 ? n_frames - 1 : 0) * cap * 2 + 2 > INT_MAX)
+        return mm_fail(ctx, MM_ERR_ARG, "mm_link_tracks_device: clip too large for 32-bit node ids");
+    if (n_frames < 2 || cap == 0) {
+        MM_HIP(ctx, hipMemsetAsync(counts, 0, 3 * sizeof(int64_t), ctx->stream));
+        if (track_ptr) MM_HIP(ctx, hipMemsetAsync(track_ptr, 0, sizeof(int32_t), ctx->stream));
+        return MM_OK;
+    }
+    if (!kp_count || !kp_xy || !match_count || !matches || !ws || !track_ptr || !obs_frame || !obs_kp)
+        return mm_fail(ctx, MM_ERR_ARG, "mm_link_tracks_device: null pointer");
+    if (((uintptr_t)ws & 255) || ((uintptr_t)kp_xy & 7)) return mm_fail(ctx, MM_ERR_ARG, "mm_link_tracks_device: alignment");
+    LinkWs w;
+    if (ws_bytes < carve(w, (uint8_t *)ws, n_frames, cap)) return mm_fail(ctx, MM_ERR_WORKSPACE, "mm_link_tracks_device: workspace too small");
+    MM_LAUNCH(ctx, "link_canon_kernel", link_canon_kernel, dim3((cap + 255) / 256, n_frames), dim3(256), 0, cap, kp_count,
+              kp_xy, w.canon);
+    MM_LAUNCH(ctx, "link_kernel", link_kernel, dim3(1), dim3(LK_THREADS), 0, n_frames, cap, kp_count, match_count, matches, w,
+              track_ptr, counts);
+    const size_t max_tracks = (size_t)(n_frames - 1) * cap;
+    MM_LAUNCH(ctx, "link_emit_kernel", link_emit_kernel, dim3((unsigned)((max_tracks + 255) / 256)), dim3(256), 0, w,
+              (const int32_t *)track_ptr, (const int64_t *)counts, obs_frame, obs_kp);
+    return MM_OK;
+}
+
+}  // extern "C"

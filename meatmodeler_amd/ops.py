@@ -135,6 +135,32 @@ def triangulate_dlt(proj, f0, f1, x0, x1, ctx=None):
     return X
 
 
+# ------------------------------------------------------------------------------------------------ track linking
+
+def link_tracks_device(kp_count, kp_xy, match_count, matches, ctx=None):
+    """pointTracking over a whole clip on the device (mm_link_tracks_device; reference processor.py:190-243,418).
+    kp_count [F] i32, kp_xy [F,cap,2] f32, match_count [F-1] i32, matches [F-1,cap,2] i32 (device tensors)
+    -> (track_ptr [T+1] i32, obs_frame [O] i32, obs_kp [O] i32, bad) device tensors in the reference's final track
+    order.  One host read-back (the two counts) sizes the views."""
+    ctx = ctx or default_context()
+    F, cap = kp_xy.shape[0], kp_xy.shape[1]
+    d = kp_xy.device
+    npairs = max(F - 1, 0)
+    if matches.shape[0] != npairs or (npairs and matches.shape[1] != cap) or match_count.shape[0] != npairs:
+        raise ValueError("link_tracks_device: matches must be [F-1, cap, 2] with match_count [F-1]")
+    track_ptr = torch.empty(npairs * cap + 1, dtype=torch.int32, device=d)
+    obs_frame = torch.empty(max(2 * npairs * cap, 1), dtype=torch.int32, device=d)
+    obs_kp = torch.empty_like(obs_frame)
+    counts = torch.zeros(3, dtype=torch.int64, device=d)
+    wsb = lib.mm_link_workspace_bytes(F, cap)
+    ws = torch.empty(max(wsb, 256), dtype=torch.uint8, device=d)
+    ctx.check(lib.mm_link_tracks_device(ctx.h, F, cap, ptr(_i32(kp_count)), ptr(kp_xy.contiguous()),
+                                        ptr(_i32(match_count)), ptr(_i32(matches)), ptr(ws), ws.numel(), ptr(track_ptr),
+                                        ptr(obs_frame), ptr(obs_kp), ptr(counts)), "mm_link_tracks_device")
+    nt, no, bad = (int(v) for v in counts.cpu())
+    return track_ptr[:nt + 1], obs_frame[:no], obs_kp[:no], bool(bad)
+
+
 # ------------------------------------------------------------------------------------------------ bundle adjustment
 
 def ba_build_index(F, P, fi, pi):

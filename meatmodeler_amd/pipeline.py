@@ -94,20 +94,21 @@ class ClipPipeline:
 
     # ------------------------------------------------------------------------------------------- triangulate
     def triangulate(self, track_ptr, obs_frame, obs_kp, kp_xy_dev, projections):
-        """First/last observation of every track -> 3-D points [T,3] f64 on the device (processor.py:246-261)."""
+        """First/last observation of every track -> 3-D points [T,3] f64 on the device (processor.py:246-261).
+        track_ptr / obs_frame / obs_kp: device tensors (or numpy arrays, uploaded here)."""
         d = self.device
-        T = len(track_ptr) - 1
-        first = track_ptr[:-1]
-        last = track_ptr[1:] - 1
-        f0 = torch.as_tensor(obs_frame[first].astype(np.int32)).to(d)
-        f1 = torch.as_tensor(obs_frame[last].astype(np.int32)).to(d)
-        k0 = torch.as_tensor(obs_kp[first].astype(np.int64)).to(d)
-        k1 = torch.as_tensor(obs_kp[last].astype(np.int64)).to(d)
-        x0 = kp_xy_dev[f0.long(), k0].to(torch.float64)
-        x1 = kp_xy_dev[f1.long(), k1].to(torch.float64)
+        track_ptr, obs_frame, obs_kp = (t if torch.is_tensor(t) else torch.as_tensor(np.ascontiguousarray(t)).to(d)
+                                        for t in (track_ptr, obs_frame, obs_kp))
+        T = track_ptr.shape[0] - 1
+        if T <= 0:
+            return torch.zeros((0, 3), dtype=torch.float64, device=d)
+        first = track_ptr[:-1].long()
+        last = track_ptr[1:].long() - 1
+        f0, f1 = obs_frame[first].int(), obs_frame[last].int()
+        x0 = kp_xy_dev[f0.long(), obs_kp[first].long()].to(torch.float64)
+        x1 = kp_xy_dev[f1.long(), obs_kp[last].long()].to(torch.float64)
         proj = torch.as_tensor(np.ascontiguousarray(projections, np.float64)).to(d)
-        return ops.triangulate_dlt(proj, f0, f1, x0, x1, self.ctx) if T else torch.zeros((0, 3), dtype=torch.float64,
-                                                                                        device=d)
+        return ops.triangulate_dlt(proj, f0.contiguous(), f1.contiguous(), x0, x1, self.ctx)
 
     # ------------------------------------------------------------------------------------------- flatten (managePoints)
     @staticmethod
@@ -118,6 +119,15 @@ class ClipPipeline:
         pi = np.repeat(np.arange(len(lens), dtype=np.int32), lens)
         coords = kp_xy_host[obs_frame, obs_kp].astype(np.float64)
         return coords, obs_frame.astype(np.int32), pi
+
+    @staticmethod
+    def tracks_to_host(out):
+        """Copy the linked tracks of a `run` result to the host: adds numpy `track_ptr` [T+1] i64, `obs_frame`,
+        `obs_kp` [O] i32 (the layout mm_link_tracks_clip returns) to `out`."""
+        out["track_ptr"] = out["track_ptr_dev"].cpu().numpy().astype(np.int64)
+        out["obs_frame"] = out["obs_frame_dev"].cpu().numpy()
+        out["obs_kp"] = out["obs_kp_dev"].cpu().numpy()
+        return out
 
     # ------------------------------------------------------------------------------------------- whole clip
     def run(self, frames, K, extrinsics, ba=True, ftol=1e-4, verbose=0, dist=None, timers=None):
@@ -149,12 +159,12 @@ class ClipPipeline:
         toc("match")
         tic("link")
         m_h = m.cpu().numpy()
-        mmax = int(m_h.max()) if m_h.size else 0
-        pairs_h = pairs[:, :max(mmax, 1)].cpu().numpy()
         n_h = det["n"].cpu().numpy() if det is not None else np.zeros(0, np.int32)
-        xy_h = det["xy"].cpu().numpy() if det is not None else np.zeros((0, self.cap, 2), np.float32)
         if world > 1:
             # every rank needs every frame's key points and every pair's matches to link identical tracks
+            mmax = int(m_h.max()) if m_h.size else 0
+            pairs_h = pairs[:, :max(mmax, 1)].cpu().numpy()
+            xy_h = det["xy"].cpu().numpy() if det is not None else np.zeros((0, self.cap, 2), np.float32)
             own = p_hi - p_lo  # frames f_lo .. f_lo+own-1 are owned; the halo frame belongs to the next rank
             last_rank_with_pairs = max(r for r in range(world) if parallel.block_range(F - 1, r, world)[1] >
                                        parallel.block_range(F - 1, r, world)[0])
@@ -166,37 +176,42 @@ class ClipPipeline:
             pad[:, :pairs_h.shape[1]] = pairs_h
             g_p = parallel.gather_varlen(pad, world, dist)
             n_h = np.concatenate(g_n).astype(np.int32)
-            xy_h = np.concatenate([a.reshape(-1, self.cap, 2) for a in g_xy]).astype(np.float32)
             m_h = np.concatenate(g_m).astype(np.int32)
-            pairs_h = np.concatenate([a.reshape(-1, self.cap, 2) for a in g_p]).astype(np.int32)
-            xy_dev = torch.as_tensor(xy_h).to(self.device)
+            xy_dev = torch.as_tensor(np.concatenate([a.reshape(-1, self.cap, 2) for a in g_xy]).astype(np.float32)).to(
+                self.device)
+            pairs_d = torch.as_tensor(np.concatenate([a.reshape(-1, self.cap, 2) for a in g_p]).astype(np.int32)).to(
+                self.device)
+            n_d, m_d = torch.as_tensor(n_h).to(self.device), torch.as_tensor(m_h).to(self.device)
         else:
-            xy_dev = det["xy"]
-        track_ptr, obs_frame, obs_kp = self.link(n_h, xy_h, m_h, pairs_h)
+            xy_dev, n_d, m_d, pairs_d = det["xy"], det["n"], m, pairs
+        track_ptr, obs_frame, obs_kp, bad = ops.link_tracks_device(n_d, xy_dev, m_d, pairs_d, self.ctx)
+        if bad:
+            raise MMError("link: match index outside the key point tables")
         toc("link")
         ext = np.asarray(extrinsics, float)[:, :3, :]
         proj = np.einsum("ij,fjk->fik", np.asarray(K, float), ext)   # K [R|t], processor.py:184,448
         tic("triangulate")
         X = self.triangulate(track_ptr, obs_frame, obs_kp, xy_dev, proj)
         toc("triangulate")
-        out = dict(det=det, n_tracks=len(track_ptr) - 1, n_obs=len(obs_frame), points0=X, track_ptr=track_ptr,
-                   obs_frame=obs_frame, obs_kp=obs_kp, match_count=m_h, kp_count=n_h, pairs_local=int(p_hi - p_lo),
+        P, O = track_ptr.shape[0] - 1, obs_frame.shape[0]
+        out = dict(det=det, n_tracks=P, n_obs=O, points0=X, track_ptr_dev=track_ptr, obs_frame_dev=obs_frame,
+                   obs_kp_dev=obs_kp, xy_dev=xy_dev, match_count=m_h, kp_count=n_h, pairs_local=int(p_hi - p_lo),
                    frames_local=int(f_hi - f_lo))
-        if not ba or len(obs_frame) == 0:
+        if not ba or O == 0:
+            T.pop("_open", None)
             return out
         tic("ba")
-        P = len(track_ptr) - 1
         with np.errstate(all="ignore"):
             cams0 = frameParameters(ext).reshape(F, 6)
         # managePoints order (point-major, insertion order inside a track), assembled on the device
         d = self.device
         if world > 1:
-            lo, hi, o_lo, o_hi = parallel.partition_tracks(track_ptr, rank, world)
+            lo, hi, o_lo, o_hi = parallel.partition_tracks(track_ptr.cpu().numpy(), rank, world)
         else:
-            lo, hi, o_lo, o_hi = 0, P, 0, len(obs_frame)
-        of_d = torch.as_tensor(np.ascontiguousarray(obs_frame[o_lo:o_hi])).to(d)
-        ok_d = torch.as_tensor(np.ascontiguousarray(obs_kp[o_lo:o_hi])).to(d)
-        lens = torch.as_tensor(np.diff(track_ptr[lo:hi + 1])).to(d)
+            lo, hi, o_lo, o_hi = 0, P, 0, O
+        of_d = obs_frame[o_lo:o_hi].contiguous()
+        ok_d = obs_kp[o_lo:o_hi]
+        lens = (track_ptr[lo + 1:hi + 1] - track_ptr[lo:hi]).long()
         pi_d = torch.repeat_interleave(torch.arange(hi - lo, dtype=torch.int32, device=d), lens, output_size=o_hi - o_lo)
         coords_d = xy_dev[of_d.long(), ok_d.long()].to(torch.float64)
         pb = ops.BADevice(K, of_d, pi_d, coords_d, F, hi - lo, d, self.ctx)

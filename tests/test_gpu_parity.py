@@ -373,8 +373,10 @@ def test_chol_solve_random_spd(n):
     np.testing.assert_allclose(L @ L.T, A, rtol=1e-10, atol=1e-9 * n)
 
 
-@pytest.mark.parametrize("n,hb", [(500, 40), (1000, 130), (770, 63), (320, 5)])
+@pytest.mark.parametrize("n,hb", [(500, 40), (1000, 130), (770, 63), (320, 5), (3000, 528), (1500, 900), (2000, 1100)])
 def test_chol_solve_banded(n, hb):
+    """Bands up to 15 blocks of 64 take the single-launch data-flow factorisation (3000/528 is the shape of the
+    500-frame clip), wider ones the launch-per-column path."""
     rng = np.random.default_rng(n + hb)
     M = np.tril(np.triu(rng.normal(size=(n, n)), -hb // 2))     # banded factor -> banded SPD product
     A = M @ M.T + n * np.eye(n)
@@ -385,6 +387,9 @@ def test_chol_solve_banded(n, hb):
     info = ops.chol_solve(Ad, bd, half_bandwidth=hb)
     assert int(info) == 0
     np.testing.assert_allclose(bd.cpu().numpy(), np.linalg.solve(A, b), rtol=1e-9, atol=1e-12)
+    L = np.tril(Ad.cpu().numpy())
+    L[i - j > hb] = 0.0
+    np.testing.assert_allclose(L, np.linalg.cholesky(A), rtol=1e-9, atol=1e-10)
 
 
 def test_chol_reports_non_spd():
@@ -553,6 +558,86 @@ def test_processor_drop_in_flow_matches_oracle_flow():
     assert coords == oc_ and fidx == of_ and pidx == opi_ and np.array(points).shape == (len(final), 1, 3)
 
 
+def _link_both(kp_count, kp_xy, mc, mm):
+    """(host linker result, device linker result) on the same tables; matches padded to the key point capacity."""
+    F, cap = kp_xy.shape[0], kp_xy.shape[1]
+    pad = np.zeros((max(F - 1, 0), cap, 2), np.int32)
+    pad[:, :mm.shape[1]] = mm[:, :cap]
+    host = ClipPipeline.link(None, kp_count, kp_xy, mc, pad)
+    tp, of, ok, bad = ops.link_tracks_device(dev(kp_count.astype(np.int32)), dev(kp_xy.astype(np.float32)),
+                                             dev(mc.astype(np.int32)), dev(pad))
+    assert not bad
+    return host, (tp.cpu().numpy(), of.cpu().numpy(), ok.cpu().numpy())
+
+
+def test_link_tracks_device_golden(golden_dir):
+    """mm_link_tracks_device == the reference's per-call pointTracking + managePoints (G7 scripts)."""
+    for sc in json.load(open(os.path.join(golden_dir, "g7_point_tracking.json"))):
+        kp = {int(k): v for k, v in sc["kp"].items()}
+        matches = {int(k): v for k, v in sc["matches"].items()}
+        F = len(kp)
+        cap = max(max(len(v) for v in kp.values()), max(len(v) for v in matches.values()))
+        kp_xy = np.zeros((F, cap, 2), np.float32)
+        kp_count = np.zeros(F, np.int32)
+        for f, v in kp.items():
+            kp_xy[f, :len(v)] = v
+            kp_count[f] = len(v)
+        mm = np.zeros((F - 1, cap, 2), np.int32)
+        mc = np.zeros(F - 1, np.int32)
+        for f, v in matches.items():
+            mm[f, :len(v)] = v
+            mc[f] = len(v)
+        _, (tp, of, ok) = _link_both(kp_count, kp_xy, mc, mm)
+        coords, fi, pi = ClipPipeline.flatten(tp, of, ok, kp_xy)
+        mg = sc["manage"]
+        assert coords.tolist() == mg["coordinates"]
+        assert fi.tolist() == mg["frame_indices"] and pi.tolist() == mg["point_indices"]
+        assert len(tp) - 1 == mg["points_shape"][0]
+
+
+@pytest.mark.parametrize("F,nk,frac,seed", [(9, 120, 0.6, 1), (40, 1500, 0.8, 2), (12, 4000, 0.95, 3), (6, 8192, 0.9, 4)])
+def test_link_tracks_device_equals_host_linker(F, nk, frac, seed):
+    """Random clips with duplicate coordinates (several key points at one pixel), several matches landing on one
+    track, ragged key point counts and -0.0 coordinates: device CSR == host CSR, entry by entry."""
+    rng = np.random.default_rng(seed)
+    kp_xy = (np.round(rng.uniform(0, 60 if nk > 1000 else 300, (F, nk, 2)) * 2) / 2).astype(np.float32)
+    kp_xy[:, 7] = kp_xy[:, 3]
+    kp_xy[:, 11, 0] = -0.0
+    kp_xy[:, 12, 0] = 0.0
+    kp_xy[:, 12, 1] = kp_xy[:, 11, 1]
+    kp_count = np.full(F, nk, np.int32)
+    kp_count[F // 2] = nk - 20
+    mc = np.zeros(F - 1, np.int32)
+    mm = np.zeros((F - 1, nk, 2), np.int32)
+    for f in range(F - 1):
+        q = np.sort(rng.choice(kp_count[f], size=int(kp_count[f] * frac), replace=False))
+        t = rng.integers(0, kp_count[f + 1], size=q.size)
+        mc[f] = q.size
+        mm[f, :q.size, 0] = q
+        mm[f, :q.size, 1] = t
+    if F > 10:
+        mc[5] = 0           # a pair without matches pops every live track
+    (tp0, of0, ok0), (tp1, of1, ok1) = _link_both(kp_count, kp_xy, mc, mm)
+    assert np.array_equal(tp0, tp1.astype(np.int64))
+    assert np.array_equal(of0, of1) and np.array_equal(ok0, ok1)
+    assert len(tp0) - 1 > 0
+
+
+def test_link_tracks_device_empty_and_malformed():
+    z = np.zeros
+    tp, of, ok, bad = ops.link_tracks_device(dev(z(1, np.int32)), dev(z((1, 4, 2), np.float32)), dev(z(0, np.int32)),
+                                             dev(z((0, 4, 2), np.int32)))
+    assert tp.cpu().tolist() == [0] and of.numel() == 0 and not bad
+    tp, of, ok, bad = ops.link_tracks_device(dev(np.array([3, 3], np.int32)), dev(z((2, 4, 2), np.float32)),
+                                             dev(z(1, np.int32)), dev(z((1, 4, 2), np.int32)))
+    assert tp.cpu().tolist() == [0] and of.numel() == 0 and not bad
+    mm = z((1, 4, 2), np.int32)
+    mm[0, 1] = (3, 0)       # query index 3 >= kp_count 3
+    tp, of, ok, bad = ops.link_tracks_device(dev(np.array([3, 3], np.int32)), dev(z((2, 4, 2), np.float32)),
+                                             dev(np.array([2], np.int32)), dev(mm))
+    assert bad and tp.cpu().tolist() == [0, 2]
+
+
 def test_clip_pipeline_equals_per_keyframe_drop_in():
     """The batched pipeline (detect all / match all / mm_link_tracks_clip) produces the same tracks as the per-keyframe
     drop-in functions."""
@@ -569,6 +654,7 @@ def test_clip_pipeline_equals_per_keyframe_drop_in():
     final = popped + tracks
     assert out["n_tracks"] == len(final)
     xy = out["det"]["xy"].cpu().numpy()
+    ClipPipeline.tracks_to_host(out)
     tp, of, ok = out["track_ptr"], out["obs_frame"], out["obs_kp"]
     for i, t in enumerate(final):
         got = [(int(of[j]), (float(xy[of[j], ok[j], 0]), float(xy[of[j], ok[j], 1]))) for j in range(tp[i], tp[i + 1])]
