@@ -480,6 +480,7 @@ __global__ __launch_bounds__(256) void chol_update_kernel(double *__restrict__ A
 // resident (the host only takes this path for grids far below one workgroup per CU).  Spins are bounded anyway: a
 // workgroup that gives up raises the abort flag, everybody leaves and the call reports MM_ERR_HIP.
 constexpr long SPIN_LIMIT = 1L << 23;
+constexpr int FUSED_MAX_BWB = 15;  // 16 + 105 = 121 resident workgroups at most
 constexpr size_t FUSED_LDS_BYTES = (size_t)(2 * NB * LDT + 4 * 16 * 17 + 3 * NB) * sizeof(double);
 
 // Coherence between the workgroups (they sit on different XCDs, each with its own L2).  MODE 1: plain loads / stores
@@ -794,6 +795,158 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, int n, 
     }
 }
 
+// ---- backward substitution L^T x = y for a narrow band: ONE launch ------------------------------------------------------
+// Workgroup 0 owns the diagonal and the first sub-diagonal: x_k = L_kk^-T (y_k - sum_d L_{k+d,k}^T x_{k+d}), with the
+// d = 1 term computed locally right after x_{k+1}.  Workgroup d (2 <= d <= bwb) owns the blocks (k + d, k) and sends
+// its 64-vector L_{k+d,k}^T x_{k+d} to workgroup 0, which adds the terms in a fixed order.  No flags: x and the
+// contribution buffer start out as a NaN sentinel (host memset 0xFF) and every reader polls the very 8 bytes it needs
+// (written by one write-through store), so a hand-over costs one memory latency instead of store-ack + flag + load.
+// Every tile a workgroup needs next is already in flight (registers) while it waits.
+constexpr unsigned long long BWD_SENTINEL = ~0ull;
+constexpr size_t BWD_LDS_BYTES = (size_t)(2 * NB * LDT + 4 * NB + 2 * NB) * sizeof(double);
+
+__device__ __forceinline__ void tile_prefetch(double (&pre)[16], const double *__restrict__ src, int ld, int rows) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int e = threadIdx.x + 256 * q;
+        const int r = e / NB, c = e % NB;
+        pre[q] = r < rows ? src[(size_t)r * ld + c] : 0.0;
+    }
+}
+__device__ __forceinline__ void tile_commit(double (*T)[LDT], const double (&pre)[16]) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int e = threadIdx.x + 256 * q;
+        T[e / NB][e % NB] = pre[q];
+    }
+}
+// out[c] = sum_r T[r][c] v[r] for c = threadIdx.x & 63 (valid in the first 64 threads after the call); 256 threads
+__device__ __forceinline__ double tile_matvec_t(const double (*T)[LDT], const double *v, double (*part)[NB]) {
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    double s = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s += T[g * 16 + q][c] * v[g * 16 + q];
+    part[g][c] = s;
+    __syncthreads();
+    return (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+}
+// poll one double until it is no longer the sentinel (bounded); *failed is set if the wait is abandoned
+__device__ __forceinline__ double poll_value(const double *p, int32_t *abort_flag, int &failed) {
+    for (long it = 0; it < SPIN_LIMIT; ++it) {
+        const double v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned long long)__double_as_longlong(v) != BWD_SENTINEL) return v;
+        if ((it & 255) == 255 && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    failed = 1;
+    return 0.0;
+}
+
+__global__ __launch_bounds__(256) void chol_band_bwd_kernel(const double *__restrict__ A, int n, int nblk, int bwb,
+                                                            const double *__restrict__ Linv, const double *__restrict__ y,
+                                                            double *x, double *contrib, int32_t *__restrict__ abort_flag,
+                                                            int32_t *__restrict__ info) {
+    extern __shared__ double smem[];
+    double (*T0)[LDT] = reinterpret_cast<double (*)[LDT]>(smem);
+    double (*T1)[LDT] = reinterpret_cast<double (*)[LDT]>(smem + NB * LDT);
+    double (*part)[NB] = reinterpret_cast<double (*)[NB]>(smem + 2 * NB * LDT);
+    double *vec = smem + 2 * NB * LDT + 4 * NB, *vec2 = vec + NB;
+    const int W = bwb + 1;
+    int failed = 0;
+    // tiles are fetched two steps ahead (a step is shorter than a trip to memory): two register slots, loop unrolled by 2
+    if (blockIdx.x == 0) {
+        double p0a[16], p1a[16], p0b[16], p1b[16];
+        auto fetch = [&](int k, double (&p0)[16], double (&p1)[16]) {  // tiles of step k: L_kk^-1 and L_{k,k-1}
+            if (k < 0) return;
+            tile_prefetch(p0, Linv + (size_t)k * NB * NB, NB, NB);
+            if (k > 0) tile_prefetch(p1, A + (size_t)k * NB * n + (size_t)(k - 1) * NB, n, min(NB, n - k * NB));
+        };
+        double local = 0.0;  // L_{k+1,k}^T x_{k+1}, element threadIdx.x (first 64 threads)
+        bool dead = false;
+        // y_k and the contributions of step k are requested during step k + 1 (right after x_{k+1} went out), so their
+        // memory latency overlaps the local matrix-vector work; what is still the sentinel then gets polled
+        double cv[FUSED_MAX_BWB + 1], yk = 0.0;
+        auto request = [&](int k) {
+            if (k < 0 || threadIdx.x >= NB) return;
+            yk = (int)threadIdx.x < min(NB, n - k * NB) ? y[(size_t)k * NB + threadIdx.x] : 0.0;
+#pragma unroll
+            for (int dd = 2; dd <= FUSED_MAX_BWB; ++dd)
+                if (dd <= bwb && k + dd < nblk)
+                    cv[dd] = __hip_atomic_load(contrib + ((size_t)k * W + dd) * NB + threadIdx.x, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+        };
+        auto step = [&](int k, double (&p0)[16], double (&p1)[16]) {
+            const int nb = min(NB, n - k * NB);
+            tile_commit(T0, p0);
+            if (k > 0) tile_commit(T1, p1);
+            fetch(k - 2, p0, p1);
+            if (threadIdx.x < NB) {
+                double rhs = yk - local;
+#pragma unroll
+                for (int dd = 2; dd <= FUSED_MAX_BWB; ++dd)  // fixed summation order
+                    if (dd <= bwb && k + dd < nblk) {
+                        if ((unsigned long long)__double_as_longlong(cv[dd]) == BWD_SENTINEL)
+                            cv[dd] = poll_value(contrib + ((size_t)k * W + dd) * NB + threadIdx.x, abort_flag, failed);
+                        rhs -= cv[dd];
+                    }
+                vec[threadIdx.x] = rhs;
+            }
+            if (__syncthreads_or(failed)) {
+                dead = true;
+                return;
+            }
+            const double xk = tile_matvec_t(T0, vec, part);
+            if (threadIdx.x < NB) {
+                if ((int)threadIdx.x < nb) st_shared<2>(x + (size_t)k * NB + threadIdx.x, xk);
+                vec2[threadIdx.x] = (int)threadIdx.x < nb ? xk : 0.0;
+            }
+            request(k - 1);
+            __syncthreads();
+            if (k > 0) local = tile_matvec_t(T1, vec2, part);
+            __syncthreads();  // T0 / T1 / part are rewritten by the next step
+        };
+        request(nblk - 1);
+        fetch(nblk - 1, p0a, p1a);
+        fetch(nblk - 2, p0b, p1b);
+        for (int k = nblk - 1; k >= 0 && !dead; k -= 2) {
+            step(k, p0a, p1a);
+            if (k - 1 >= 0 && !dead) step(k - 1, p0b, p1b);
+        }
+        if (dead) MM_FUSED_ABANDON;
+        return;
+    }
+    const int d = blockIdx.x + 1;  // 2 .. bwb
+    const int kfirst = nblk - 1 - d;
+    if (kfirst < 0) return;
+    double pa[16], pb[16];
+    auto fetch = [&](int k, double (&pp)[16]) {
+        if (k >= 0) tile_prefetch(pp, A + (size_t)(k + d) * NB * n + (size_t)k * NB, n, min(NB, n - (k + d) * NB));
+    };
+    bool dead = false;
+    auto step = [&](int k, double (&pp)[16]) {
+        tile_commit(T0, pp);
+        fetch(k - 2, pp);
+        const int rows = min(NB, n - (k + d) * NB);
+        if (threadIdx.x < NB)
+            vec[threadIdx.x] = (int)threadIdx.x < rows ? poll_value(x + (size_t)(k + d) * NB + threadIdx.x, abort_flag, failed) : 0.0;
+        if (__syncthreads_or(failed)) {
+            dead = true;
+            return;
+        }
+        const double t = tile_matvec_t(T0, vec, part);
+        if (threadIdx.x < NB) st_shared<2>(contrib + ((size_t)k * W + d) * NB + threadIdx.x, t);
+        __syncthreads();
+    };
+    fetch(kfirst, pa);
+    fetch(kfirst - 1, pb);
+    for (int k = kfirst; k >= 0 && !dead; k -= 2) {
+        step(k, pa);
+        if (k - 1 >= 0 && !dead) step(k - 1, pb);
+    }
+    if (dead) MM_FUSED_ABANDON;
+}
+
 // ---- solves -----------------------------------------------------------------------------------------------------------
 // z = Linv * v (transpose = 0) or Linv^T * v into LDS vector `out`; 256 threads, 4 per row.
 __device__ __forceinline__ void block_gemv64(const double *__restrict__ Linv, const double *vin, double *out,
@@ -870,8 +1023,6 @@ __global__ __launch_bounds__(256) void bwd_step_kernel(const double *__restrict_
 
 }  // namespace
 
-constexpr int FUSED_MAX_BWB = 15;  // 16 + 105 = 121 resident workgroups at most
-
 extern "C" {
 
 size_t mm_chol_workspace_bytes(int n) {
@@ -946,6 +1097,23 @@ int mm_chol_solve(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int half_b
             const int grid = below > 0 ? (below + 31) / 32 : 1;
             MM_LAUNCH(ctx, "fwd_step_kernel", fwd_step_kernel, dim3(grid), dim3(256), 0, (const double *)A,
                       (const double *)(Linv + (size_t)k * NB * NB), bc, ytmp, n, k0, row_end);
+        }
+        if (fused_mode > 0 && nblk >= 2 && bwb >= 1 && bwb <= FUSED_MAX_BWB) {  // L^T x = y in one launch
+            static bool bwd_attr_set = false;
+            if (!bwd_attr_set) {
+                MM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(chol_band_bwd_kernel),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_LDS_BYTES));
+                bwd_attr_set = true;
+            }
+            int32_t *flags = (int32_t *)((char *)ytmp + mm_align_up((size_t)(n + NB) * sizeof(double), 256));
+            double *contrib = (double *)((char *)flags + mm_align_up((2 * (size_t)nblk * (FUSED_MAX_BWB + 1) + nblk + 64) * sizeof(int32_t), 256));
+            // x (the output) and the contribution buffer start as the NaN sentinel the kernel polls on
+            MM_HIP(ctx, hipMemsetAsync(flags, 0, sizeof(int32_t), ctx->stream));
+            MM_HIP(ctx, hipMemsetAsync(bc, 0xFF, (size_t)n * sizeof(double), ctx->stream));
+            MM_HIP(ctx, hipMemsetAsync(contrib, 0xFF, (size_t)nblk * (bwb + 1) * NB * sizeof(double), ctx->stream));
+            MM_LAUNCH(ctx, "chol_band_bwd_kernel", chol_band_bwd_kernel, dim3(bwb >= 2 ? bwb : 1), dim3(256), BWD_LDS_BYTES,
+                      (const double *)A, n, nblk, bwb, (const double *)Linv, (const double *)ytmp, bc, contrib, flags, info);
+            continue;
         }
         for (int k = nblk - 1; k >= 0; --k) {  // L^T x = y
             const int k0 = k * NB;
