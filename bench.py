@@ -95,6 +95,14 @@ def algorithmic_work(name, cfg):
         n = 6 * Fc
         bwb = min((6 * cfg.get("cam_span", Fc) + 5 + 63) // 64, (n + 63) // 64)
         return 0, 0, it * ((n + 63) // 64) * bwb * 2 * 64 ** 3
+    if name in ("chol_band_fused_kernel", "chol_band_bwd_kernel"):   # per LAUNCH (table() multiplies by the launch count)
+        n = 6 * Fc
+        nblk = (n + 63) // 64
+        bwb = min((6 * cfg.get("cam_span", Fc) + 5 + 63) // 64, nblk)
+        if name == "chol_band_bwd_kernel":   # the band of L and the diagonal-block inverses, read once
+            return nblk * (bwb + 1) * 64 * 64 * 8, 0, 0
+        # per block column: 64^3/3 (factor) + 64^3/3 (inverse) + bwb solves of 64^3 + bwb (bwb + 1) / 2 products of 2 64^3
+        return 0, 0, nblk * 64 ** 3 * (2.0 / 3.0 + bwb + bwb * (bwb + 1))
     if name == "chol_diag_kernel":       # 64x64 Cholesky + triangular inverse per block column
         return 0, 0, it * ((6 * Fc + 63) // 64) * 2 * 64 ** 3 / 3.0
     return None, 0, 0
@@ -200,6 +208,8 @@ def main():
         rows = []
         for name, (cnt, ms) in sorted(prof_.items(), key=lambda kv: -kv[1][1]):
             by, lops, fl = algorithmic_work(name, cfg)
+            if name.startswith("chol_band_"):
+                by, fl = (by or 0) * cnt / steps_, fl * cnt / steps_
             per = ms / steps_
             row = dict(kernel=name, launches_per_step=cnt / steps_, ms_per_step=per, avg_us=1e3 * ms / max(cnt, 1))
             if by:
@@ -215,6 +225,8 @@ def main():
     kernels = []
     for name, (cnt, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
         by, lops, fl = algorithmic_work(name, cfg)
+        if name.startswith("chol_band_"):
+            by, fl = (by or 0) * cnt / a.steps, fl * cnt / a.steps
         per = ms / a.steps
         row = dict(kernel=name, launches_per_step=cnt / a.steps, ms_per_step=per, avg_us=1e3 * ms / max(cnt, 1))
         if by:
@@ -241,6 +253,11 @@ def main():
         traffic = None
         if F == 500 and N == 4000 and "FETCH_SIZE_KB_per_launch" in pmc and "WRITE_SIZE_KB_per_launch" in pmc:
             traffic = (pmc["FETCH_SIZE_KB_per_launch"] + pmc["WRITE_SIZE_KB_per_launch"]) * 1024.0
+        if dom["kernel"] == "chol_band_fused_kernel":
+            note = ("single-launch banded Cholesky: a chain of %d dependent 64-column steps (factor 64x64 -> solve -> "
+                    "update), bound by the latency of that chain, not by MFMA throughput" % ((6 * F + 63) // 64))
+        else:
+            note = None
         if "mfma_f64_TFLOPs" in dom:
             roofline = dict(kernel=dom["kernel"], bound="mfma", achieved=dom["mfma_f64_TFLOPs"], peak=MFMA_F64_PEAK_TF,
                             unit="TFLOP/s", frac=dom["mfma_f64_TFLOPs"] / MFMA_F64_PEAK_TF, traffic=traffic,
@@ -254,6 +271,8 @@ def main():
                 roofline["valu_achieved_Tlops"] = dom["valu_Tlops"]
                 roofline["valu_peak_Tlops"] = VALU_PEAK_TLOPS
                 roofline["valu_frac"] = dom["valu_Tlops"] / VALU_PEAK_TLOPS
+        if note:
+            roofline["note"] = note
         if traffic is not None:
             roofline["traffic_note"] = ("FETCH_SIZE + WRITE_SIZE per launch from separate rocprofv3 --pmc passes "
                                         "(profiles/r01_pmc_traffic.json); FETCH not doubled: 8-byte gathers are uncalibrated")
@@ -274,6 +293,12 @@ def main():
                                    "2-view DLT, full BA (TRF, Schur, f64 MFMA Cholesky)" + (" [BA off]" if a.no_ba else ""),
                        "frames": F, "height": H, "width": W, "nfeatures": N, "parallelism": f"pairs/points x{world}"},
             "ba_residuals_per_s": ba_rps, "frames_per_s": F / (elapsed / a.steps), "stage_ms": stage_ms,
+            # the trust-region path on this outlier-laden clip is chaotic (the iteration count moves with rounding-level
+            # changes), so the per-iteration time is the figure to compare between builds, not ms_per_step
+            "ba": None if res is None else {
+                "nfev": nfev, "njev": res.njev, "iterations": getattr(res, "iterations", None),
+                "ms_per_iteration": stage_ms["ba_solve"] / max(getattr(res, "iterations", 0) or 1, 1),
+                "host_segments_ms_last_step": getattr(res, "host_segments_ms", None)},
             "problem": {"keypoints": int(kp_count.sum()), "descriptor_pairs": pair_evals,
                         "matches": int(out["match_count"].sum()), "tracks": out["n_tracks"], "observations": n_obs,
                         "ba_nfev": nfev, "ba_status": res.status if res is not None else None,

@@ -203,6 +203,10 @@ size_t mm_ba_schur_workspace_bytes(const mm_ba_problem *pb); /* 42 doubles per c
 int mm_ba_pairs_count(mm_ctx *ctx, const mm_ba_problem *pb, int32_t *cnt /*dev [O]*/, int32_t *span_out /*dev [1]*/);
 int mm_ba_pairs_emit(mm_ctx *ctx, const mm_ba_problem *pb, const int64_t *offsets /*dev [O]*/, int span,
                      int32_t *key /*dev [n]*/, int32_t *pair_o /*dev [n]*/, int32_t *pair_o2 /*dev [n]*/);
+/* Regulariser of the trust-region sub-problem on the device (SciPy trf.py:473-477, reached through
+ * bundleAdjuster.py:180-192): gh2 = |g_h|^2, d11 = |J_h g_h|^2 (device scalars), Delta the radius.
+ * out [2] dev = {reg, max(reg, min_damping)}. */
+int mm_trf_damping(mm_ctx *ctx, const double *gh2, const double *d11, double Delta, double min_damping, double *out);
 /* dp [P,3] = Cinv (gp - E^T dc). */
 int mm_ba_backsub(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, const double *pts, const double *Cinv,
                   const double *gp, const double *dc /*dev [F,6]*/, double *dp);

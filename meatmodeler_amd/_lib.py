@@ -75,6 +75,7 @@ SIGNATURES = {
     "mm_ba_schur_workspace_bytes": (C.c_size_t, [C.POINTER(BAProblem)]),
     "mm_ba_pairs_count": (C.c_int, [vp, C.POINTER(BAProblem), vp, vp]),
     "mm_ba_pairs_emit": (C.c_int, [vp, C.POINTER(BAProblem), vp, C.c_int, vp, vp, vp]),
+    "mm_trf_damping": (C.c_int, [vp, vp, vp, C.c_double, C.c_double, vp]),
     "mm_ba_backsub": (C.c_int, [vp, C.POINTER(BAProblem), vp, vp, vp, vp, vp, vp]),
     "mm_chol_workspace_bytes": (C.c_size_t, [C.c_int]),
     "mm_chol_solve": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, C.c_size_t]),

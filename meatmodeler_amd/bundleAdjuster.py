@@ -16,6 +16,8 @@ Jacobian; see DESIGN.md §BA for what "parity" means on this gauge-free problem.
 Host Python only sequences launches and does the 2x2 / scalar algebra of the trust region; torch is used for
 device buffers and a handful of axpy / dot reductions on the parameter vector.
 """
+import time
+
 import numpy as np
 import torch
 from numpy.linalg import norm as _norm
@@ -291,46 +293,42 @@ class SchurTRF:
         actual = None
         if verbose == 2:
             _print_header()
+        # wall time between the host synchronisation points of an iteration (the syncs drain the stream, so these are
+        # real intervals): normal equations, damping, Schur, Cholesky, subspace .. sync A | trial steps .. accept
+        seg = {"to_syncA": 0.0, "syncA_to_accept": 0.0}
+        t_mark = time.perf_counter()
+        g_norm = None
         while True:
-            # ---- host sync 1: |g|_inf, |g_h|, |J_h g_h|^2 (needed for the damping before the system can be built) ----
             gh = g / si                                   # g_h = d * g, d = 1 / scale_inv
-            u1 = pb.jvp(self._cams(x), self._pts(x), self._cams(gh / si), self._pts(gh / si))   # J (d g_h)
+            ghs = gh / si
+            u1 = pb.jvp(self._cams(x), self._pts(x), self._cams(ghs), self._pts(ghs))   # J (d g_h)
             gmax = g.abs().max().reshape(1)
-            d11 = torch.dot(u1.reshape(-1), u1.reshape(-1)).reshape(1)
+            d11_t = torch.dot(u1.reshape(-1), u1.reshape(-1)).reshape(1)
             if self.allreduce is not None:
                 self.allreduce(gmax, op="max")
-                self.allreduce(d11)
-            g_norm, gh2, d11 = torch.cat([gmax, self._dots([(gh, gh)]), d11]).tolist()
-            gh_norm = np.sqrt(gh2)
-            if g_norm < gtol:
-                termination = 1
-            if verbose == 2:
-                _print_iteration(iteration, nfev, cost, actual, step_norm, g_norm)
+                self.allreduce(d11_t)
+            gh2_t = self._dots([(gh, gh)])
             if termination is not None or nfev == max_nfev:
+                g_norm = float(gmax.item())
+                if verbose == 2:
+                    _print_iteration(iteration, nfev, cost, actual, step_norm, g_norm)
                 break
-            # Cauchy-derived regulariser (trf.py:473-477): a = 0.5 |J_h g_h|^2, b = -|g_h|^2
-            a_q = 0.5 * d11
-            b_q = -gh2
-            to_tr = Delta / gh_norm
-            ts = [0.0, to_tr]
-            if a_q != 0:
-                ext = -0.5 * b_q / a_q
-                if 0.0 < ext < to_tr:
-                    ts.append(ext)
-            ts = np.asarray(ts)
-            ag_value = float(np.min(ts * (a_q * ts + b_q)))
-            reg = -ag_value / Delta ** 2
-            # damped blocks: J^T J + reg * D^-2  (D^-2 = scale_inv^2).  No gauge is fixed (as in the reference), so
+            # Cauchy-derived regulariser (trf.py:473-477) computed on the device: the reduced system is built and
+            # factored without the host having seen |g|, |g_h| or |J_h g_h| (they arrive with sync A).
+            # Damped blocks: J^T J + reg * D^-2  (D^-2 = scale_inv^2).  No gauge is fixed (as in the reference), so
             # J^T J has a 7-dimensional null space and only the damping makes the reduced system definite; SciPy's
             # LSMR copes with a singular system, a Cholesky factorisation needs `reg` to stay above rounding:
-            # a floor of 1e-9 (relative to the unit diagonal of the scaled system) and x100 retries on a bad pivot.
-            reg_eff = max(reg, self.min_damping)
+            # a floor of 1e-9 (relative to the unit diagonal of the scaled system), x100 on a bad pivot, and the
+            # raised floor is kept for the rest of the solve (a system that needed it once needs it again).
+            damp = pb.trf_damping(gh2_t, d11_t, Delta, self.min_damping)
+            reg_eff = damp[1:2]
+            gh_norm_t = torch.sqrt(gh2_t)
             sic2 = (si[:nc] * si[:nc]).view(F, 6)
             sip2 = (si[nc:] * si[nc:]).view(P, 3)
             gc, gp = self._cams(g), self._pts(g)
             for attempt in range(6):
                 Bd = B.clone()
-                Bd.diagonal(dim1=1, dim2=2).add_(sic2, alpha=reg_eff)
+                Bd.diagonal(dim1=1, dim2=2).addcmul_(sic2, reg_eff)
                 Cd = C.clone()
                 Cd[:, self.diag_idx] += reg_eff * sip2
                 S, v, Cinv = pb.schur(self._cams(x), self._pts(x), Bd, Cd, gc, gp)
@@ -350,27 +348,40 @@ class SchurTRF:
                 q[nc:] = pb.backsub(self._cams(x), self._pts(x), Cinv, gp, v.view(F, 6)).reshape(-1)
                 # orthonormal basis of span{g_h, gn_h} (trf.py:481-482), all on the device
                 gn = q * si                               # gn_h = q * scale_inv
-                q1 = gh / gh_norm
+                q1 = gh / gh_norm_t
                 sc = self._dots([(q1, gn)])[0]
                 w = gn - sc * q1
                 wn2, gn2 = self._dots([(w, w), (gn, gn)])
                 q2 = w / torch.sqrt(wn2)
                 s1, s2 = q1 / si, q2 / si                 # unscaled basis steps d * q
-                Jq1 = u1.reshape(-1) / gh_norm            # J_h q1 = J (d q1)
+                Jq1 = u1.reshape(-1) / gh_norm_t          # J_h q1 = J (d q1)
                 Jq2 = pb.jvp(self._cams(x), self._pts(x), self._cams(s2), self._pts(s2)).reshape(-1)
                 bs = torch.stack([torch.dot(Jq1, Jq1), torch.dot(Jq1, Jq2), torch.dot(Jq2, Jq2)])
                 self._ar(bs)
                 nn = self._dots([(s1, s1), (s1, s2), (s2, s2), (q2, gh), (x, x)])
-                # ---- host sync 2 ----
-                vals = torch.cat([info.to(torch.float64), wn2.reshape(1), gn2.reshape(1), bs, nn]).tolist()
+                # ---- host sync A ----
+                vals = torch.cat([info.to(torch.float64), wn2.reshape(1), gn2.reshape(1), bs, nn, gmax,
+                                  gh2_t.reshape(1), reg_eff]).tolist()
                 if int(vals[0]) == 0:
                     break
                 if int(vals[0]) < 0:
                     raise MMError("mm_chol_solve: the fused banded factorisation was abandoned (info = -1)")
-                reg_eff *= 100.0
+                reg_eff = reg_eff * 100.0
+                if vals[-1] <= self.min_damping * (1.0 + 1e-12):      # failed AT the floor: the floor was too low
+                    self.min_damping *= 100.0
             else:
                 raise MMError(f"reduced camera system is not positive definite (pivot {int(vals[0])})")
-            _, wn2, gn2, b11, b12, b22, n11, n12, n22, g2, xx = vals
+            _, wn2, gn2, b11, b12, b22, n11, n12, n22, g2, xx, g_norm, gh2, _ = vals
+            gh_norm = np.sqrt(gh2)
+            t_now = time.perf_counter()
+            seg["to_syncA"] += t_now - t_mark
+            t_mark = t_now
+            if g_norm < gtol:                              # (checked before the step is used, as trf.py:443 does)
+                termination = 1
+            if verbose == 2:
+                _print_iteration(iteration, nfev, cost, actual, step_norm, g_norm)
+            if termination is not None:
+                break
             if not (wn2 > 1e-28 * max(gn2, 1e-300)):       # gn_h parallel to g_h: the subspace is one-dimensional
                 s2 = torch.zeros_like(s1)
                 b12, b22, n12, n22, g2 = 0.0, 1.0, 0.0, 0.0, 0.0
@@ -396,6 +407,9 @@ class SchurTRF:
                     break
                 alpha *= Delta / Delta_new
                 Delta = Delta_new
+            t_now = time.perf_counter()
+            seg["syncA_to_accept"] += t_now - t_mark
+            t_mark = t_now
             if actual > 0:
                 x, cost = x_new, cost_new
                 B, C = self._normal(x, g)
@@ -408,7 +422,8 @@ class SchurTRF:
         if termination is None:
             termination = 0
         return BAResult(cams=self._cams(x).clone(), pts=self._pts(x).clone(), cost=cost, optimality=g_norm, nfev=nfev,
-                        njev=njev, status=termination, message=_MESSAGES[termination], success=termination > 0)
+                        njev=njev, status=termination, message=_MESSAGES[termination], success=termination > 0,
+                        iterations=iteration, host_segments_ms={k: 1e3 * v for k, v in seg.items()})
 
 
 def _finish_verbose(res, cost0, verbose):

@@ -243,6 +243,25 @@ int check_pb(mm_ctx *ctx, const mm_ba_problem *pb, const char *who) {
 
 constexpr int RES_BLOCKS = 2048;
 
+// Regulariser of the 2-D subspace trust-region step, on the device so that the host does not have to wait for the
+// three scalars before the reduced system can be built (SciPy trf.py:473-477 via least_squares(method='trf',
+// tr_solver='lsmr'), reference bundleAdjuster.py:180-192): with a = 0.5 |J_h g_h|^2, b = -|g_h|^2 minimise
+// t (a t + b) over [0, Delta / |g_h|]; reg = -min / Delta^2.  out = {reg, max(reg, min_damping)}.
+__global__ void trf_damping_kernel(const double *__restrict__ gh2, const double *__restrict__ d11, double Delta,
+                                   double min_damping, double *__restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double a = 0.5 * d11[0], b = -gh2[0];
+    const double to_tr = Delta / sqrt(gh2[0]);
+    double best = fmin(0.0, to_tr * (a * to_tr + b));
+    if (a != 0.0) {
+        const double ext = -0.5 * b / a;
+        if (ext > 0.0 && ext < to_tr) best = fmin(best, ext * (a * ext + b));
+    }
+    const double reg = -best / (Delta * Delta);
+    out[0] = reg;
+    out[1] = fmax(reg, min_damping);
+}
+
 }  // namespace
 
 extern "C" {
@@ -309,6 +328,13 @@ int mm_ba_backsub(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, cons
         return mm_fail(ctx, MM_ERR_ARG, "mm_ba_backsub: null pointer");
     if (pb->P == 0) return MM_OK;
     MM_LAUNCH(ctx, "ba_backsub_kernel", ba_backsub_kernel, dim3((pb->P + 255) / 256), dim3(256), 0, *pb, cams, pts, Cinv, gp, dc, dp);
+    return MM_OK;
+}
+
+int mm_trf_damping(mm_ctx *ctx, const double *gh2, const double *d11, double Delta, double min_damping, double *out) {
+    if (!ctx) return MM_ERR_ARG;
+    if (!gh2 || !d11 || !out || !(Delta > 0.0)) return mm_fail(ctx, MM_ERR_ARG, "mm_trf_damping: bad argument");
+    MM_LAUNCH(ctx, "trf_damping_kernel", trf_damping_kernel, dim3(1), dim3(64), 0, gh2, d11, Delta, min_damping, out);
     return MM_OK;
 }
 

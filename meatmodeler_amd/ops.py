@@ -325,6 +325,10 @@ class BADevice:
                                        self._schur_ws.numel()), "mm_ba_schur")
         return S, v, Cinv
 
+    def trf_damping(self, gh2, d11, Delta, min_damping):
+        """Device scalars -> tensor [reg, max(reg, min_damping)] (see ops.trf_damping)."""
+        return trf_damping(gh2, d11, Delta, min_damping, self.ctx)
+
     def chol_solve(self, S, v, half_bandwidth=None):
         """In-place banded Cholesky solve of the reduced camera system (see ops.chol_solve)."""
         return chol_solve(S, v, self.ctx, half_bandwidth=half_bandwidth)
@@ -334,6 +338,14 @@ class BADevice:
         self.ctx.check(lib.mm_ba_backsub(self.ctx.h, C.byref(self.pb), ptr(cams), ptr(pts), ptr(Cinv), ptr(gp), ptr(dc),
                                          ptr(dp)), "mm_ba_backsub")
         return dp
+
+
+def trf_damping(gh2, d11, Delta, min_damping, ctx=None):
+    """Device scalars |g_h|^2 and |J_h g_h|^2 -> tensor [reg, max(reg, min_damping)] (mm_trf_damping)."""
+    ctx = ctx or default_context()
+    out = torch.empty(2, dtype=torch.float64, device=gh2.device)
+    ctx.check(lib.mm_trf_damping(ctx.h, ptr(gh2), ptr(d11), float(Delta), float(min_damping), ptr(out)), "mm_trf_damping")
+    return out
 
 
 def chol_solve(A, b, ctx=None, half_bandwidth=None):

@@ -70,6 +70,16 @@ class NumpyBA:
         out = np.einsum("omi,oi->om", Jc, wc.numpy()[self.fi]) + np.einsum("omi,oi->om", Jp, wp.numpy()[self.pi])
         return torch.from_numpy(out)
 
+    def trf_damping(self, gh2, d11, Delta, min_damping):
+        """SciPy trf.py:473-477 (the product runs this as a one-thread kernel, mm_trf_damping)."""
+        a, b = 0.5 * float(d11), -float(gh2)
+        to_tr = Delta / np.sqrt(float(gh2))
+        ts = [0.0, to_tr]
+        if a != 0 and 0.0 < -0.5 * b / a < to_tr:
+            ts.append(-0.5 * b / a)
+        reg = -min(t * (a * t + b) for t in ts) / Delta ** 2
+        return torch.tensor([reg, max(reg, min_damping)], dtype=torch.float64)
+
     @staticmethod
     def _sym(C6):
         C = np.zeros((len(C6), 3, 3))
