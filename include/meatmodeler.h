@@ -203,6 +203,12 @@ size_t mm_ba_schur_workspace_bytes(const mm_ba_problem *pb); /* 42 doubles per c
 int mm_ba_pairs_count(mm_ctx *ctx, const mm_ba_problem *pb, int32_t *cnt /*dev [O]*/, int32_t *span_out /*dev [1]*/);
 int mm_ba_pairs_emit(mm_ctx *ctx, const mm_ba_problem *pb, const int64_t *offsets /*dev [O]*/, int span,
                      int32_t *key /*dev [n]*/, int32_t *pair_o /*dev [n]*/, int32_t *pair_o2 /*dev [n]*/);
+/* k <= 8 inner products <a_q, b_q> over vectors of length n in one launch (the trust-region driver's reductions, SciPy
+ * trf.py via bundleAdjuster.py:180-192).  a, b: HOST arrays of k device pointers.  out [k,3] dev = {sum over i < split,
+ * sum over i >= split, total}; deterministic.  The workspace must be zero-filled once before its first use. */
+size_t mm_multi_dot_workspace_bytes(void);
+int mm_multi_dot(mm_ctx *ctx, int k, const double *const *a, const double *const *b, int64_t n, int64_t split,
+                 double *out, void *ws, size_t ws_bytes);
 /* Regulariser of the trust-region sub-problem on the device (SciPy trf.py:473-477, reached through
  * bundleAdjuster.py:180-192): gh2 = |g_h|^2, d11 = |J_h g_h|^2 (device scalars), Delta the radius.
  * out [2] dev = {reg, max(reg, min_damping)}. */
@@ -210,6 +216,16 @@ int mm_trf_damping(mm_ctx *ctx, const double *gh2, const double *d11, double Del
 /* dp [P,3] = Cinv (gp - E^T dc). */
 int mm_ba_backsub(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, const double *pts, const double *Cinv,
                   const double *gp, const double *dc /*dev [F,6]*/, double *dp);
+/* mm_ba_schur followed by mm_chol_solve(S, 6F, v, 1, half_bandwidth), overlapped: S is built in n_slabs ascending camera
+ * slabs (slab s = cameras [s, s+1) * cams_per_slab; slab_seg_ptr / slab_chunk_ptr: HOST arrays [n_slabs+1] with the first
+ * segment / chunk of each slab) on the context's stream while the single-launch banded factorisation runs on a second
+ * stream and consumes block rows as their slabs complete.  On return (stream-ordered) v holds the solution and info the
+ * factorisation status.  Without a pair list / slabs, or for wide bands, the two steps simply run one after the other. */
+int mm_ba_schur_solve(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, const double *pts, const double *Bd,
+                      const double *Cd, const double *gc, const double *gp, double *S, double *v, double *Cinv,
+                      int half_bandwidth, int32_t *info, void *ws_schur, size_t ws_schur_bytes, void *ws_chol,
+                      size_t ws_chol_bytes, int n_slabs, int cams_per_slab, const int64_t *slab_seg_ptr,
+                      const int64_t *slab_chunk_ptr);
 /* SPD solve A x = b by blocked Cholesky (f64 MFMA trailing updates).  A [n,n] row-major, lower triangle is
  * overwritten by L; b [nrhs,n] is overwritten by x.  half_bandwidth: A[i][j] == 0 whenever i - j > half_bandwidth
  * (pass n for a dense matrix); the factorisation and the substitutions skip blocks outside the band.

@@ -234,13 +234,18 @@ class SchurTRF:
     def _dots(self, pairs):
         """[<a, b> for (a, b) in pairs] as a device vector; the camera part of the parameter vector is replicated on
         every rank, the point part is sharded."""
+        out = self.pb.multi_dot(pairs, self.nc)          # [k, 3] = (camera part, point part, total), one launch
         if self.allreduce is None:
-            return torch.stack([torch.dot(a, b) for a, b in pairs])
-        nc = self.nc
-        cam = torch.stack([torch.dot(a[:nc], b[:nc]) for a, b in pairs])
-        pts = torch.stack([torch.dot(a[nc:], b[nc:]) for a, b in pairs])
+            return out[:, 2]
+        pts = out[:, 1].contiguous()
         self.allreduce(pts)
-        return cam + pts
+        return out[:, 0] + pts
+
+    def _dots_sharded(self, pairs):
+        """Inner products of residual-space vectors (every rank holds its own observations)."""
+        out = self.pb.multi_dot(pairs, 0)[:, 2].contiguous()
+        self._ar(out)
+        return out
 
     def _normal(self, x, g):
         """Block normal equations at x; the gradient goes straight into the flat buffer g."""
@@ -256,6 +261,14 @@ class SchurTRF:
             si[si == 0] = 1.0
             return si
         return torch.maximum(si, old)
+
+    def _damping_patterns(self, si):
+        """scale_inv^2 laid out like the blocks it is added to: [F,6,6] diagonal and the packed [P,6] upper triangle."""
+        nc, F, P = self.nc, self.pb.F, self.pb.P
+        sic2_36 = torch.diag_embed((si[:nc] * si[:nc]).view(F, 6))
+        sip2_6 = torch.zeros((P, 6), dtype=si.dtype, device=si.device)
+        sip2_6[:, self.diag_idx] = (si[nc:] * si[nc:]).view(P, 3)
+        return sic2_36, sip2_6
 
     def solve(self, cams0, pts0, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None, verbose=0, local_points_norm=None):
         pb = self.pb
@@ -280,6 +293,7 @@ class SchurTRF:
         nfev, njev = 1, 1
         B, C = self._normal(x, g)
         si = self._scale_inv(B, C)
+        sic2_36, sip2_6 = self._damping_patterns(si)
         xs = x * si
         Delta = float(torch.sqrt(self._dots([(xs, xs)])[0]).item())
         if Delta == 0:
@@ -303,10 +317,10 @@ class SchurTRF:
             ghs = gh / si
             u1 = pb.jvp(self._cams(x), self._pts(x), self._cams(ghs), self._pts(ghs))   # J (d g_h)
             gmax = g.abs().max().reshape(1)
-            d11_t = torch.dot(u1.reshape(-1), u1.reshape(-1)).reshape(1)
+            u1 = u1.reshape(-1)
+            d11_t = self._dots_sharded([(u1, u1)])
             if self.allreduce is not None:
                 self.allreduce(gmax, op="max")
-                self.allreduce(d11_t)
             gh2_t = self._dots([(gh, gh)])
             if termination is not None or nfev == max_nfev:
                 g_norm = float(gmax.item())
@@ -323,15 +337,15 @@ class SchurTRF:
             damp = pb.trf_damping(gh2_t, d11_t, Delta, self.min_damping)
             reg_eff = damp[1:2]
             gh_norm_t = torch.sqrt(gh2_t)
-            sic2 = (si[:nc] * si[:nc]).view(F, 6)
-            sip2 = (si[nc:] * si[nc:]).view(P, 3)
             gc, gp = self._cams(g), self._pts(g)
             for attempt in range(6):
-                Bd = B.clone()
-                Bd.diagonal(dim1=1, dim2=2).addcmul_(sic2, reg_eff)
-                Cd = C.clone()
-                Cd[:, self.diag_idx] += reg_eff * sip2
-                S, v, Cinv = pb.schur(self._cams(x), self._pts(x), Bd, Cd, gc, gp)
+                Bd = torch.addcmul(B, sic2_36, reg_eff)   # B + reg diag(scale_inv^2), C + reg diag(...) (packed 6)
+                Cd = torch.addcmul(C, sip2_6, reg_eff)
+                if self.allreduce is None and hasattr(pb, "schur_solve"):
+                    # one GPU: the build of S and its factorisation overlap (mm_ba_schur_solve)
+                    info, v, Cinv = pb.schur_solve(self._cams(x), self._pts(x), Bd, Cd, gc, gp, half_bw)
+                else:
+                    S, v, Cinv = pb.schur(self._cams(x), self._pts(x), Bd, Cd, gc, gp)
                 if self.allreduce is not None:
                     # every rank added the full blockdiag(Bd) and gc: remove the duplicates after the sum
                     ws = self.allreduce.world_size
@@ -342,26 +356,26 @@ class SchurTRF:
                         f = torch.arange(F, device=dev)
                         blk[f, :, f, :] -= (ws - 1) * Bd
                         v -= (ws - 1) * gc.reshape(-1)
-                info = pb.chol_solve(S, v, half_bandwidth=half_bw)
+                if self.allreduce is not None or not hasattr(pb, "schur_solve"):
+                    info = pb.chol_solve(S, v, half_bandwidth=half_bw)
                 q = torch.empty(n, **f64)                 # q = (J^T J + reg D^-2)^-1 g  (unscaled Gauss-Newton step)
                 q[:nc] = v
                 q[nc:] = pb.backsub(self._cams(x), self._pts(x), Cinv, gp, v.view(F, 6)).reshape(-1)
                 # orthonormal basis of span{g_h, gn_h} (trf.py:481-482), all on the device
                 gn = q * si                               # gn_h = q * scale_inv
                 q1 = gh / gh_norm_t
-                sc = self._dots([(q1, gn)])[0]
-                w = gn - sc * q1
-                wn2, gn2 = self._dots([(w, w), (gn, gn)])
+                sc, gn2 = self._dots([(q1, gn), (gn, gn)])
+                w = torch.addcmul(gn, q1, sc, value=-1.0)  # gn - sc q1
+                wn2 = self._dots([(w, w)])
                 q2 = w / torch.sqrt(wn2)
                 s1, s2 = q1 / si, q2 / si                 # unscaled basis steps d * q
-                Jq1 = u1.reshape(-1) / gh_norm_t          # J_h q1 = J (d q1)
                 Jq2 = pb.jvp(self._cams(x), self._pts(x), self._cams(s2), self._pts(s2)).reshape(-1)
-                bs = torch.stack([torch.dot(Jq1, Jq1), torch.dot(Jq1, Jq2), torch.dot(Jq2, Jq2)])
-                self._ar(bs)
+                # J_h q1 = J (d q1) = u1 / |g_h|: <Jq1, Jq1> = d11 / |g_h|^2, <Jq1, Jq2> = <u1, Jq2> / |g_h|
+                bs = self._dots_sharded([(u1, Jq2), (Jq2, Jq2)])
                 nn = self._dots([(s1, s1), (s1, s2), (s2, s2), (q2, gh), (x, x)])
                 # ---- host sync A ----
                 vals = torch.cat([info.to(torch.float64), wn2.reshape(1), gn2.reshape(1), bs, nn, gmax,
-                                  gh2_t.reshape(1), reg_eff]).tolist()
+                                  gh2_t.reshape(1), d11_t.reshape(1), reg_eff]).tolist()
                 if int(vals[0]) == 0:
                     break
                 if int(vals[0]) < 0:
@@ -371,8 +385,9 @@ class SchurTRF:
                     self.min_damping *= 100.0
             else:
                 raise MMError(f"reduced camera system is not positive definite (pivot {int(vals[0])})")
-            _, wn2, gn2, b11, b12, b22, n11, n12, n22, g2, xx, g_norm, gh2, _ = vals
+            _, wn2, gn2, u1Jq2, b22, n11, n12, n22, g2, xx, g_norm, gh2, d11, _ = vals
             gh_norm = np.sqrt(gh2)
+            b11, b12 = d11 / gh2, u1Jq2 / gh_norm
             t_now = time.perf_counter()
             seg["to_syncA"] += t_now - t_mark
             t_mark = t_now
@@ -415,6 +430,7 @@ class SchurTRF:
                 B, C = self._normal(x, g)
                 njev += 1
                 si = self._scale_inv(B, C, si)
+                sic2_36, sip2_6 = self._damping_patterns(si)
             else:
                 step_norm = 0
                 actual = 0

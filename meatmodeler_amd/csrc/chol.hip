@@ -656,8 +656,12 @@ __device__ __forceinline__ void finish_off_block(double (*As)[LDT], double (*Bs)
 template <int MODE>
 __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, int n, int nblk, int bwb, double *Linv,
                                                               int32_t *__restrict__ flags, int32_t *__restrict__ info,
-                                                              const double *__restrict__ b_fwd, double *y,
-                                                              double *contrib) {
+                                                              const double *b_fwd, double *y,
+                                                              double *contrib, const int32_t *slab_ready,
+                                                              int cams_per_slab, int n_cams) {
+    // these waves form a latency chain; when the reduced system is being built by a concurrent launch they share their
+    // SIMDs with its waves, so ask the instruction arbiter to prefer them
+    __builtin_amdgcn_s_setprio(3);
     extern __shared__ double smem[];
     double (*As)[LDT] = reinterpret_cast<double (*)[LDT]>(smem);
     double (*Bs)[LDT] = reinterpret_cast<double (*)[LDT]>(smem + NB * LDT);
@@ -672,6 +676,14 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, int n, 
     auto flag = [&](int r, int d) { return flags + (size_t)r * W + d; };
     auto yflag = [&](int r) { return flags + (size_t)nblk * W + 1 + r; };
     auto cflag = [&](int r, int d) { return flags + (size_t)nblk * W + 1 + nblk + (size_t)r * W + d; };
+    // Rows of A (and of the right-hand side) may still be under construction by a concurrent launch on another
+    // stream (the reduced camera system, built in camera slabs): block row r covers the cameras 64r/6 .. (64r+63)/6,
+    // i.e. at most two slabs, whose flags are raised by stream-ordered one-thread kernels after each slab.
+    auto rows_ready = [&](int r) -> bool {
+        if (!slab_ready) return true;
+        const int s_lo = (NB * r / 6) / cams_per_slab, s_hi = min(n_cams - 1, (NB * r + NB - 1) / 6) / cams_per_slab;
+        return wg_wait<MODE>(slab_ready + s_lo, s_hi != s_lo ? slab_ready + s_hi : nullptr, abort_flag, &s_ok);
+    };
     // role of this workgroup: offset d (0 = row head: blocks (r, r-1) and (r, r)), first column / row j, period
     int d = 0, j = blockIdx.x, period = W;
     if ((int)blockIdx.x >= W) {
@@ -690,7 +702,6 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, int n, 
             const int r = c + d;
             const int rows = min(NB, n - r * NB);
             double *tile = A + (size_t)r * NB * n + (size_t)c * NB;
-            MM_ACC_FOREACH(a0[a][b][i] = row < rows ? tile[(size_t)row * n + col] : 0.0;)
             zero_acc(acc);
             for (int k = max(0, r - bwb); k < c; ++k) {
                 if (!wg_wait<MODE>(flag(r, r - k), flag(c, c - k), abort_flag, &s_ok)) MM_FUSED_ABANDON;
@@ -699,6 +710,10 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, int n, 
                 __syncthreads();
                 tile_gemm_nt(As, Bs, acc);
             }
+            // the block's own entries are fetched as late as possible (their latency hides behind the wait for L_cc):
+            // when the matrix is still being produced by a concurrent launch, this owner needs row r only now
+            if (!rows_ready(r)) MM_FUSED_ABANDON;
+            MM_ACC_FOREACH(a0[a][b][i] = row < rows ? ld_shared<MODE>(tile + (size_t)row * n + col) : 0.0;)
             if (!wg_wait<MODE>(flag(c, 0), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
             finish_off_block<MODE>(As, Bs, T, a0, acc, A + (size_t)c * NB * n + (size_t)c * NB, Linv + (size_t)c * NB * NB, tile,
                                    n, rows);
@@ -720,8 +735,6 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, int n, 
         const bool has_sub = r >= 1 && bwb >= 1;
         double *dtile = A + (size_t)r * NB * n + (size_t)r * NB;
         double *stile = dtile - NB;  // block (r, r - 1)
-        MM_ACC_FOREACH(a0[a][b][i] = (row < nb && col < nb && col <= row) ? dtile[(size_t)row * n + col] : 0.0;)
-        if (has_sub) MM_ACC_FOREACH(a1[a][b][i] = row < nb ? stile[(size_t)row * n + col] : 0.0;)
         zero_acc(acc);
         zero_acc(acc1);
         for (int k = max(0, r - bwb); k + 1 < r; ++k) {
@@ -732,6 +745,9 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, int n, 
             tile_gemm_nt(As, Bs, acc1);
             tile_gemm_nt(As, As, acc);
         }
+        if (!rows_ready(r)) MM_FUSED_ABANDON;  // (see the off-diagonal owner: fetched late, hidden behind the next wait)
+        MM_ACC_FOREACH(a0[a][b][i] = (row < nb && col < nb && col <= row) ? ld_shared<MODE>(dtile + (size_t)row * n + col) : 0.0;)
+        if (has_sub) MM_ACC_FOREACH(a1[a][b][i] = row < nb ? ld_shared<MODE>(stile + (size_t)row * n + col) : 0.0;)
         if (has_sub) {
             if (!wg_wait<MODE>(flag(r - 1, 0), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
             finish_off_block<MODE>(As, Bs, T, a1, acc1, dtile - (size_t)NB * n - NB, Linv + (size_t)(r - 1) * NB * NB, stile, n,
@@ -773,7 +789,7 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, int n, 
             if ((rr >> 4) != (cc >> 4)) Linv[(size_t)r * NB * NB + e] = X[rr][cc];
         }
         if (b_fwd) {  // y_r = L_rr^-1 (b_r - sum_d L_{r,r-d} y_{r-d})
-            if (threadIdx.x < NB) rhs[threadIdx.x] = (int)threadIdx.x < nb ? b_fwd[(size_t)r * NB + threadIdx.x] : 0.0;
+            if (threadIdx.x < NB) rhs[threadIdx.x] = (int)threadIdx.x < nb ? ld_shared<MODE>(b_fwd + (size_t)r * NB + threadIdx.x) : 0.0;
             if (has_sub) {  // this workgroup owns (r, r-1); its LDS copy is gone (M), read the block back
                 if (!wg_wait<MODE>(yflag(r - 1), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
                 load_tile_shared<MODE>(As, stile, n, nb);
@@ -1034,6 +1050,29 @@ size_t mm_chol_workspace_bytes(int n) {
 
 int mm_chol_solve(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int half_bandwidth, int32_t *info, void *ws,
                   size_t ws_bytes) {
+    return mm_chol_solve_gated(ctx, A, n, b, nrhs, half_bandwidth, info, ws, ws_bytes, nullptr, 1, 0);
+}
+
+}  // extern "C"
+
+static int chol_fused_mode() {
+    static const int mode = [] {
+        const char *e = getenv("MM_CHOL_FUSED");
+        return e ? atoi(e) : 2;
+    }();
+    return mode;
+}
+
+bool mm_chol_fused_eligible(int n, int half_bandwidth) {
+    const int nblk = (n + NB - 1) / NB;
+    long bwb_l = ((long)half_bandwidth + NB - 1) / NB;
+    const int bwb = bwb_l > nblk ? nblk : (int)bwb_l;
+    return chol_fused_mode() > 0 && nblk >= 2 && bwb >= 1 && bwb <= FUSED_MAX_BWB && !(n & 1);
+}
+
+// mm_chol_solve with the rows of A / b gated by slab flags (slab_ready == nullptr: everything is there already)
+int mm_chol_solve_gated(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int half_bandwidth, int32_t *info, void *ws,
+                        size_t ws_bytes, const int32_t *slab_ready, int cams_per_slab, int n_cams) {
     if (!ctx) return MM_ERR_ARG;
     if (n == 0) return MM_OK;
     if (!A || !info || n < 0 || nrhs < 0 || (nrhs > 0 && !b) || half_bandwidth < 0)
@@ -1048,10 +1087,9 @@ int mm_chol_solve(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int half_b
     long bwb_l = ((long)half_bandwidth + NB - 1) / NB;
     const int bwb = bwb_l > nblk ? nblk : (int)bwb_l;
     bool fwd_done = false;  // forward substitution of right-hand side 0 already done by the fused kernel
-    static const int fused_mode = [] {
-        const char *e = getenv("MM_CHOL_FUSED");
-        return e ? atoi(e) : 2;
-    }();
+    const int fused_mode = chol_fused_mode();
+    if (slab_ready && !mm_chol_fused_eligible(n, half_bandwidth))
+        return mm_fail(ctx, MM_ERR_ARG, "mm_chol_solve_gated: gating needs the single-launch factorisation");
     if (fused_mode > 0 && nblk >= 2 && bwb >= 1 && bwb <= FUSED_MAX_BWB) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -1069,10 +1107,10 @@ int mm_chol_solve(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int half_b
         const int grid = (bwb + 1) + bwb * (bwb - 1) / 2;
         if (fused_mode == 1)
             MM_LAUNCH(ctx, "chol_band_fused_kernel", chol_band_fused_kernel<1>, dim3(grid), dim3(256), FUSED_LDS_BYTES, A, n,
-                      nblk, bwb, Linv, flags, info, b_fwd, ytmp, contrib);
+                      nblk, bwb, Linv, flags, info, b_fwd, ytmp, contrib, slab_ready, cams_per_slab, n_cams);
         else
             MM_LAUNCH(ctx, "chol_band_fused_kernel", chol_band_fused_kernel<2>, dim3(grid), dim3(256), FUSED_LDS_BYTES, A, n,
-                      nblk, bwb, Linv, flags, info, b_fwd, ytmp, contrib);
+                      nblk, bwb, Linv, flags, info, b_fwd, ytmp, contrib, slab_ready, cams_per_slab, n_cams);
         fwd_done = b_fwd != nullptr;
     } else {
         for (int k = 0; k < nblk; ++k) {
@@ -1127,5 +1165,3 @@ int mm_chol_solve(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int half_b
     }
     return MM_OK;
 }
-
-}  // extern "C"

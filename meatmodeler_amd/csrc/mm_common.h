@@ -20,7 +20,23 @@ struct mm_ctx {
     int prof = 0;  // 0 off, 1 every launch, 2 only launches of >= 64 workgroups (micro-launch chains stay untouched)
     std::vector<mm_prof_rec> recs;
     std::vector<hipEvent_t> pool;
+    // second stream + fork/join events for overlapping the reduced-system build with its factorisation (lazily created)
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
+
+// launches of the enclosed scope go to another stream of the context
+struct mm_stream_swap {
+    mm_ctx *c;
+    hipStream_t saved;
+    mm_stream_swap(mm_ctx *ctx, hipStream_t s) : c(ctx), saved(ctx->stream) { ctx->stream = s; }
+    ~mm_stream_swap() { c->stream = saved; }
+};
+
+// chol.hip internals used by the overlapped Schur + solve entry point (schur.hip)
+bool mm_chol_fused_eligible(int n, int half_bandwidth);
+int mm_chol_solve_gated(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int half_bandwidth, int32_t *info, void *ws,
+                        size_t ws_bytes, const int32_t *slab_ready, int cams_per_slab, int n_cams);
 
 static inline hipEvent_t mm_prof_event(mm_ctx *c) {
     hipEvent_t e = nullptr;

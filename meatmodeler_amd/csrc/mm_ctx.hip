@@ -28,6 +28,9 @@ void mm_ctx_destroy(mm_ctx *ctx) {
         (void)hipEventDestroy(r.b);
     }
     for (auto e : ctx->pool) (void)hipEventDestroy(e);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
     delete ctx;
 }
 

@@ -22,7 +22,6 @@
 namespace {
 
 constexpr int MAXL = 8;
-constexpr int HALF_PATCH = 15;
 constexpr int EDGE = 31;
 
 struct OrbGeom {

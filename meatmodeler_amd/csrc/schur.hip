@@ -121,13 +121,14 @@ __global__ __launch_bounds__(64 * SP_WAVES, 2) void schur_pairs_kernel(mm_ba_pro
                                                                     const double *__restrict__ pts,
                                                                     const double *__restrict__ Cinv,
                                                                     const double *__restrict__ gp,
-                                                                    double *__restrict__ partial) {
+                                                                    double *__restrict__ partial, int64_t chunk_lo,
+                                                                    int64_t chunk_hi) {
     __shared__ double Ks[9];
     if (threadIdx.x < 9) Ks[threadIdx.x] = pb.K[threadIdx.x];
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int64_t c = (int64_t)blockIdx.x * SP_WAVES + (threadIdx.x >> 6);
-    if (c >= pb.n_chunks) return;  // wave-uniform; no workgroup barriers below
+    const int64_t c = chunk_lo + (int64_t)blockIdx.x * SP_WAVES + (threadIdx.x >> 6);
+    if (c >= chunk_hi) return;  // wave-uniform; no workgroup barriers below
     const int seg = pb.seg_ids[pb.chunk_seg[c]];
     const int i = seg / (pb.cam_span + 1), d = seg % (pb.cam_span + 1);
     const int f2 = i - d;
@@ -181,10 +182,10 @@ __global__ __launch_bounds__(64 * SP_WAVES, 2) void schur_pairs_kernel(mm_ba_pro
 __global__ __launch_bounds__(256) void schur_pairs_reduce_kernel(mm_ba_problem pb, const double *__restrict__ partial,
                                                                  const double *__restrict__ Bd,
                                                                  const double *__restrict__ gc, double *__restrict__ S,
-                                                                 double *__restrict__ v) {
+                                                                 double *__restrict__ v, int64_t seg_lo, int64_t seg_hi) {
     const int q = threadIdx.x & 63;
-    const int64_t sidx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (sidx >= pb.n_seg || q >= 42) return;
+    const int64_t sidx = seg_lo + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (sidx >= seg_hi || q >= 42) return;
     const int seg = pb.seg_ids[sidx];
     const int i = seg / (pb.cam_span + 1), d = seg % (pb.cam_span + 1);
     const int f2 = i - d;
@@ -199,6 +200,12 @@ __global__ __launch_bounds__(256) void schur_pairs_reduce_kernel(mm_ba_problem p
     } else {
         v[(size_t)i * 6 + (q - 36)] = gc[(size_t)i * 6 + (q - 36)] - s;
     }
+}
+
+// raised by a one-thread launch queued behind the kernels of a camera slab: everything before it in the stream is done
+// and visible device-wide, so a concurrent consumer on another stream may read the slab's rows
+__global__ void slab_flag_kernel(int32_t *flags, int s) {
+    __hip_atomic_store(flags + s, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // cameras without any observation never appear in a segment: their diagonal block / rhs is just (Bd, gc)
@@ -274,9 +281,11 @@ extern "C" int mm_ba_pairs_emit(mm_ctx *ctx, const mm_ba_problem *pb, const int6
     return MM_OK;
 }
 
+constexpr int MAX_SLABS = 64;
+
 extern "C" size_t mm_ba_schur_workspace_bytes(const mm_ba_problem *pb) {
     if (!pb || pb->n_chunks <= 0) return 0;
-    return mm_align_up((size_t)pb->n_chunks * 42 * sizeof(double), 256);
+    return mm_align_up((size_t)pb->n_chunks * 42 * sizeof(double), 256) + 256 /* slab flags */;
 }
 
 extern "C" int mm_ba_schur(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, const double *pts,
@@ -299,13 +308,75 @@ extern "C" int mm_ba_schur(mm_ctx *ctx, const mm_ba_problem *pb, const double *c
         MM_LAUNCH(ctx, "schur_diag_fill_kernel", schur_diag_fill_kernel, dim3(pb->F), dim3(64), 0, *pb, Bd, gc, S, v);
         const int64_t wgs = (pb->n_chunks + SP_WAVES - 1) / SP_WAVES;
         MM_LAUNCH(ctx, "schur_pairs_kernel", schur_pairs_kernel, dim3((unsigned)wgs), dim3(64 * SP_WAVES), 0, *pb, cams,
-                  pts, Cinv, gp, (double *)ws);
+                  pts, Cinv, gp, (double *)ws, (int64_t)0, (int64_t)pb->n_chunks);
         MM_LAUNCH(ctx, "schur_pairs_reduce_kernel", schur_pairs_reduce_kernel, dim3((unsigned)((pb->n_seg + 3) / 4)),
-                  dim3(256), 0, *pb, (const double *)ws, Bd, gc, S, v);
+                  dim3(256), 0, *pb, (const double *)ws, Bd, gc, S, v, (int64_t)0, (int64_t)pb->n_seg);
         return MM_OK;
     }
     const int nwin = (pb->F + SR_WIN - 1) / SR_WIN;
     MM_LAUNCH(ctx, "schur_rows_kernel", schur_rows_kernel, dim3(pb->F, nwin), dim3(256), 0, *pb, cams, pts, Bd, Cinv, gc,
               gp, S, v);
+    return MM_OK;
+}
+
+// Reduced camera system + its solution, overlapped: S is built in camera slabs (ascending) on the context's stream
+// while the single-launch banded Cholesky, started first on a second stream, consumes block rows as their slabs are
+// flagged complete.  The factorisation is a chain of dependent block columns that keeps ~46 CUs busy; building S keeps
+// the other ~210 busy; one after the other they cost 0.52 + 1.05 ms at C3, overlapped about the longer of the two.
+// Falls back to mm_ba_schur + mm_chol_solve when the problem has no pair list / slabs or the band is too wide.
+extern "C" int mm_ba_schur_solve(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, const double *pts,
+                                 const double *Bd, const double *Cd, const double *gc, const double *gp, double *S,
+                                 double *v, double *Cinv, int half_bandwidth, int32_t *info, void *ws_schur,
+                                 size_t ws_schur_bytes, void *ws_chol, size_t ws_chol_bytes, int n_slabs,
+                                 int cams_per_slab, const int64_t *slab_seg_ptr, const int64_t *slab_chunk_ptr) {
+    if (!ctx) return MM_ERR_ARG;
+    if (!pb || !info) return mm_fail(ctx, MM_ERR_ARG, "mm_ba_schur_solve: bad argument");
+    const int n = pb->F * 6;
+    const bool pairs_ok = pb->n_seg > 0 && pb->n_chunks > 0 && pb->seg_ids && pb->seg_chunk_ptr && pb->chunk_seg &&
+                          pb->chunk_begin && pb->chunk_end && pb->pair_o && pb->pair_o2;
+    const bool overlap = pairs_ok && n_slabs >= 2 && n_slabs <= MAX_SLABS && cams_per_slab >= 16 && slab_seg_ptr &&
+                         slab_chunk_ptr && mm_chol_fused_eligible(n, half_bandwidth) && pb->P > 0;
+    if (!overlap) {
+        int rc = mm_ba_schur(ctx, pb, cams, pts, Bd, Cd, gc, gp, S, v, Cinv, ws_schur, ws_schur_bytes);
+        if (rc) return rc;
+        return mm_chol_solve(ctx, S, n, v, 1, half_bandwidth, info, ws_chol, ws_chol_bytes);
+    }
+    if (!cams || !pts || !Bd || !Cd || !gc || !gp || !S || !v || !Cinv) return mm_fail(ctx, MM_ERR_ARG, "mm_ba_schur_solve: null pointer");
+    if (!ws_schur || ws_schur_bytes < mm_ba_schur_workspace_bytes(pb)) return mm_fail(ctx, MM_ERR_WORKSPACE, "mm_ba_schur_solve: workspace too small");
+    if (slab_seg_ptr[0] != 0 || slab_seg_ptr[n_slabs] != pb->n_seg || slab_chunk_ptr[0] != 0 || slab_chunk_ptr[n_slabs] != pb->n_chunks ||
+        (int64_t)n_slabs * cams_per_slab < pb->F)
+        return mm_fail(ctx, MM_ERR_ARG, "mm_ba_schur_solve: slab tables do not cover the problem");
+    if (!ctx->aux) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = numerically lowest = highest priority
+        MM_HIP(ctx, hipStreamCreateWithPriority(&ctx->aux, hipStreamNonBlocking, hi));
+        MM_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        MM_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    }
+    double *partial = (double *)ws_schur;
+    int32_t *slab_ready = (int32_t *)((char *)ws_schur + mm_align_up((size_t)pb->n_chunks * 42 * sizeof(double), 256));
+    MM_LAUNCH(ctx, "point_inverse_kernel", point_inverse_kernel, dim3((pb->P + 255) / 256), dim3(256), 0, pb->P, Cd, Cinv);
+    MM_HIP(ctx, hipMemsetAsync(S, 0, (size_t)n * n * sizeof(double), ctx->stream));
+    MM_HIP(ctx, hipMemsetAsync(slab_ready, 0, MAX_SLABS * sizeof(int32_t), ctx->stream));
+    MM_LAUNCH(ctx, "schur_diag_fill_kernel", schur_diag_fill_kernel, dim3(pb->F), dim3(64), 0, *pb, Bd, gc, S, v);
+    MM_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+    MM_HIP(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
+    {   // the consumer goes first, so that its workgroups are resident before the producer floods the CUs
+        mm_stream_swap sw(ctx, ctx->aux);
+        int rc = mm_chol_solve_gated(ctx, S, n, v, 1, half_bandwidth, info, ws_chol, ws_chol_bytes, slab_ready, cams_per_slab, pb->F);
+        if (rc) return rc;
+        MM_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
+    }
+    for (int sl = 0; sl < n_slabs; ++sl) {
+        const int64_t c_lo = slab_chunk_ptr[sl], c_hi = slab_chunk_ptr[sl + 1], s_lo = slab_seg_ptr[sl], s_hi = slab_seg_ptr[sl + 1];
+        if (c_hi > c_lo) {
+            MM_LAUNCH(ctx, "schur_pairs_kernel", schur_pairs_kernel, dim3((unsigned)((c_hi - c_lo + SP_WAVES - 1) / SP_WAVES)),
+                      dim3(64 * SP_WAVES), 0, *pb, cams, pts, (const double *)Cinv, gp, partial, c_lo, c_hi);
+            MM_LAUNCH(ctx, "schur_pairs_reduce_kernel", schur_pairs_reduce_kernel, dim3((unsigned)((s_hi - s_lo + 3) / 4)),
+                      dim3(256), 0, *pb, (const double *)partial, Bd, gc, S, v, s_lo, s_hi);
+        }
+        MM_LAUNCH(ctx, "slab_flag_kernel", slab_flag_kernel, dim3(1), dim3(1), 0, slab_ready, sl);
+    }
+    MM_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     return MM_OK;
 }

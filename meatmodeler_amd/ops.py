@@ -188,6 +188,7 @@ class BADevice:
         (CSR by point, CSR by camera, co-observation pair list and its chunk table) are built on the device: torch
         provides the sorts / scans (index plumbing), two HIP kernels enumerate the pairs."""
         self.ctx = ctx or default_context()
+        self._mdot = None
         dev = device
         self.device = dev
         self.F, self.P, self.O = int(F), int(P), int(len(fi))
@@ -225,6 +226,7 @@ class BADevice:
         else:
             self.cam_obs = torch.zeros(0, dtype=torch.int32, device=dev)
         self.cam_span = 0
+        self.slabs = None
         self.pb = BAProblem(F, P, O, ptr(self.K), ptr(self.fi), ptr(self.pi), ptr(self.obs),
                             ptr(self.pt_ptr), ptr(self.pt_obs), ptr(self.cam_ptr), ptr(self.cam_obs),
                             0, 0, 0, None, None, 0, None, None, None, None, None)
@@ -272,10 +274,21 @@ class BADevice:
                 self.pb.seg_ids, self.pb.seg_chunk_ptr = ptr(self.seg_ids), ptr(self.seg_chunk_ptr)
                 self.pb.chunk_seg, self.pb.chunk_begin, self.pb.chunk_end = ptr(self.chunk_seg), ptr(self.chunk_begin), ptr(self.chunk_end)
                 self.pb.pair_o, self.pb.pair_o2 = ptr(self.pair_o), ptr(self.pair_o2)
+                # camera slabs for the overlapped build + solve (mm_ba_schur_solve): first segment / chunk of each slab
+                n_slabs = 8
+                cps = -(-F // n_slabs)
+                if cps >= 16:
+                    seg_cam = seg_ids.to(torch.int64) // (self.cam_span + 1)
+                    bounds = torch.arange(n_slabs + 1, **i64) * cps
+                    sseg = torch.searchsorted(seg_cam, bounds)
+                    schunk = torch.cat([first, first_hi[-1:]])[sseg]
+                    self.slabs = (n_slabs, cps, np.ascontiguousarray(sseg.cpu().numpy(), np.int64),
+                                  np.ascontiguousarray(schunk.cpu().numpy(), np.int64))
         self._ws = torch.empty(2048 * 8, dtype=torch.uint8, device=dev)
         self._cost2 = torch.zeros(1, dtype=torch.float64, device=dev)
         self._S = None  # reduced camera system, allocated once (6F x 6F doubles)
         self._schur_ws = None
+        self._chol_ws = None
 
     def residual(self, cams, pts, want_res=False):
         """-> (sum of squared residuals as a 1-element device tensor, res [O,2] or None)."""
@@ -325,6 +338,38 @@ class BADevice:
                                        self._schur_ws.numel()), "mm_ba_schur")
         return S, v, Cinv
 
+    def schur_solve(self, cams, pts, Bd, Cd, gc, gp, half_bandwidth):
+        """Reduced camera system built and solved in one overlapped call (mm_ba_schur_solve): -> (info, dc [6F], Cinv).
+        dc is the solution of S dc = v (the camera part of the damped Gauss-Newton step)."""
+        n = 6 * self.F
+        if self._S is None:
+            self._S = torch.empty((n, n), dtype=torch.float64, device=self.device)
+        v = torch.empty(n, dtype=torch.float64, device=self.device)
+        Cinv = torch.empty((self.P, 6), dtype=torch.float64, device=self.device)
+        info = torch.zeros(1, dtype=torch.int32, device=self.device)
+        if self._schur_ws is None:
+            nb = lib.mm_ba_schur_workspace_bytes(C.byref(self.pb))
+            self._schur_ws = torch.empty(max(nb, 256), dtype=torch.uint8, device=self.device)
+        if self._chol_ws is None:
+            self._chol_ws = torch.empty(lib.mm_chol_workspace_bytes(n), dtype=torch.uint8, device=self.device)
+        hb = int(min(half_bandwidth, n))
+        if self.slabs is not None:
+            ns, cps, sseg, schunk = self.slabs
+            a_seg, a_chunk = sseg.ctypes.data_as(_lib.c_i64p), schunk.ctypes.data_as(_lib.c_i64p)
+        else:
+            ns, cps, a_seg, a_chunk = 0, 0, None, None
+        self.ctx.check(lib.mm_ba_schur_solve(self.ctx.h, C.byref(self.pb), ptr(cams), ptr(pts), ptr(Bd), ptr(Cd), ptr(gc),
+                                             ptr(gp), ptr(self._S), ptr(v), ptr(Cinv), hb, ptr(info), ptr(self._schur_ws),
+                                             self._schur_ws.numel(), ptr(self._chol_ws), self._chol_ws.numel(), ns, cps,
+                                             a_seg, a_chunk), "mm_ba_schur_solve")
+        return info, v, Cinv
+
+    def multi_dot(self, pairs, split=0):
+        """[k, 3] device tensor of inner products (camera part, point part, total); see ops.MultiDot."""
+        if self._mdot is None:
+            self._mdot = MultiDot(self.device, self.ctx)
+        return self._mdot(pairs, split)
+
     def trf_damping(self, gh2, d11, Delta, min_damping):
         """Device scalars -> tensor [reg, max(reg, min_damping)] (see ops.trf_damping)."""
         return trf_damping(gh2, d11, Delta, min_damping, self.ctx)
@@ -338,6 +383,32 @@ class BADevice:
         self.ctx.check(lib.mm_ba_backsub(self.ctx.h, C.byref(self.pb), ptr(cams), ptr(pts), ptr(Cinv), ptr(gp), ptr(dc),
                                          ptr(dp)), "mm_ba_backsub")
         return dp
+
+
+class MultiDot:
+    """[<a, b> for (a, b) in pairs] in one launch (mm_multi_dot): returns a device tensor [k, 3] =
+    (sum over i < split, sum over i >= split, total).  Holds the zero-initialised workspace."""
+
+    def __init__(self, device, ctx=None):
+        self.ctx = ctx or default_context()
+        self.ws = torch.zeros(lib.mm_multi_dot_workspace_bytes(), dtype=torch.uint8, device=device)
+
+    def __call__(self, pairs, split=0):
+        out_all = []
+        for i0 in range(0, len(pairs), 8):
+            chunk = pairs[i0:i0 + 8]
+            k = len(chunk)
+            n = chunk[0][0].numel()
+            for a, b in chunk:
+                assert a.dtype == torch.float64 and b.dtype == torch.float64 and a.is_contiguous() and b.is_contiguous()
+                assert a.numel() == n and b.numel() == n
+            pa = (C.c_void_p * k)(*[a.data_ptr() for a, _ in chunk])
+            pb_ = (C.c_void_p * k)(*[b.data_ptr() for _, b in chunk])
+            out = torch.empty((k, 3), dtype=torch.float64, device=self.ws.device)
+            self.ctx.check(lib.mm_multi_dot(self.ctx.h, k, pa, pb_, n, int(split), ptr(out), ptr(self.ws), self.ws.numel()),
+                           "mm_multi_dot")
+            out_all.append(out)
+        return out_all[0] if len(out_all) == 1 else torch.cat(out_all)
 
 
 def trf_damping(gh2, d11, Delta, min_damping, ctx=None):

@@ -70,6 +70,10 @@ class NumpyBA:
         out = np.einsum("omi,oi->om", Jc, wc.numpy()[self.fi]) + np.einsum("omi,oi->om", Jp, wp.numpy()[self.pi])
         return torch.from_numpy(out)
 
+    def multi_dot(self, pairs, split=0):
+        rows = [[torch.dot(a[:split], b[:split]), torch.dot(a[split:], b[split:]), torch.dot(a, b)] for a, b in pairs]
+        return torch.stack([torch.stack(r) for r in rows])
+
     def trf_damping(self, gh2, d11, Delta, min_damping):
         """SciPy trf.py:473-477 (the product runs this as a one-thread kernel, mm_trf_damping)."""
         a, b = 0.5 * float(d11), -float(gh2)

@@ -392,6 +392,29 @@ def test_chol_solve_banded(n, hb):
     np.testing.assert_allclose(L, np.linalg.cholesky(A), rtol=1e-9, atol=1e-10)
 
 
+@pytest.mark.parametrize("F,P,L", [(200, 6000, 12), (130, 2000, 40)])
+def test_schur_solve_overlapped_equals_sequential(F, P, L):
+    """mm_ba_schur_solve (S built in camera slabs on one stream while the single-launch Cholesky consumes finished
+    block rows on another) returns bit for bit what mm_ba_schur followed by mm_chol_solve returns."""
+    pr = synth.make_ba_problem(F, P, L, seed=F)
+    cams = dev(bo.frame_parameters(pr["ext"]).reshape(F, 6))
+    pts = dev(pr["pts0"])
+    pb = ops.BADevice(pr["K"], pr["fi"], pr["pi"], pr["obs"], F, P, DEV)
+    assert pb.slabs is not None and pb.n_pairs > 0
+    B, gc, C6, gp = pb.normal_eq(cams, pts)
+    Bd = B + 1e-3 * torch.diag_embed(torch.diagonal(B, dim1=1, dim2=2))
+    Cd = C6.clone()
+    Cd[:, [0, 3, 5]] *= 1.0 + 1e-3
+    hb = 6 * pb.cam_span + 5
+    S, v, Cinv0 = pb.schur(cams, pts, Bd, Cd, gc, gp)
+    info0 = ops.chol_solve(S, v, half_bandwidth=hb)
+    ref = v.clone()
+    for _ in range(3):      # repeated: the flags / workspaces are reused
+        info, dc, Cinv = pb.schur_solve(cams, pts, Bd, Cd, gc, gp, hb)
+        assert int(info) == 0 and int(info0) == 0
+        assert torch.equal(dc, ref) and torch.equal(Cinv, Cinv0)
+
+
 def test_chol_reports_non_spd():
     A = np.eye(70)
     A[66, 66] = -1.0
