@@ -17,6 +17,7 @@ Host Python only sequences launches and does the 2x2 / scalar algebra of the tru
 device buffers and a handful of axpy / dot reductions on the parameter vector.
 """
 import time
+import warnings
 
 import numpy as np
 import torch
@@ -208,6 +209,7 @@ class SchurTRF:
         self.allreduce = allreduce
         self.timers = timers
         self.min_damping = min_damping
+        self._overlap_checked = False
 
     # -- reductions that need the cross-rank sum when sharded --
     def _ar(self, *tensors):
@@ -344,6 +346,15 @@ class SchurTRF:
                 if self.allreduce is None and hasattr(pb, "schur_solve"):
                     # one GPU: the build of S and its factorisation overlap (mm_ba_schur_solve)
                     info, v, Cinv = pb.schur_solve(self._cams(x), self._pts(x), Bd, Cd, gc, gp, half_bw)
+                    if getattr(pb, "overlap", False) and not self._overlap_checked:
+                        # first overlapped solve: make sure the two streams really ran concurrently (a profiler that
+                        # serialises kernels starves the consumer, which then gives up with info = -1)
+                        self._overlap_checked = True
+                        if int(info.item()) < 0:
+                            warnings.warn("mm_ba_schur_solve: kernels are being serialised; building and solving the "
+                                          "reduced system one after the other from here on")
+                            pb.overlap = False
+                            info, v, Cinv = pb.schur_solve(self._cams(x), self._pts(x), Bd, Cd, gc, gp, half_bw)
                 else:
                     S, v, Cinv = pb.schur(self._cams(x), self._pts(x), Bd, Cd, gc, gp)
                 if self.allreduce is not None:

@@ -4,6 +4,7 @@ torch is used for device memory and streams only; every computation below is a H
 `libmeatmodeler_hip.so`.  All functions take/return torch tensors on the context's device.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -227,6 +228,10 @@ class BADevice:
             self.cam_obs = torch.zeros(0, dtype=torch.int32, device=dev)
         self.cam_span = 0
         self.slabs = None
+        # build + solve overlapped on two streams (mm_ba_schur_solve).  Needs concurrent kernel execution: tools that
+        # serialise kernels (rocprofv3 --pmc, launch-blocking debug modes) make the consumer wait for a producer that
+        # cannot start; its bounded spins then give up (info = -1) and the driver falls back to one after the other.
+        self.overlap = os.environ.get("MM_SCHUR_OVERLAP", "1") != "0"
         self.pb = BAProblem(F, P, O, ptr(self.K), ptr(self.fi), ptr(self.pi), ptr(self.obs),
                             ptr(self.pt_ptr), ptr(self.pt_obs), ptr(self.cam_ptr), ptr(self.cam_obs),
                             0, 0, 0, None, None, 0, None, None, None, None, None)
@@ -353,7 +358,7 @@ class BADevice:
         if self._chol_ws is None:
             self._chol_ws = torch.empty(lib.mm_chol_workspace_bytes(n), dtype=torch.uint8, device=self.device)
         hb = int(min(half_bandwidth, n))
-        if self.slabs is not None:
+        if self.slabs is not None and self.overlap:
             ns, cps, sseg, schunk = self.slabs
             a_seg, a_chunk = sseg.ctypes.data_as(_lib.c_i64p), schunk.ctypes.data_as(_lib.c_i64p)
         else:

@@ -415,6 +415,34 @@ def test_schur_solve_overlapped_equals_sequential(F, P, L):
         assert torch.equal(dc, ref) and torch.equal(Cinv, Cinv0)
 
 
+def test_schur_solve_falls_back_when_kernels_are_serialised():
+    """The overlapped build + solve needs two kernels in flight at once.  With kernel launches serialised (here by the
+    runtime's AMD_SERIALIZE_KERNEL debug switch; rocprofv3 --pmc does the same) the consumer's bounded spins give up,
+    the driver notices (info = -1), warns and continues with the two steps one after the other."""
+    import subprocess
+    import sys
+    code = (
+        "import warnings, numpy as np, torch\n"
+        "from meatmodeler_amd import ops, synth\n"
+        "from meatmodeler_amd.bundleAdjuster import SchurTRF, frameParameters\n"
+        "pr = synth.make_ba_problem(130, 2000, 12, seed=3)\n"
+        "dev = torch.device('cuda:0')\n"
+        "pb = ops.BADevice(pr['K'], pr['fi'], pr['pi'], pr['obs'], 130, 2000, dev)\n"
+        "assert pb.slabs is not None and pb.overlap\n"
+        "cams = torch.as_tensor(frameParameters(pr['ext']).reshape(130, 6)).to(dev)\n"
+        "pts = torch.as_tensor(pr['pts0']).to(dev)\n"
+        "with warnings.catch_warnings(record=True) as w:\n"
+        "    warnings.simplefilter('always')\n"
+        "    res = SchurTRF(pb).solve(cams, pts, max_nfev=4)\n"
+        "assert any('serialised' in str(x.message) for x in w), [str(x.message) for x in w]\n"
+        "assert not pb.overlap and np.isfinite(res.cost) and res.nfev == 4\n"
+        "print('fallback ok', res.cost)\n")
+    env = dict(os.environ, AMD_SERIALIZE_KERNEL="3")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=240,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "fallback ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_chol_reports_non_spd():
     A = np.eye(70)
     A[66, 66] = -1.0

@@ -17,6 +17,8 @@ rm -rf $ROOT/gpurun_out/prof
 timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile > $ROOT/gpurun_out/rocprof.log 2>&1
 rc=$?; echo "rocprof rc=$rc"
 find $ROOT/gpurun_out/prof -name "*_kernel_trace.csv" -delete
+# (counter collection serialises kernels: the overlapped build + solve runs one after the other there)
+export MM_SCHUR_OVERLAP=0
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf $ROOT/gpurun_out/pmc_$ctr
   timeout -k 10 900 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $ROOT/gpurun_out/pmc_$ctr -- python3 $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile > $ROOT/gpurun_out/pmc_$ctr.log 2>&1
