@@ -331,7 +331,7 @@ class BADevice:
         (deterministically) and the rest of S is zero; otherwise all of S is filled."""
         n = 6 * self.F
         if self._S is None:
-            self._S = torch.empty((n, n), dtype=torch.float64, device=self.device)
+            self._alloc_S(n)
         S = self._S
         v = torch.empty(n, dtype=torch.float64, device=self.device)
         Cinv = torch.empty((self.P, 6), dtype=torch.float64, device=self.device)
@@ -343,12 +343,24 @@ class BADevice:
                                        self._schur_ws.numel()), "mm_ba_schur")
         return S, v, Cinv
 
+    def _alloc_S(self, n):
+        # n extra (zeroed) rows behind the matrix: band_view's diagonal-major strides run past row n - 1
+        self._S_storage = torch.zeros(2 * n * n, dtype=torch.float64, device=self.device)
+        self._S = self._S_storage[:n * n].view(n, n)
+
+    def band_view(self, half_bandwidth):
+        """The lower band of the reduced camera system as a strided [n, hb + 1] view of its storage: entry [j, k] is
+        S[j + k, j] (rows past n - 1 fall into the zero padding).  What ranks exchange instead of the dense matrix."""
+        n = 6 * self.F
+        hb = int(min(half_bandwidth, n - 1))
+        return torch.as_strided(self._S_storage, (n, hb + 1), (n + 1, n))
+
     def schur_solve(self, cams, pts, Bd, Cd, gc, gp, half_bandwidth):
         """Reduced camera system built and solved in one overlapped call (mm_ba_schur_solve): -> (info, dc [6F], Cinv).
         dc is the solution of S dc = v (the camera part of the damped Gauss-Newton step)."""
         n = 6 * self.F
         if self._S is None:
-            self._S = torch.empty((n, n), dtype=torch.float64, device=self.device)
+            self._alloc_S(n)
         v = torch.empty(n, dtype=torch.float64, device=self.device)
         Cinv = torch.empty((self.P, 6), dtype=torch.float64, device=self.device)
         info = torch.zeros(1, dtype=torch.int32, device=self.device)
