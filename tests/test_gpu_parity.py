@@ -443,6 +443,54 @@ def test_schur_solve_falls_back_when_kernels_are_serialised():
     assert r.returncode == 0 and "fallback ok" in r.stdout, r.stdout + r.stderr
 
 
+@pytest.mark.parametrize("n,k,split", [(1, 1, 0), (1000, 3, 400), (1_234_567, 5, 3000), (300_001, 8, 300_001), (50_000, 11, 7)])
+def test_multi_dot_vs_numpy(n, k, split):
+    """mm_multi_dot: k inner products in one launch, reported as (i < split, i >= split, total); more than 8 pairs are
+    split over several launches by the wrapper; repeated calls reuse the workspace (its counter resets itself)."""
+    rng = np.random.default_rng(n + k)
+    A = rng.normal(size=(k, n))
+    B = rng.normal(size=(k, n))
+    md = ops.MultiDot(DEV)
+    pairs = [(dev(A[i]), dev(B[i])) for i in range(k)]
+    for _ in range(2):
+        out = md(pairs, split).cpu().numpy()
+        want = np.array([[A[i, :split] @ B[i, :split], A[i, split:] @ B[i, split:], A[i] @ B[i]] for i in range(k)])
+        np.testing.assert_allclose(out, want, rtol=1e-11, atol=1e-9)
+    out2 = md(pairs, split).cpu().numpy()
+    assert np.array_equal(out, out2)            # deterministic
+
+
+def test_trf_damping_vs_scipy_formula():
+    """mm_trf_damping == the scalar recipe of SciPy trf.py:473-477 (regulariser from the Cauchy-like model along g_h)."""
+    rng = np.random.default_rng(5)
+    for _ in range(50):
+        gh2, d11 = float(rng.uniform(1e-3, 1e6)), float(rng.uniform(0, 1e8)) * float(rng.integers(0, 2) + rng.integers(0, 2))
+        Delta, floor = float(10 ** rng.uniform(-3, 4)), 1e-9
+        a, b = 0.5 * d11, -gh2
+        to_tr = Delta / np.sqrt(gh2)
+        ts = [0.0, to_tr]
+        if a != 0 and 0.0 < -0.5 * b / a < to_tr:
+            ts.append(-0.5 * b / a)
+        reg = -min(t * (a * t + b) for t in ts) / Delta ** 2
+        out = ops.trf_damping(dev(np.array([gh2])), dev(np.array([d11])), Delta, floor).cpu().numpy()
+        np.testing.assert_allclose(out, [reg, max(reg, floor)], rtol=1e-13, atol=0)
+
+
+def test_band_view_addresses_lower_band():
+    pr = synth.make_ba_problem(12, 80, 4, seed=2)
+    pb = ops.BADevice(pr["K"], pr["fi"], pr["pi"], pr["obs"], 12, 80, DEV)
+    n = 72
+    pb._alloc_S(n)
+    S = torch.arange(n * n, dtype=torch.float64, device=DEV).view(n, n)
+    pb._S.copy_(S)
+    hb = 17
+    band = pb.band_view(hb).cpu().numpy()
+    Sh = S.cpu().numpy()
+    for j in (0, 5, 40, 71):
+        for k in (0, 1, hb):
+            assert band[j, k] == (Sh[j + k, j] if j + k < n else 0.0)
+
+
 def test_chol_reports_non_spd():
     A = np.eye(70)
     A[66, 66] = -1.0
