@@ -116,20 +116,30 @@ __global__ __launch_bounds__(256) void schur_rows_kernel(mm_ba_problem pb, const
 // S is summed in the same order on every run — the trust-region iteration, which is chaotic on outlier-laden matches,
 // then repeats bit for bit.  No atomics; only the LOWER block triangle is produced (S is zero-filled first).
 constexpr int SP_WAVES = 4;
+constexpr int MAX_SLABS = 64;
+// slab bookkeeping of the overlapped build + solve (all null / 0 when nobody consumes S concurrently)
+struct SlabSync {
+    int32_t *ready;   // [n_slabs] flags polled by the consumer
+    int32_t *done;    // [n_slabs] finished-segment counters
+    int32_t seg_count[MAX_SLABS];
+    int cams_per_slab;
+};
 // launch bound 2 waves per SIMD: 256 VGPRs (68 B of scratch) instead of 271 -> twice the waves to hide the f64 latency
 __global__ __launch_bounds__(64 * SP_WAVES, 2) void schur_pairs_kernel(mm_ba_problem pb, const double *__restrict__ cams,
                                                                     const double *__restrict__ pts,
                                                                     const double *__restrict__ Cinv,
                                                                     const double *__restrict__ gp,
-                                                                    double *__restrict__ partial, int64_t chunk_lo,
-                                                                    int64_t chunk_hi) {
+                                                                    double *partial, const double *__restrict__ Bd,
+                                                                    const double *__restrict__ gc, double *S, double *v,
+                                                                    int32_t *seg_done, SlabSync slabs) {
     __shared__ double Ks[9];
     if (threadIdx.x < 9) Ks[threadIdx.x] = pb.K[threadIdx.x];
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int64_t c = chunk_lo + (int64_t)blockIdx.x * SP_WAVES + (threadIdx.x >> 6);
-    if (c >= chunk_hi) return;  // wave-uniform; no workgroup barriers below
-    const int seg = pb.seg_ids[pb.chunk_seg[c]];
+    const int64_t c = (int64_t)blockIdx.x * SP_WAVES + (threadIdx.x >> 6);
+    if (c >= pb.n_chunks) return;  // wave-uniform; no workgroup barriers below
+    const int sidx = pb.chunk_seg[c];
+    const int seg = pb.seg_ids[sidx];
     const int i = seg / (pb.cam_span + 1), d = seg % (pb.cam_span + 1);
     const int f2 = i - d;
     const double *ci_cam = cams + (size_t)i * 6, *c2_cam = cams + (size_t)f2 * 6;
@@ -172,38 +182,63 @@ __global__ __launch_bounds__(64 * SP_WAVES, 2) void schur_pairs_kernel(mm_ba_pro
         }
     }
     wave_sum_n<42>(acc);
-    if (lane == 0) {
-#pragma unroll
-        for (int q = 0; q < 42; ++q) partial[c * 42 + q] = acc[q];
-    }
-}
-
-// Second pass: entry q of segment sidx = sum of its chunks' partials in chunk order (fixed order -> reproducible).
-__global__ __launch_bounds__(256) void schur_pairs_reduce_kernel(mm_ba_problem pb, const double *__restrict__ partial,
-                                                                 const double *__restrict__ Bd,
-                                                                 const double *__restrict__ gc, double *__restrict__ S,
-                                                                 double *__restrict__ v, int64_t seg_lo, int64_t seg_hi) {
-    const int q = threadIdx.x & 63;
-    const int64_t sidx = seg_lo + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (sidx >= seg_hi || q >= 42) return;
-    const int seg = pb.seg_ids[sidx];
-    const int i = seg / (pb.cam_span + 1), d = seg % (pb.cam_span + 1);
-    const int f2 = i - d;
-    if (q >= 36 && d != 0) return;
-    double s = 0.0;
-    for (int c = pb.seg_chunk_ptr[sidx]; c < pb.seg_chunk_ptr[sidx + 1]; ++c) s += partial[(size_t)c * 42 + q];
+    // ---- finish the segment: the wave that completes its last chunk writes the block of S (and the rhs rows) ----
+    // One chunk (the common case: ~160 pairs per segment): straight from the registers.  Several chunks: every wave
+    // leaves its partial sums and counts up; the last one adds the partials IN CHUNK ORDER, so the result does not
+    // depend on which wave that was.  Everything another workgroup (or the concurrently running factorisation) reads
+    // goes through write-through stores / cache-bypassing loads, and a producer drains its stores before it counts.
+    const int c_first = pb.seg_chunk_ptr[sidx], n_ch = pb.seg_chunk_ptr[sidx + 1] - c_first;
     const size_t n = (size_t)pb.F * 6;
-    if (q < 36) {
-        double val = -s;
-        if (d == 0) val += Bd[(size_t)i * 36 + q];
-        S[((size_t)i * 6 + q / 6) * n + (size_t)f2 * 6 + q % 6] = val;
-    } else {
-        v[(size_t)i * 6 + (q - 36)] = gc[(size_t)i * 6 + (q - 36)] - s;
+    bool writer = true;
+    if (n_ch > 1) {
+        if (lane == 0) {
+#pragma unroll
+            for (int q = 0; q < 42; ++q)
+                __hip_atomic_store(partial + (size_t)c * 42 + q, acc[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        int last = 0;
+        if (lane == 0) last = atomicAdd(seg_done + sidx, 1) == n_ch - 1;
+        writer = __shfl(last, 0, 64) != 0;
+    }
+    if (!writer) return;
+    if (n_ch > 1) {
+        double sum = 0.0;
+        if (lane < 42)
+            for (int cc = 0; cc < n_ch; ++cc)
+                sum += __hip_atomic_load(partial + (size_t)(c_first + cc) * 42 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane < 36) {
+            double val = -sum;
+            if (d == 0) val += Bd[(size_t)i * 36 + lane];
+            __hip_atomic_store(S + ((size_t)i * 6 + lane / 6) * n + (size_t)f2 * 6 + lane % 6, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (lane < 42 && d == 0) {
+            __hip_atomic_store(v + (size_t)i * 6 + (lane - 36), gc[(size_t)i * 6 + (lane - 36)] - sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < 36; ++q) {
+            double val = -acc[q];
+            if (d == 0) val += Bd[(size_t)i * 36 + q];
+            __hip_atomic_store(S + ((size_t)i * 6 + q / 6) * n + (size_t)f2 * 6 + q % 6, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (d == 0) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+                __hip_atomic_store(v + (size_t)i * 6 + q, gc[(size_t)i * 6 + q] - acc[36 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (slabs.ready) {  // a concurrent consumer waits for whole camera slabs: count finished segments per slab
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            const int sl = i / slabs.cams_per_slab;
+            if (atomicAdd(slabs.done + sl, 1) == slabs.seg_count[sl] - 1)
+                __hip_atomic_store(slabs.ready + sl, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
-// raised by a one-thread launch queued behind the kernels of a camera slab: everything before it in the stream is done
-// and visible device-wide, so a concurrent consumer on another stream may read the slab's rows
+// marks a camera slab without any segment as complete (its rows only hold what schur_diag_fill wrote)
 __global__ void slab_flag_kernel(int32_t *flags, int s) {
     __hip_atomic_store(flags + s, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -281,12 +316,30 @@ extern "C" int mm_ba_pairs_emit(mm_ctx *ctx, const mm_ba_problem *pb, const int6
     return MM_OK;
 }
 
-constexpr int MAX_SLABS = 64;
-
 extern "C" size_t mm_ba_schur_workspace_bytes(const mm_ba_problem *pb) {
     if (!pb || pb->n_chunks <= 0) return 0;
-    return mm_align_up((size_t)pb->n_chunks * 42 * sizeof(double), 256) + 256 /* slab flags */;
+    return mm_align_up((size_t)pb->n_chunks * 42 * sizeof(double), 256) /* partial sums of multi-chunk segments */ +
+           mm_align_up((size_t)pb->n_seg * sizeof(int32_t), 256) /* finished-chunk counters */ +
+           2 * MAX_SLABS * sizeof(int32_t) /* slab flags, slab counters */;
 }
+
+namespace {
+struct SchurWs {
+    double *partial;
+    int32_t *seg_done, *slab_ready, *slab_done;
+};
+SchurWs carve_schur_ws(const mm_ba_problem *pb, void *ws) {
+    SchurWs w;
+    char *p = (char *)ws;
+    w.partial = (double *)p;
+    p += mm_align_up((size_t)pb->n_chunks * 42 * sizeof(double), 256);
+    w.seg_done = (int32_t *)p;
+    p += mm_align_up((size_t)pb->n_seg * sizeof(int32_t), 256);
+    w.slab_ready = (int32_t *)p;
+    w.slab_done = w.slab_ready + MAX_SLABS;
+    return w;
+}
+}  // namespace
 
 extern "C" int mm_ba_schur(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, const double *pts,
                            const double *Bd, const double *Cd, const double *gc, const double *gp, double *S, double *v,
@@ -307,10 +360,11 @@ extern "C" int mm_ba_schur(mm_ctx *ctx, const mm_ba_problem *pb, const double *c
         MM_HIP(ctx, hipMemsetAsync(S, 0, (size_t)pb->F * 6 * pb->F * 6 * sizeof(double), ctx->stream));
         MM_LAUNCH(ctx, "schur_diag_fill_kernel", schur_diag_fill_kernel, dim3(pb->F), dim3(64), 0, *pb, Bd, gc, S, v);
         const int64_t wgs = (pb->n_chunks + SP_WAVES - 1) / SP_WAVES;
+        const SchurWs w = carve_schur_ws(pb, ws);
+        MM_HIP(ctx, hipMemsetAsync(w.seg_done, 0, (size_t)pb->n_seg * sizeof(int32_t), ctx->stream));
+        SlabSync none = {};
         MM_LAUNCH(ctx, "schur_pairs_kernel", schur_pairs_kernel, dim3((unsigned)wgs), dim3(64 * SP_WAVES), 0, *pb, cams,
-                  pts, Cinv, gp, (double *)ws, (int64_t)0, (int64_t)pb->n_chunks);
-        MM_LAUNCH(ctx, "schur_pairs_reduce_kernel", schur_pairs_reduce_kernel, dim3((unsigned)((pb->n_seg + 3) / 4)),
-                  dim3(256), 0, *pb, (const double *)ws, Bd, gc, S, v, (int64_t)0, (int64_t)pb->n_seg);
+                  pts, (const double *)Cinv, gp, w.partial, Bd, gc, S, v, w.seg_done, none);
         return MM_OK;
     }
     const int nwin = (pb->F + SR_WIN - 1) / SR_WIN;
@@ -353,30 +407,31 @@ extern "C" int mm_ba_schur_solve(mm_ctx *ctx, const mm_ba_problem *pb, const dou
         MM_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
         MM_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     }
-    double *partial = (double *)ws_schur;
-    int32_t *slab_ready = (int32_t *)((char *)ws_schur + mm_align_up((size_t)pb->n_chunks * 42 * sizeof(double), 256));
+    const SchurWs w = carve_schur_ws(pb, ws_schur);
+    SlabSync slabs = {};
+    slabs.ready = w.slab_ready;
+    slabs.done = w.slab_done;
+    slabs.cams_per_slab = cams_per_slab;
+    for (int sl = 0; sl < n_slabs; ++sl) slabs.seg_count[sl] = (int32_t)(slab_seg_ptr[sl + 1] - slab_seg_ptr[sl]);
     MM_LAUNCH(ctx, "point_inverse_kernel", point_inverse_kernel, dim3((pb->P + 255) / 256), dim3(256), 0, pb->P, Cd, Cinv);
     MM_HIP(ctx, hipMemsetAsync(S, 0, (size_t)n * n * sizeof(double), ctx->stream));
-    MM_HIP(ctx, hipMemsetAsync(slab_ready, 0, MAX_SLABS * sizeof(int32_t), ctx->stream));
+    MM_HIP(ctx, hipMemsetAsync(w.seg_done, 0, (size_t)pb->n_seg * sizeof(int32_t), ctx->stream));
+    MM_HIP(ctx, hipMemsetAsync(w.slab_ready, 0, 2 * MAX_SLABS * sizeof(int32_t), ctx->stream));
     MM_LAUNCH(ctx, "schur_diag_fill_kernel", schur_diag_fill_kernel, dim3(pb->F), dim3(64), 0, *pb, Bd, gc, S, v);
+    for (int sl = 0; sl < n_slabs; ++sl)   // a slab without any segment is complete as it is
+        if (slabs.seg_count[sl] == 0) MM_LAUNCH(ctx, "slab_flag_kernel", slab_flag_kernel, dim3(1), dim3(1), 0, w.slab_ready, sl);
     MM_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
     MM_HIP(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
     {   // the consumer goes first, so that its workgroups are resident before the producer floods the CUs
         mm_stream_swap sw(ctx, ctx->aux);
-        int rc = mm_chol_solve_gated(ctx, S, n, v, 1, half_bandwidth, info, ws_chol, ws_chol_bytes, slab_ready, cams_per_slab, pb->F);
+        int rc = mm_chol_solve_gated(ctx, S, n, v, 1, half_bandwidth, info, ws_chol, ws_chol_bytes, w.slab_ready, cams_per_slab, pb->F);
         if (rc) return rc;
         MM_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
     }
-    for (int sl = 0; sl < n_slabs; ++sl) {
-        const int64_t c_lo = slab_chunk_ptr[sl], c_hi = slab_chunk_ptr[sl + 1], s_lo = slab_seg_ptr[sl], s_hi = slab_seg_ptr[sl + 1];
-        if (c_hi > c_lo) {
-            MM_LAUNCH(ctx, "schur_pairs_kernel", schur_pairs_kernel, dim3((unsigned)((c_hi - c_lo + SP_WAVES - 1) / SP_WAVES)),
-                      dim3(64 * SP_WAVES), 0, *pb, cams, pts, (const double *)Cinv, gp, partial, c_lo, c_hi);
-            MM_LAUNCH(ctx, "schur_pairs_reduce_kernel", schur_pairs_reduce_kernel, dim3((unsigned)((s_hi - s_lo + 3) / 4)),
-                      dim3(256), 0, *pb, (const double *)partial, Bd, gc, S, v, s_lo, s_hi);
-        }
-        MM_LAUNCH(ctx, "slab_flag_kernel", slab_flag_kernel, dim3(1), dim3(1), 0, slab_ready, sl);
-    }
+    // ONE launch builds all of S; chunks are ordered by camera, so the slabs complete roughly in ascending order and
+    // the waves that finish a slab's last segment raise its flag (no kernel boundaries inside the build)
+    MM_LAUNCH(ctx, "schur_pairs_kernel", schur_pairs_kernel, dim3((unsigned)((pb->n_chunks + SP_WAVES - 1) / SP_WAVES)),
+              dim3(64 * SP_WAVES), 0, *pb, cams, pts, (const double *)Cinv, gp, w.partial, Bd, gc, S, v, w.seg_done, slabs);
     MM_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     return MM_OK;
 }
