@@ -183,13 +183,43 @@ __global__ __launch_bounds__(256) void orb_fast_kernel(OrbGeom g, const uint8_t 
         *reinterpret_cast<uint32_t *>(&P[r][c4]) = v;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < FS_H * FS_W; e += 256) {
+    // Two passes over the score positions.  Pass 1 is the exact compass pre-test (any 9 contiguous ring pixels contain
+    // at least two of the four compass pixels, so a corner needs two of them brighter than p + t or two darker than
+    // p - t) and compacts the survivors into an LDS list with one LDS atomic per wave; pass 2 runs the full 16-pixel
+    // score on the list with full waves.  (Testing and scoring in one pass, a wave pays for the score as soon as one
+    // of its 64 pixels survives.)
+    __shared__ uint16_t todo[FS_H * FS_W];
+    __shared__ int n_todo;
+    if (threadIdx.x == 0) n_todo = 0;
+    __syncthreads();
+    for (int e0 = 0; e0 < FS_H * FS_W; e0 += 256) {
+        const int e = e0 + threadIdx.x;
+        bool pass = false;
+        if (e < FS_H * FS_W) {
+            const int sr = e / FS_W, sc = e % FS_W;
+            // score position: image (ox-1+sc, oy-1+sr) -> P[r = sr+3][c = sc+6]
+            const int x = ox - 1 + sc, y = oy - 1 + sr;
+            Sc[sr][sc] = 0;
+            if (x < w - 3 && y < h - 3) {
+                const int r = sr + 3, c = sc + 6;
+                const int p = P[r][c], hi = p + fast_t, lo = p - fast_t;
+                const int a0 = P[r + 3][c], a4 = P[r][c + 3], a8 = P[r - 3][c], a12 = P[r][c - 3];
+                const int nb = (a0 > hi) + (a4 > hi) + (a8 > hi) + (a12 > hi);
+                const int nd = (a0 < lo) + (a4 < lo) + (a8 < lo) + (a12 < lo);
+                pass = nb >= 2 || nd >= 2;
+            }
+        }
+        const unsigned long long m = __ballot(pass);
+        int base = 0;
+        if ((threadIdx.x & 63) == 0 && m) base = atomicAdd(&n_todo, __popcll(m));
+        base = __shfl(base, 0, 64);
+        if (pass) todo[base + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1))] = (uint16_t)e;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_todo; i += 256) {
+        const int e = todo[i];
         const int sr = e / FS_W, sc = e % FS_W;
-        // score position: image (ox-1+sc, oy-1+sr) -> P[r = sr+3][c = sc+6]
-        const int x = ox - 1 + sc, y = oy - 1 + sr;
-        int s = 0;
-        if (x < w - 3 && y < h - 3) s = fast_score(P, sr + 3, sc + 6, fast_t);
-        Sc[sr][sc] = (uint8_t)s;
+        Sc[sr][sc] = (uint8_t)fast_score(P, sr + 3, sc + 6, fast_t);
     }
     __syncthreads();
     // Survivors of the strict 3x3 NMS are collected in LDS first (at most 1 in 4 pixels can survive), so the tile costs
