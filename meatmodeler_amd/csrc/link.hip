@@ -95,7 +95,25 @@ __device__ __forceinline__ int block_exscan(const int (&flag)[LK_IPT], int (&ran
 __global__ __launch_bounds__(LK_THREADS) void link_kernel(int F, int cap, const int32_t *__restrict__ kp_count,
                                                           const int32_t *__restrict__ match_count,
                                                           const int32_t *__restrict__ matches, LinkWs ws,
-                                                          int32_t *__restrict__ track_ptr, int64_t *__restrict__ counts) {
+                                                          int32_t *__restrict__ track_ptr, int64_t *__restrict__ counts,
+                                                          int state_in_lds) {
+    // The per-pair state (first-owner table, last-match table, hit positions, the two live lists: 9 arrays of `cap`
+    // words) lives in LDS when it fits (cap <= 4096: 144 KB of the CU's 160 KB) -- every phase of a pair is a dependent
+    // round trip to these arrays, ~2 us each through global memory, a few hundred ns through LDS.
+    extern __shared__ int32_t lds_state[];
+    int32_t *owner = ws.owner, *lastm = ws.lastm, *hitpos = ws.hitpos;
+    int32_t *live_track[2] = {ws.live_track[0], ws.live_track[1]}, *live_kp[2] = {ws.live_kp[0], ws.live_kp[1]},
+            *live_node[2] = {ws.live_node[0], ws.live_node[1]};
+    if (state_in_lds) {
+        owner = lds_state;
+        lastm = lds_state + cap;
+        hitpos = lds_state + 2 * cap;
+        for (int b = 0; b < 2; ++b) {
+            live_track[b] = lds_state + (3 + 3 * b) * cap;
+            live_kp[b] = lds_state + (4 + 3 * b) * cap;
+            live_node[b] = lds_state + (5 + 3 * b) * cap;
+        }
+    }
     __shared__ int s_wave[17];
     __shared__ int s_T, s_ntracks, s_popbase, s_nodebase, s_bad;
     const int tid = threadIdx.x;
@@ -115,12 +133,12 @@ __global__ __launch_bounds__(LK_THREADS) void link_kernel(int F, int cap, const 
         const int32_t *mk = matches + (size_t)k * cap * 2;
         const int32_t *ck = ws.canon + (size_t)k * cap;
         for (int i = tid; i < cap; i += LK_THREADS) {
-            ws.owner[i] = INT_MAX;
-            ws.lastm[i] = -1;
+            owner[i] = INT_MAX;
+            lastm[i] = -1;
         }
         __syncthreads();
         // A: first live position per canonical key point of frame k
-        for (int pos = tid; pos < T; pos += LK_THREADS) atomicMin(&ws.owner[ck[ws.live_kp[cur][pos]]], pos);
+        for (int pos = tid; pos < T; pos += LK_THREADS) atomicMin(&owner[ck[live_kp[cur][pos]]], pos);
         __syncthreads();
         // B: each match finds its track (or none); the last match on a track wins
         for (int m = tid; m < M; m += LK_THREADS) {
@@ -130,13 +148,13 @@ __global__ __launch_bounds__(LK_THREADS) void link_kernel(int F, int cap, const 
                 s_bad = 1;  // malformed match: ignored (and reported)
                 pos = -2;
             } else {
-                const int o = ld_agent(&ws.owner[ck[q]]);
+                const int o = ld_agent(&owner[ck[q]]);
                 if (o != INT_MAX) {
                     pos = o;
-                    atomicMax(&ws.lastm[o], m);
+                    atomicMax(&lastm[o], m);
                 }
             }
-            ws.hitpos[m] = pos;
+            hitpos[m] = pos;
         }
         __syncthreads();
         // C: ranks of survivors / popped tracks (over live positions) and of new tracks (over matches)
@@ -145,12 +163,12 @@ __global__ __launch_bounds__(LK_THREADS) void link_kernel(int F, int cap, const 
         for (int q = 0; q < LK_IPT; ++q) {
             const int i = tid * LK_IPT + q;
             const bool live = i < T;
-            const int lm = live ? ld_agent(&ws.lastm[i]) : -1;
+            const int lm = live ? ld_agent(&lastm[i]) : -1;
             const bool upd = lm >= 0;
             l_last[q] = lm;
             f_surv[q] = upd;
             f_pop[q] = live && !upd;
-            f_new[q] = (i < M) && ws.hitpos[i] == -1;
+            f_new[q] = (i < M) && hitpos[i] == -1;
         }
         const int n_surv = block_exscan(f_surv, r_surv, s_wave);
         const int n_pop = block_exscan(f_pop, r_pop, s_wave);
@@ -161,20 +179,20 @@ __global__ __launch_bounds__(LK_THREADS) void link_kernel(int F, int cap, const 
         for (int q = 0; q < LK_IPT; ++q) {
             const int i = tid * LK_IPT + q;
             if (f_surv[q]) {
-                const int tr = ws.live_track[cur][i];
+                const int tr = live_track[cur][i];
                 const int t = mk[2 * l_last[q] + 1];
                 const int nid = node_base + r_surv[q];
                 ws.node_kp[nid] = t;
                 ws.node_frame[nid] = k + 1;
-                ws.node_prev[nid] = ws.live_node[cur][i];
-                ws.live_track[nxt][r_surv[q]] = tr;
-                ws.live_kp[nxt][r_surv[q]] = t;
-                ws.live_node[nxt][r_surv[q]] = nid;
+                ws.node_prev[nid] = live_node[cur][i];
+                live_track[nxt][r_surv[q]] = tr;
+                live_kp[nxt][r_surv[q]] = t;
+                live_node[nxt][r_surv[q]] = nid;
                 ws.track_len[tr] += 1;
             } else if (f_pop[q]) {
-                const int tr = ws.live_track[cur][i];
+                const int tr = live_track[cur][i];
                 ws.final_order[pop_base + r_pop[q]] = tr;
-                ws.track_tail[tr] = ws.live_node[cur][i];
+                ws.track_tail[tr] = live_node[cur][i];
             }
             if (f_new[q]) {
                 const int tr = n_tracks + r_new[q];
@@ -186,9 +204,9 @@ __global__ __launch_bounds__(LK_THREADS) void link_kernel(int F, int cap, const 
                 ws.node_frame[nid + 1] = k + 1;
                 ws.node_prev[nid + 1] = nid;
                 const int p = n_surv + r_new[q];
-                ws.live_track[nxt][p] = tr;
-                ws.live_kp[nxt][p] = mk[2 * i + 1];
-                ws.live_node[nxt][p] = nid + 1;
+                live_track[nxt][p] = tr;
+                live_kp[nxt][p] = mk[2 * i + 1];
+                live_node[nxt][p] = nid + 1;
                 ws.track_len[tr] = 2;
             }
         }
@@ -205,9 +223,9 @@ __global__ __launch_bounds__(LK_THREADS) void link_kernel(int F, int cap, const 
     // the tracks still alive come last (processor.py:418)
     const int T = s_T, n_tracks = s_ntracks, pop_base = s_popbase;
     for (int pos = tid; pos < T; pos += LK_THREADS) {
-        const int tr = ws.live_track[cur][pos];
+        const int tr = live_track[cur][pos];
         ws.final_order[pop_base + pos] = tr;
-        ws.track_tail[tr] = ws.live_node[cur][pos];
+        ws.track_tail[tr] = live_node[cur][pos];
     }
     __syncthreads();
     // CSR offsets in final order: chunked block scan with a running base
@@ -306,8 +324,18 @@ int mm_link_tracks_device(mm_ctx *ctx, int n_frames, int cap, const int32_t *kp_
     if (ws_bytes < carve(w, (uint8_t *)ws, n_frames, cap)) return mm_fail(ctx, MM_ERR_WORKSPACE, "mm_link_tracks_device: workspace too small");
     MM_LAUNCH(ctx, "link_canon_kernel", link_canon_kernel, dim3((cap + 255) / 256, n_frames), dim3(256), 0, cap, kp_count,
               kp_xy, w.canon);
-    MM_LAUNCH(ctx, "link_kernel", link_kernel, dim3(1), dim3(LK_THREADS), 0, n_frames, cap, kp_count, match_count, matches, w,
-              track_ptr, counts);
+    const int state_in_lds = cap <= 4096;
+    const size_t lds_bytes = state_in_lds ? (size_t)9 * cap * sizeof(int32_t) : 0;
+    if (lds_bytes > 48 * 1024) {
+        static size_t lds_set = 0;
+        if (lds_bytes > lds_set) {
+            MM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(link_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)lds_bytes));
+            lds_set = lds_bytes;
+        }
+    }
+    MM_LAUNCH(ctx, "link_kernel", link_kernel, dim3(1), dim3(LK_THREADS), lds_bytes, n_frames, cap, kp_count, match_count,
+              matches, w, track_ptr, counts, state_in_lds);
     const size_t max_tracks = (size_t)(n_frames - 1) * cap;
     MM_LAUNCH(ctx, "link_emit_kernel", link_emit_kernel, dim3((unsigned)((max_tracks + 255) / 256)), dim3(256), 0, w,
               (const int32_t *)track_ptr, (const int64_t *)counts, obs_frame, obs_kp);
