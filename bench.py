@@ -255,7 +255,9 @@ def main():
             traffic = (pmc["FETCH_SIZE_KB_per_launch"] + pmc["WRITE_SIZE_KB_per_launch"]) * 1024.0
         if dom["kernel"] == "chol_band_fused_kernel":
             note = ("single-launch banded Cholesky: a chain of %d dependent 64-column steps (factor 64x64 -> solve -> "
-                    "update), bound by the latency of that chain, not by MFMA throughput" % ((6 * F + 63) // 64))
+                    "update), bound by the latency of that chain, not by MFMA throughput; on one GPU it runs concurrently "
+                    "with the build of the matrix (schur_pairs_kernel, other stream) and its duration includes waiting for "
+                    "finished row slabs -- alone it takes 0.84 ms (tools/bench_chol.py)" % ((6 * F + 63) // 64))
         else:
             note = None
         if "mfma_f64_TFLOPs" in dom:

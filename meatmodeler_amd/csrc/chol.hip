@@ -279,7 +279,14 @@ __device__ __forceinline__ void inv_offdiag16(const double (*M)[NB + 1], double 
 
 // L (in place, lower triangle of M), the reciprocal pivots R and the four 16 x 16 diagonal blocks of X = L^-1 (the
 // rest of X zeroed); 256 threads.  The diagonal inverses ride on an idle wave while wave 0 factors the next panel.
-__device__ __forceinline__ void factor_block_lds(double (*M)[NB + 1], double (*X)[NB + 1], double *R, int k0, int &bad) {
+struct NoStageA {
+    __device__ void operator()() const {}
+};
+// stage_a() is called by wave 2 while wave 0 factors the last panel: at that point every 16 x 16 block of L below the
+// diagonal blocks and the inverses X_00, X_11 are final (the fused kernel publishes them early)
+template <class StageA = NoStageA>
+__device__ __forceinline__ void factor_block_lds(double (*M)[NB + 1], double (*X)[NB + 1], double *R, int k0, int &bad,
+                                                 StageA stage_a = StageA()) {
     const int w = threadIdx.x >> 6;
     if (w == 0) {
         panel16_factor<0>(M, R);
@@ -298,6 +305,7 @@ __device__ __forceinline__ void factor_block_lds(double (*M)[NB + 1], double (*X
     panel16_update<3>(M);
     if (w == 0) panel16_factor<3>(M, R);
     if (w == 1) inv_diag16(M, X, R, 2);
+    if (w == 2) stage_a();
     __syncthreads();
     if (w == 0) inv_diag16(M, X, R, 3);
     if (w == 1) bad = block_first_bad(M, k0);
@@ -583,64 +591,93 @@ __device__ __forceinline__ double tile_matvec(const double (*Tm)[LD], const doub
 }
 
 // finish an off-diagonal block: solve P L_cc^T = A0 - acc, written to `tile` (global) and left in As.  The producer
-// publishes L_cc and the four 16 x 16 diagonal blocks X_jj of its inverse as soon as they exist (the rest of L_cc^-1
-// is off the critical path), so the solve runs by 16-column blocks: P_j = (V_j - sum_{k<j} P_k L_jk^T) X_jj^T,
-// wave w on rows 16w..16w+15 (40 MFMA per wave, wave-local LDS traffic only).
+// publishes L_cc in two stages: (A) while it still factors its last panel, the 16 x 16 blocks below the diagonal blocks
+// and the inverses X_00, X_11; (B) X_22, X_33.  The solve runs by 16-column blocks,
+//   P_j = (V_j - sum_{k<j} P_k L_jk^T) X_jj^T,   wave w on rows 16w..16w+15 (40 MFMA per wave, wave-local LDS traffic),
+// and everything that does not need X_22 / X_33 happens after (A): only 12 MFMA and a 4 KB load follow (B).
 template <int MODE>
-__device__ __forceinline__ void finish_off_block(double (*As)[LDT], double (*Bs)[LDT], double (*Xd)[16][17],
-                                                 const double4_t (&a0)[2][2], const double4_t (&acc)[2][2],
-                                                 const double *Lcc /*diag tile of A*/, const double *Linv_c,
-                                                 double *tile, int n, int rows) {
-    MM_ACC_FOREACH(As[row][col] = a0[a][b][i] - acc[a][b][i];)
-    load_tile_shared<MODE>(Bs, Lcc, n, NB);
-    {
-        double v[4];
+__device__ __forceinline__ void load_xdiag(double (*Xd)[16][17], const double *Linv_c, int blk0) {
+    double v[2];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = threadIdx.x + 256 * q, blk = e >> 8, rr = (e >> 4) & 15, cc = e & 15;
-            v[q] = ld_shared<MODE>(Linv_c + (size_t)(16 * blk + rr) * NB + 16 * blk + cc);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = threadIdx.x + 256 * q;
-            Xd[e >> 8][(e >> 4) & 15][e & 15] = v[q];
-        }
+    for (int q = 0; q < 2; ++q) {
+        const int e = threadIdx.x + 256 * q, blk = blk0 + (e >> 8), rr = (e >> 4) & 15, cc = e & 15;
+        v[q] = ld_shared<MODE>(Linv_c + (size_t)(16 * blk + rr) * NB + 16 * blk + cc);
     }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, row0 = 16 * (threadIdx.x >> 6);
-    const int lr = lane & 15, lk = lane >> 4;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int q = 0; q < 2; ++q) {
+        const int e = threadIdx.x + 256 * q;
+        Xd[blk0 + (e >> 8)][(e >> 4) & 15][e & 15] = v[q];
+    }
+}
+
+// s = sum_{k in [K0, K1)} P_k L_jk^T for this wave's 16 rows, subtracted from block j of As
+template <int J, int K0, int K1>
+__device__ __forceinline__ void trsm_update(double (*As)[LDT], const double (*Bs)[LDT], int row0, int lr, int lk) {
+    if constexpr (K1 > K0) {
         double4_t s = {0, 0, 0, 0};
 #pragma unroll
-        for (int k = 0; k < j; ++k)
+        for (int k = K0; k < K1; ++k)
 #pragma unroll
             for (int ss = 0; ss < 4; ++ss) {
                 const double av = As[row0 + lr][16 * k + 4 * ss + lk];   // P_k
-                const double bv = Bs[16 * j + lr][16 * k + 4 * ss + lk];  // L_jk
+                const double bv = Bs[16 * J + lr][16 * k + 4 * ss + lk];  // L_jk
                 s = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, s, 0, 0, 0);
             }
-        if (j > 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) As[row0 + lk + 4 * i][16 * j + lr] -= s[i];
-            wave_lds_sync();
-        }
-        double4_t pj = {0, 0, 0, 0};
-#pragma unroll
-        for (int ss = 0; ss < 4; ++ss) {
-            const double av = As[row0 + lr][16 * j + 4 * ss + lk];  // W = V_j - sum
-            const double bv = Xd[j][lr][4 * ss + lk];               // X_jj^T
-            pj = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, pj, 0, 0, 0);
-        }
-        wave_lds_sync();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = row0 + lk + 4 * i, col = 16 * j + lr;
-            As[row][col] = pj[i];
-            if (row < rows) st_shared<MODE>(tile + (size_t)row * n + col, pj[i]);
-        }
+        for (int i = 0; i < 4; ++i) As[row0 + lk + 4 * i][16 * J + lr] -= s[i];
         wave_lds_sync();
     }
+}
+
+// P_j = W_j X_jj^T: block j of As in place, and to global memory
+template <int MODE, int J>
+__device__ __forceinline__ void trsm_finish(double (*As)[LDT], const double (*Xd)[16][17], double *tile, int n, int rows,
+                                            int row0, int lr, int lk) {
+    double4_t pj = {0, 0, 0, 0};
+#pragma unroll
+    for (int ss = 0; ss < 4; ++ss) {
+        const double av = As[row0 + lr][16 * J + 4 * ss + lk];  // W = V_j - sum
+        const double bv = Xd[J][lr][4 * ss + lk];               // X_jj^T
+        pj = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, pj, 0, 0, 0);
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = row0 + lk + 4 * i, col = 16 * J + lr;
+        As[row][col] = pj[i];
+        if (row < rows) st_shared<MODE>(tile + (size_t)row * n + col, pj[i]);
+    }
+    wave_lds_sync();
+}
+
+template <int MODE>
+__device__ __forceinline__ void finish_off_block_a(double (*As)[LDT], double (*Bs)[LDT], double (*Xd)[16][17],
+                                                   const double4_t (&a0)[2][2], const double4_t (&acc)[2][2],
+                                                   const double *Lcc /*diag tile of A*/, const double *Linv_c,
+                                                   double *tile, int n, int rows) {
+    MM_ACC_FOREACH(As[row][col] = a0[a][b][i] - acc[a][b][i];)
+    load_tile_shared<MODE>(Bs, Lcc, n, NB);
+    load_xdiag<MODE>(Xd, Linv_c, 0);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, row0 = 16 * (threadIdx.x >> 6);
+    const int lr = lane & 15, lk = lane >> 4;
+    trsm_finish<MODE, 0>(As, Xd, tile, n, rows, row0, lr, lk);
+    trsm_update<1, 0, 1>(As, Bs, row0, lr, lk);
+    trsm_finish<MODE, 1>(As, Xd, tile, n, rows, row0, lr, lk);
+    trsm_update<2, 0, 2>(As, Bs, row0, lr, lk);
+    trsm_update<3, 0, 2>(As, Bs, row0, lr, lk);
+}
+
+template <int MODE>
+__device__ __forceinline__ void finish_off_block_b(double (*As)[LDT], double (*Bs)[LDT], double (*Xd)[16][17],
+                                                   const double *Linv_c, double *tile, int n, int rows) {
+    load_xdiag<MODE>(Xd, Linv_c, 2);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, row0 = 16 * (threadIdx.x >> 6);
+    const int lr = lane & 15, lk = lane >> 4;
+    trsm_finish<MODE, 2>(As, Xd, tile, n, rows, row0, lr, lk);
+    trsm_update<3, 2, 3>(As, Bs, row0, lr, lk);
+    trsm_finish<MODE, 3>(As, Xd, tile, n, rows, row0, lr, lk);
 }
 
 #define MM_FUSED_ABANDON                       \
@@ -676,6 +713,7 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, int n, 
     auto flag = [&](int r, int d) { return flags + (size_t)r * W + d; };
     auto yflag = [&](int r) { return flags + (size_t)nblk * W + 1 + r; };
     auto cflag = [&](int r, int d) { return flags + (size_t)nblk * W + 1 + nblk + (size_t)r * W + d; };
+    auto aflag = [&](int r) { return flags + 2 * (size_t)nblk * W + 1 + nblk + r; };   // stage (A) of diagonal block r
     // Rows of A (and of the right-hand side) may still be under construction by a concurrent launch on another
     // stream (the reduced camera system, built in camera slabs): block row r covers the cameras 64r/6 .. (64r+63)/6,
     // i.e. at most two slabs, whose flags are raised by stream-ordered one-thread kernels after each slab.
@@ -714,9 +752,11 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, int n, 
             // when the matrix is still being produced by a concurrent launch, this owner needs row r only now
             if (!rows_ready(r)) MM_FUSED_ABANDON;
             MM_ACC_FOREACH(a0[a][b][i] = row < rows ? ld_shared<MODE>(tile + (size_t)row * n + col) : 0.0;)
+            if (!wg_wait<MODE>(aflag(c), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
+            finish_off_block_a<MODE>(As, Bs, T, a0, acc, A + (size_t)c * NB * n + (size_t)c * NB, Linv + (size_t)c * NB * NB,
+                                     tile, n, rows);
             if (!wg_wait<MODE>(flag(c, 0), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
-            finish_off_block<MODE>(As, Bs, T, a0, acc, A + (size_t)c * NB * n + (size_t)c * NB, Linv + (size_t)c * NB * NB, tile,
-                                   n, rows);
+            finish_off_block_b<MODE>(As, Bs, T, Linv + (size_t)c * NB * NB, tile, n, rows);
             wg_publish<MODE>(flag(r, d));
             if (b_fwd) {  // L_rc y_c for the forward substitution (the block is still in As)
                 if (!wg_wait<MODE>(yflag(c), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
@@ -749,9 +789,11 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, int n, 
         MM_ACC_FOREACH(a0[a][b][i] = (row < nb && col < nb && col <= row) ? ld_shared<MODE>(dtile + (size_t)row * n + col) : 0.0;)
         if (has_sub) MM_ACC_FOREACH(a1[a][b][i] = row < nb ? ld_shared<MODE>(stile + (size_t)row * n + col) : 0.0;)
         if (has_sub) {
+            if (!wg_wait<MODE>(aflag(r - 1), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
+            finish_off_block_a<MODE>(As, Bs, T, a1, acc1, dtile - (size_t)NB * n - NB, Linv + (size_t)(r - 1) * NB * NB, stile,
+                                     n, nb);
             if (!wg_wait<MODE>(flag(r - 1, 0), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
-            finish_off_block<MODE>(As, Bs, T, a1, acc1, dtile - (size_t)NB * n - NB, Linv + (size_t)(r - 1) * NB * NB, stile, n,
-                                   nb);
+            finish_off_block_b<MODE>(As, Bs, T, Linv + (size_t)(r - 1) * NB * NB, stile, n, nb);
             wg_publish<MODE>(flag(r, 1));  // (its barrier also orders the LDS copy of the block)
             tile_gemm_nt(As, As, acc);
         }
@@ -760,22 +802,36 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, int n, 
                                                                           : ((row >= nb && row == col) ? 1.0 : 0.0);)
         __syncthreads();
         int bad = 0;
-        factor_block_lds(M, X, R, r * NB, bad);
-        if (bad && threadIdx.x == 64) report_bad(info, bad);
-        // what the blocks below need first: L_rr (into A) and the diagonal 16 x 16 blocks of its inverse
-        {   // the 16 x 16 blocks below the diagonal of L_rr and the diagonal blocks of the inverse
-            double *Lr = Linv + (size_t)r * NB * NB;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int e = threadIdx.x + 256 * q, blk = e >> 8, rr = 16 * blk + ((e >> 4) & 15), cc = 16 * blk + (e & 15);
-                st_shared<MODE>(Lr + rr * NB + cc, X[rr][cc]);
-            }
+        double *Lr = Linv + (size_t)r * NB * NB;
+        // stage (A), by wave 2 during the last panel: the six 16 x 16 blocks of L_rr below its diagonal blocks and the
+        // inverses X_00, X_11 -- what the blocks below need for all but the last 12 MFMA of their solve
+        auto stage_a = [&]() {
+            const int lane = threadIdx.x & 63;
 #pragma unroll
             for (int q = 0; q < 6; ++q) {
                 constexpr int BI[6] = {1, 2, 2, 3, 3, 3}, BJ[6] = {0, 0, 1, 0, 1, 2};
-                const int rr = 16 * BI[q] + (threadIdx.x >> 4), cc = 16 * BJ[q] + (threadIdx.x & 15);
-                if (rr < nb) st_shared<MODE>(dtile + (size_t)rr * n + cc, M[rr][cc]);
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const int rr = 16 * BI[q] + 4 * h + (lane >> 4), cc = 16 * BJ[q] + (lane & 15);
+                    if (rr < nb) st_shared<MODE>(dtile + (size_t)rr * n + cc, M[rr][cc]);
+                }
             }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int e = lane + 64 * q, blk = e >> 8, rr = 16 * blk + ((e >> 4) & 15), cc = 16 * blk + (e & 15);
+                st_shared<MODE>(Lr + rr * NB + cc, X[rr][cc]);
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) __hip_atomic_store(aflag(r), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        factor_block_lds(M, X, R, r * NB, bad, stage_a);
+        if (bad && threadIdx.x == 64) report_bad(info, bad);
+        // stage (B): the inverses X_22, X_33
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = 512 + threadIdx.x + 256 * q, blk = e >> 8, rr = 16 * blk + ((e >> 4) & 15), cc = 16 * blk + (e & 15);
+            st_shared<MODE>(Lr + rr * NB + cc, X[rr][cc]);
         }
         wg_publish<MODE>(flag(r, 0));
         for (int q = 0; q < 4; ++q) {  // diagonal 16 x 16 blocks of L_rr: only the later kernels read them
@@ -1044,7 +1100,7 @@ extern "C" {
 size_t mm_chol_workspace_bytes(int n) {
     size_t nblk = (size_t)(n + NB - 1) / NB;
     return mm_align_up(nblk * NB * NB * sizeof(double), 256) + mm_align_up((size_t)(n + NB) * sizeof(double), 256) +
-           mm_align_up((2 * nblk * (FUSED_MAX_BWB + 1) + nblk + 64) * sizeof(int32_t), 256) +
+           mm_align_up((2 * nblk * (FUSED_MAX_BWB + 1) + 2 * nblk + 64) * sizeof(int32_t), 256) +
            mm_align_up(nblk * (FUSED_MAX_BWB + 1) * NB * sizeof(double), 256);
 }
 
@@ -1100,8 +1156,8 @@ int mm_chol_solve_gated(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int 
             attr_set = true;
         }
         int32_t *flags = (int32_t *)((char *)ytmp + mm_align_up((size_t)(n + NB) * sizeof(double), 256));
-        const size_t nflags = 2 * (size_t)nblk * (bwb + 1) + nblk + 1;
-        double *contrib = (double *)((char *)flags + mm_align_up((2 * (size_t)nblk * (FUSED_MAX_BWB + 1) + nblk + 64) * sizeof(int32_t), 256));
+        const size_t nflags = 2 * (size_t)nblk * (bwb + 1) + 2 * nblk + 1;
+        double *contrib = (double *)((char *)flags + mm_align_up((2 * (size_t)nblk * (FUSED_MAX_BWB + 1) + 2 * nblk + 64) * sizeof(int32_t), 256));
         const double *b_fwd = nrhs >= 1 ? b : nullptr;  // the first right-hand side rides along
         MM_HIP(ctx, hipMemsetAsync(flags, 0, nflags * sizeof(int32_t), ctx->stream));
         const int grid = (bwb + 1) + bwb * (bwb - 1) / 2;
@@ -1144,7 +1200,7 @@ int mm_chol_solve_gated(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int 
                 bwd_attr_set = true;
             }
             int32_t *flags = (int32_t *)((char *)ytmp + mm_align_up((size_t)(n + NB) * sizeof(double), 256));
-            double *contrib = (double *)((char *)flags + mm_align_up((2 * (size_t)nblk * (FUSED_MAX_BWB + 1) + nblk + 64) * sizeof(int32_t), 256));
+            double *contrib = (double *)((char *)flags + mm_align_up((2 * (size_t)nblk * (FUSED_MAX_BWB + 1) + 2 * nblk + 64) * sizeof(int32_t), 256));
             // x (the output) and the contribution buffer start as the NaN sentinel the kernel polls on
             MM_HIP(ctx, hipMemsetAsync(flags, 0, sizeof(int32_t), ctx->stream));
             MM_HIP(ctx, hipMemsetAsync(bc, 0xFF, (size_t)n * sizeof(double), ctx->stream));
