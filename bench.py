@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--arc", type=float, default=None, help="orbit arc in degrees (default 0.72 deg/frame)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ba", action="store_true")
+    ap.add_argument("--ba-window", type=int, default=0,
+                    help="sliding-window BA instead of the global one (SURVEY 8(f)-2): keyframes per window (1 GPU only)")
+    ap.add_argument("--ba-stride", type=int, default=0, help="keyframes between windows (default: window / 2)")
     ap.add_argument("--verbose", type=int, default=0)
     ap.add_argument("--no-profile", action="store_true", help="no per-launch HIP events in the timed steps")
     return ap.parse_args()
@@ -151,6 +154,11 @@ def main():
     d = dist if use_dist else None
 
     def step(timers=None):
+        if a.ba_window > 0 and not use_dist:
+            o = pipe.run(frames, K, ext, ba=False, dist=None, timers=timers)
+            o["windows"] = pipe.adjust_windows(o, K, ext, window=a.ba_window, stride=a.ba_stride or max(1, a.ba_window // 2),
+                                               ftol=1e-4, timers=timers)["windows"]
+            return o
         return pipe.run(frames, K, ext, ba=not a.no_ba, ftol=1e-4, verbose=a.verbose, dist=d, timers=timers)
 
     for _ in range(a.warmup):
@@ -179,7 +187,7 @@ def main():
         step()
         prof_full = ctx.profile_report()
         ctx.profile(0)
-    STAGES = ("detect", "match", "link", "triangulate", "ba", "ba_solve")
+    STAGES = ("detect", "match", "link", "triangulate", "ba", "ba_solve", "ba_windows")
     el = torch.tensor([elapsed] + [timers.get(k, 0.0) for k in STAGES],
                       dtype=torch.float64, device=dev)
     if use_dist:
@@ -306,6 +314,12 @@ def main():
                         "ba_nfev": nfev, "ba_status": res.status if res is not None else None,
                         "ba_cost": res.cost if res is not None else None, "cam_span": out.get("cam_span"),
                         "schur_pairs": out.get("n_pairs"), "render_s": t_render},
+            "sliding_window_ba": None if "windows" not in out else {
+                "window": a.ba_window, "stride": a.ba_stride or max(1, a.ba_window // 2), "windows": len(out["windows"]),
+                "ms": stage_ms["ba_windows"], "nfev_total": int(sum(w["nfev"] for w in out["windows"])),
+                "observations_total": int(sum(w["observations"] for w in out["windows"])),
+                "residual_evals_per_s": sum(w["observations"] * w["nfev"] for w in out["windows"]) /
+                                        max(stage_ms["ba_windows"] * 1e-3, 1e-9)},
             "roofline": roofline,
             "bf_knn2": bf,
             "kernels": kernels[:12],

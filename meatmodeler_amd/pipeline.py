@@ -120,6 +120,69 @@ class ClipPipeline:
         coords = kp_xy_host[obs_frame, obs_kp].astype(np.float64)
         return coords, obs_frame.astype(np.int32), pi
 
+    # ------------------------------------------------------------------------------------------- sliding-window BA
+    @staticmethod
+    def window_selection(first_frame, last_frame, lo, hi, n_frames):
+        """Tracks adjusted by the window of keyframes [lo, hi): every observation inside the window, and the track is
+        finished ("popped", processor.py:233-238) by keyframe hi - 1 -- its last observation is at or before hi - 2 --
+        or the clip ends with this window.  Works on numpy arrays and on tensors alike."""
+        inside = (first_frame >= lo) & (last_frame < hi)
+        if hi >= n_frames:
+            return inside
+        return inside & (last_frame <= hi - 2)
+
+    def adjust_windows(self, out, K, extrinsics, window=50, stride=25, ftol=1e-4, verbose=0, timers=None):
+        """Incremental bundle adjustment over a sliding window of keyframes: the reference keeps this step as a
+        commented hook (processor.py:395-408: after a keyframe whose tracks were popped, `managePoints(popped_tracks)`
+        + `adjustPoints` over everything so far); bounding it to the last `window` keyframes is what makes the
+        2000-frame clips tractable.  For hi = window, window + stride, ..., F the cameras
+        lo = hi - window .. hi - 1 and the finished tracks that live entirely inside the window are adjusted with
+        exactly the solver of `adjustPoints` (all window cameras and points free, ftol as given); camera parameters and
+        points are written back and later windows start from them.
+
+        `out` is the result of `run(..., ba=False)`.  -> dict(cams [F,6] device, points [T,3] device, windows=[...])."""
+        d = self.device
+        F = int(np.asarray(extrinsics).shape[0])
+        tp, of_, ok = out["track_ptr_dev"], out["obs_frame_dev"], out["obs_kp_dev"]
+        xy = out["xy_dev"]
+        T = tp.shape[0] - 1
+        with np.errstate(all="ignore"):
+            cams = torch.as_tensor(frameParameters(np.asarray(extrinsics, float)[:, :3, :]).reshape(F, 6)).to(d)
+        pts = out["points0"].clone()
+        stats = []
+        if T == 0:
+            return dict(cams=cams, points=pts, windows=stats)
+        tp64 = tp.long()
+        first_f, last_f = of_[tp64[:-1]], of_[tp64[1:] - 1]
+        lens_all = tp64[1:] - tp64[:-1]
+        window = max(2, min(int(window), F))
+        his = list(range(window, F, max(1, int(stride)))) + [F]
+        t0 = time.perf_counter()
+        for hi in his:
+            lo = max(0, hi - window)
+            sel = torch.nonzero(self.window_selection(first_f, last_f, lo, hi, F)).reshape(-1)
+            P = int(sel.numel())
+            if P == 0:
+                continue
+            lens = lens_all[sel]
+            O = int(lens.sum().item())
+            # observation indices of the selected tracks, point-major (managePoints order)
+            starts = tp64[sel]
+            offs = torch.cumsum(lens, 0) - lens
+            oi = torch.repeat_interleave(starts - offs, lens, output_size=O) + torch.arange(O, device=d)
+            fi = (of_[oi] - lo).to(torch.int32)
+            pi = torch.repeat_interleave(torch.arange(P, dtype=torch.int32, device=d), lens, output_size=O)
+            coords = xy[of_[oi].long(), ok[oi].long()].to(torch.float64)
+            pb = ops.BADevice(K, fi, pi, coords, hi - lo, P, d, self.ctx)
+            res = SchurTRF(pb).solve(cams[lo:hi].contiguous(), pts[sel].contiguous(), ftol=ftol, verbose=verbose)
+            cams[lo:hi] = res.cams
+            pts[sel] = res.pts
+            stats.append(dict(lo=lo, hi=hi, points=P, observations=O, nfev=res.nfev, cost=res.cost, status=res.status))
+        self.ctx.sync()
+        if timers is not None:
+            timers["ba_windows"] = timers.get("ba_windows", 0.0) + (time.perf_counter() - t0) * 1e3
+        return dict(cams=cams, points=pts, windows=stats)
+
     @staticmethod
     def tracks_to_host(out):
         """Copy the linked tracks of a `run` result to the host: adds numpy `track_ptr` [T+1] i64, `obs_frame`,

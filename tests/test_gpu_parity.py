@@ -775,6 +775,52 @@ def test_clip_pipeline_equals_per_keyframe_drop_in():
         assert got == want, i
 
 
+def test_sliding_window_ba_equals_window_by_window_adjustment():
+    """ClipPipeline.adjust_windows (the reference's commented incremental hook, processor.py:395-408, bounded to a
+    window): the device-side selection / flattening of every window equals a plain NumPy selection in managePoints
+    order, every window is adjusted by exactly the adjustPoints solver (same nfev and cost, bit for bit), later windows
+    start from the written-back cameras and points, and the cost the oracle computes at a window's result is the
+    reported one."""
+    from meatmodeler_amd.bundleAdjuster import SchurTRF, frameParameters
+    F, W, S = 9, 5, 2
+    frames, ext, K = synth.render_orbit_frames(F, 640, 480, arc_deg=10.0)
+    pipe = ClipPipeline(480, 640, 600, batch=F)
+    out = pipe.run(dev(frames), K, ext, ba=False)
+    res = pipe.adjust_windows(out, K, ext, window=W, stride=S)
+    ClipPipeline.tracks_to_host(out)
+    tp, of, ok = out["track_ptr"], out["obs_frame"], out["obs_kp"]
+    xy = out["xy_dev"].cpu().numpy()
+    cams = frameParameters(np.asarray(ext)[:, :3, :]).reshape(F, 6)
+    pts = out["points0"].cpu().numpy().copy()
+    first, last = of[tp[:-1]], of[tp[1:] - 1]
+    wins = iter(res["windows"])
+    n_checked = 0
+    for hi in list(range(W, F, S)) + [F]:
+        lo = max(0, hi - W)
+        sel = np.nonzero(ClipPipeline.window_selection(first, last, lo, hi, F))[0]
+        if len(sel) == 0:
+            continue
+        fi, pi, coords = [], [], []
+        for j, t in enumerate(sel):
+            for o in range(tp[t], tp[t + 1]):
+                fi.append(of[o] - lo)
+                pi.append(j)
+                coords.append(xy[of[o], ok[o]])
+        pb = ops.BADevice(K, np.array(fi), np.array(pi), np.array(coords, np.float64), hi - lo, len(sel), DEV)
+        r = SchurTRF(pb).solve(dev(cams[lo:hi]), dev(pts[sel]))
+        st = next(wins)
+        assert (st["lo"], st["hi"], st["points"], st["observations"]) == (lo, hi, len(sel), len(fi))
+        assert (st["nfev"], st["cost"]) == (r.nfev, r.cost)
+        x1 = np.hstack([r.cams.cpu().numpy().ravel(), r.pts.cpu().numpy().ravel()])
+        c_oracle = 0.5 * np.sum(bo.point_fun(x1, K, hi - lo, len(sel), np.array(fi), np.array(pi), np.array(coords)) ** 2)
+        assert abs(c_oracle - st["cost"]) <= 1e-7 * max(c_oracle, 1.0)
+        cams[lo:hi] = r.cams.cpu().numpy()
+        pts[sel] = r.pts.cpu().numpy()
+        n_checked += 1
+    assert n_checked >= 2 and next(wins, None) is None
+    assert np.array_equal(res["points"].cpu().numpy(), pts) and np.array_equal(res["cams"].cpu().numpy(), cams)
+
+
 def test_clip_pipeline_with_ba_reduces_reprojection_error():
     frames, ext, K = synth.render_orbit_frames(6, 640, 480, arc_deg=8.0)
     pipe = ClipPipeline(480, 640, 1000, batch=6)
