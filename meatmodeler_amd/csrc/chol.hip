@@ -1,17 +1,21 @@
-// SPD solve by blocked right-looking Cholesky, f64, with an optional band (gfx950).
+// SPD solve by blocked Cholesky, f64, with an optional band (gfx950).
 //
 // This is the dense linear algebra of the trust-region step: the reduced camera system S (6F x 6F) that the
 // reference hands to LSMR implicitly (scipy trf.py:480 via bundleAdjuster.py:180-192) is factored here.
-//   step k:  (1) chol_diag   : L_kk = chol(A_kk) and L_kk^-1, ONE wave, the 64x64 block in registers (row per lane),
-//                              columns broadcast through LDS; ~2x2016 fully unrolled FMAs per lane
-//            (2) chol_panel  : A_ik <- A_ik L_kk^-T          (64x64x64 f64-MFMA GEMM per row block, B operand = L_kk^-1)
-//            (3) chol_update : A_ij <- A_ij - A_ik A_jk^T    (64x64x64 f64-MFMA GEMM per block pair i >= j > k)
 // Tracks built from consecutive-keyframe matching only connect cameras at most `track length` apart, so S is block
-// banded; `half_bandwidth` (A[i][j] == 0 for i - j > half_bandwidth) limits (2) and (3) to the band: n*bw^2 instead
-// of n^3/3 flops.  half_bandwidth >= n means dense.
-// Solves: one launch per block column and direction; every workgroup recomputes the 64-vector L_kk^-1 b_k (4 kflop)
-// instead of waiting for a separate launch.  Row-major A, lower triangle referenced / overwritten.
-// MFMA fragment maps for f64 16x16x4 (guide §3): A lane l -> A[l&15][l>>4], B lane l -> B[l>>4][l&15],
+// banded; `half_bandwidth` (A[i][j] == 0 for i - j > half_bandwidth) limits the work to the band: n*bw^2 instead of
+// n^3/3 flops.  half_bandwidth >= n means dense.  Row-major A, lower triangle referenced / overwritten.
+//
+// Two execution schemes over the same 64 x 64 block kernels:
+//   * narrow bands (<= 15 blocks): ONE data-flow scheduled launch factors the matrix and does the forward substitution
+//     (chol_band_fused_kernel), one more does the backward substitution (chol_band_bwd_kernel) -- see the comments there;
+//   * everything else: right-looking, three launches per block column
+//       (1) chol_diag   : L_kk = chol(A_kk) and L_kk^-1
+//       (2) chol_panel  : A_ik <- A_ik L_kk^-T          (64x64x64 f64-MFMA GEMM per row block, B operand = L_kk^-1)
+//       (3) chol_update : A_ij <- A_ij - A_ik A_jk^T    (64x64x64 f64-MFMA GEMM per block pair i >= j > k)
+//     and one launch per block column and direction for the substitutions (every workgroup recomputes the 64-vector
+//     L_kk^-1 b_k instead of waiting for a separate launch).
+// MFMA fragment maps for f64 16x16x4 (guide section 3): A lane l -> A[l&15][l>>4], B lane l -> B[l>>4][l&15],
 // D reg i of lane l -> D[(l>>4) + 4 i][l&15].
 #include "mm_common.h"
 #include <cstdlib>
@@ -491,7 +495,8 @@ constexpr long SPIN_LIMIT = 1L << 23;
 constexpr int FUSED_MAX_BWB = 15;  // 16 + 105 = 121 resident workgroups at most
 constexpr size_t FUSED_LDS_BYTES = (size_t)(2 * NB * LDT + 4 * 16 * 17 + 3 * NB) * sizeof(double);
 
-// Coherence between the workgroups (they sit on different XCDs, each with its own L2).  MODE 1: plain loads / stores
+// Coherence between the workgroups (they sit on different XCDs, each with its own L2).  MODE 1 (measured, not shipped:
+// +4 % per factorisation; instantiate chol_band_fused_kernel<1> to compare): plain loads / stores
 // of the blocks, bracketed by agent-scope release / acquire fences (L2 write-back + invalidate per hand-over).
 // MODE 2: every shared block is written and read with agent-scope relaxed atomics (write-through stores, cache-bypassing
 // loads: `global_* ... sc1`), the writer drains its stores (s_waitcnt) before raising the flag: no cache maintenance.
@@ -1149,8 +1154,6 @@ int mm_chol_solve_gated(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int 
     if (fused_mode > 0 && nblk >= 2 && bwb >= 1 && bwb <= FUSED_MAX_BWB) {
         static bool attr_set = false;
         if (!attr_set) {
-            MM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(chol_band_fused_kernel<1>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS_BYTES));
             MM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(chol_band_fused_kernel<2>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS_BYTES));
             attr_set = true;
@@ -1161,12 +1164,8 @@ int mm_chol_solve_gated(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int 
         const double *b_fwd = nrhs >= 1 ? b : nullptr;  // the first right-hand side rides along
         MM_HIP(ctx, hipMemsetAsync(flags, 0, nflags * sizeof(int32_t), ctx->stream));
         const int grid = (bwb + 1) + bwb * (bwb - 1) / 2;
-        if (fused_mode == 1)
-            MM_LAUNCH(ctx, "chol_band_fused_kernel", chol_band_fused_kernel<1>, dim3(grid), dim3(256), FUSED_LDS_BYTES, A, n,
-                      nblk, bwb, Linv, flags, info, b_fwd, ytmp, contrib, slab_ready, cams_per_slab, n_cams);
-        else
-            MM_LAUNCH(ctx, "chol_band_fused_kernel", chol_band_fused_kernel<2>, dim3(grid), dim3(256), FUSED_LDS_BYTES, A, n,
-                      nblk, bwb, Linv, flags, info, b_fwd, ytmp, contrib, slab_ready, cams_per_slab, n_cams);
+        MM_LAUNCH(ctx, "chol_band_fused_kernel", chol_band_fused_kernel<2>, dim3(grid), dim3(256), FUSED_LDS_BYTES, A, n, nblk,
+                  bwb, Linv, flags, info, b_fwd, ytmp, contrib, slab_ready, cams_per_slab, n_cams);
         fwd_done = b_fwd != nullptr;
     } else {
         for (int k = 0; k < nblk; ++k) {
