@@ -320,6 +320,39 @@ def test_ba_normal_equations_jvp_schur_backsub_consistent():
     np.testing.assert_allclose(got, sol, rtol=1e-6, atol=1e-9 * np.abs(sol).max())
 
 
+def test_ba_full_size_adjoint_and_reduced_system_properties():
+    """BASELINE size (500 cameras, 300 k points, 1.5 M observations): properties that need no oracle run --
+    the sweeps are mutually adjoint (<J w, r> == <w, J^T r> with J^T r from the normal-equation sweep, J w from the
+    JVP sweep), the cost is the squared norm of the residual vector, and the overlapped build + banded solve returns
+    the solution of the reduced camera system it built (|S dc - v| small against |v|)."""
+    F, P, L = 500, 300_000, 5
+    pr = synth.make_ba_problem(F, P, L, seed=9)
+    cams = dev(bo.frame_parameters(pr["ext"]).reshape(F, 6))
+    pts = dev(pr["pts0"])
+    pb = ops.BADevice(pr["K"], pr["fi"], pr["pi"], pr["obs"], F, P, DEV)
+    cost2, res = pb.residual(cams, pts, True)
+    assert abs(float(cost2) - float((res * res).sum())) <= 1e-11 * float(cost2)
+    B, gc, C6, gp = pb.normal_eq(cams, pts)
+    rng = np.random.default_rng(1)
+    wc, wp = dev(rng.normal(size=(F, 6))), dev(rng.normal(size=(P, 3)))
+    Jw = pb.jvp(cams, pts, wc, wp)
+    lhs = float((Jw * res).sum())
+    rhs = float((wc * gc).sum() + (wp * gp).sum())
+    assert abs(lhs - rhs) <= 1e-9 * max(abs(lhs), abs(rhs), 1.0)
+    Bd = B + 1e-4 * torch.diag_embed(torch.diagonal(B, dim1=1, dim2=2))
+    Cd = C6.clone()
+    Cd[:, [0, 3, 5]] *= 1.0 + 1e-4
+    hb = 6 * pb.cam_span + 5
+    S, v, _ = pb.schur(cams, pts, Bd, Cd, gc, gp)
+    Sl = torch.tril(S)
+    Sfull = Sl + torch.tril(S, -1).T
+    v0 = v.clone()
+    info, dc, _ = pb.schur_solve(cams, pts, Bd, Cd, gc, gp, hb)
+    assert int(info) == 0
+    r = Sfull @ dc - v0
+    assert float(r.norm()) <= 1e-9 * float(v0.norm())
+
+
 def test_device_built_indices_equal_host_builders():
     """CSR by point / camera and the co-observation pair list built on the device (torch sorts + two HIP kernels)
     are identical to the host C++ builders (mm_ba_build_index / mm_ba_build_pairs)."""
@@ -734,6 +767,40 @@ def test_link_tracks_device_equals_host_linker(F, nk, frac, seed):
     assert np.array_equal(tp0, tp1.astype(np.int64))
     assert np.array_equal(of0, of1) and np.array_equal(ok0, ok1)
     assert len(tp0) - 1 > 0
+
+
+def test_link_tracks_device_full_size_properties():
+    """BASELINE size (500 frames x 4000 key points, ~3000 matches per pair, distinct coordinates): properties that hold
+    for any correct linking -- every track has >= 2 observations on consecutive ascending frames, every step of a track
+    is one of the pair's matches, every match is used exactly once (as a continuation or as the start of a track), no
+    (frame, key point) starts or continues two tracks from the same match -- and the device result equals the host
+    linker's."""
+    rng = np.random.default_rng(11)
+    F, nk = 500, 4000
+    # distinct coordinates per frame: canonical key point == key point
+    kp_xy = np.stack([np.tile(np.arange(nk, dtype=np.float32), (F, 1)), np.tile(np.arange(F, dtype=np.float32)[:, None], (1, nk))], -1)
+    kp_count = np.full(F, nk, np.int32)
+    mc = np.zeros(F - 1, np.int32)
+    mm = np.zeros((F - 1, nk, 2), np.int32)
+    for f in range(F - 1):
+        m = int(rng.integers(2500, 3500))
+        q = np.sort(rng.choice(nk, size=m, replace=False))       # a query key point matches at most once (kNN + ratio)
+        t = rng.integers(0, nk, size=m)                          # several queries may hit the same train key point
+        mc[f], mm[f, :m, 0], mm[f, :m, 1] = m, q, t
+    (tp0, of0, ok0), (tp, of, ok) = _link_both(kp_count, kp_xy, mc, mm)
+    assert np.array_equal(tp0, tp.astype(np.int64)) and np.array_equal(of0, of) and np.array_equal(ok0, ok)
+    lens = np.diff(tp)
+    assert lens.min() >= 2 and tp[-1] == len(of)
+    inner = np.ones(len(of), bool)
+    inner[tp[1:-1]] = False                                      # positions that continue the previous observation
+    inner[0] = False
+    step_f, step_a, step_b = of[:-1][inner[1:]], ok[:-1][inner[1:]], ok[1:][inner[1:]]
+    assert np.array_equal(of[1:][inner[1:]], step_f + 1)         # consecutive frames inside a track
+    key = lambda f, a, b: (f.astype(np.int64) * nk + a) * nk + b
+    all_matches = np.concatenate([key(np.full(mc[f], f), mm[f, :mc[f], 0], mm[f, :mc[f], 1]) for f in range(F - 1)])
+    steps = key(step_f, step_a, step_b)
+    assert len(np.unique(steps)) == len(steps)
+    assert np.isin(steps, all_matches).all() and len(steps) == len(all_matches)   # every match is exactly one step
 
 
 def test_link_tracks_device_empty_and_malformed():
