@@ -209,6 +209,18 @@ int mm_ba_pairs_emit(mm_ctx *ctx, const mm_ba_problem *pb, const int64_t *offset
 size_t mm_multi_dot_workspace_bytes(void);
 int mm_multi_dot(mm_ctx *ctx, int k, const double *const *a, const double *const *b, int64_t n, int64_t split,
                  double *out, void *ws, size_t ws_bytes);
+/* Fused element-wise passes of the 2-D subspace trust-region step (SciPy trf.py:478-494 via bundleAdjuster.py:180-192),
+ * each accumulating the inner products the next pass needs (deterministic, reported like mm_multi_dot as rows of
+ * {i < split, i >= split, total}; one more row holds maxima).  in / outv / scalars: HOST arrays of device pointers.
+ *   op 0: in {g, si}                 outv {gh = g/si, ghs = gh/si}            out rows: gh.gh | max |g|
+ *   op 1: in {v[split], dp[n-split], si, gh}  scalars {gh2}  outv {gn = [v;dp]*si, q1 = gh/sqrt(gh2)}   rows: q1.gn, gn.gn | -
+ *   op 2: in {gn, q1}  scalars {sc}   outv {w = gn - sc q1}                    rows: w.w | -
+ *   op 3: in {w, q1, si, gh, x}  scalars {wn2}  outv {q2 = w/sqrt(wn2), s1 = q1/si, s2 = q2/si}
+ *                                                                              rows: s1.s1, s1.s2, s2.s2, q2.gh, x.x | -
+ *   op 4: in {x, s1, s2}  h0, h1      outv {x + h0 s1 + h1 s2}                 (no result rows)
+ * out [(K+1), 3] dev; workspace as for mm_multi_dot (zero-filled once). */
+int mm_trf_fused(mm_ctx *ctx, int op, const double *const *in, double *const *outv, const double *const *scalars,
+                 double h0, double h1, int64_t n, int64_t split, double *out, void *ws, size_t ws_bytes);
 /* Regulariser of the trust-region sub-problem on the device (SciPy trf.py:473-477, reached through
  * bundleAdjuster.py:180-192): gh2 = |g_h|^2, d11 = |J_h g_h|^2 (device scalars), Delta the radius.
  * out [2] dev = {reg, max(reg, min_damping)}. */

@@ -79,6 +79,8 @@ SIGNATURES = {
                                     C.c_size_t, vp, C.c_size_t, C.c_int, C.c_int, c_i64p, c_i64p]),
     "mm_multi_dot_workspace_bytes": (C.c_size_t, []),
     "mm_multi_dot": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.c_int64, C.c_int64, vp, vp, C.c_size_t]),
+    "mm_trf_fused": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.c_double, C.c_double, C.c_int64,
+                               C.c_int64, vp, vp, C.c_size_t]),
     "mm_trf_damping": (C.c_int, [vp, vp, vp, C.c_double, C.c_double, vp]),
     "mm_ba_backsub": (C.c_int, [vp, C.POINTER(BAProblem), vp, vp, vp, vp, vp, vp]),
     "mm_chol_workspace_bytes": (C.c_size_t, [C.c_int]),

@@ -243,6 +243,14 @@ class SchurTRF:
         self.allreduce(pts)
         return out[:, 0] + pts
 
+    def _combine(self, rows):
+        """rows [k, 3] of a fused pass -> [k] totals (the point part is summed across ranks when sharded)."""
+        if self.allreduce is None:
+            return rows[:, 2]
+        pts = rows[:, 1].contiguous()
+        self.allreduce(pts)
+        return rows[:, 0] + pts
+
     def _dots_sharded(self, pairs):
         """Inner products of residual-space vectors (every rank holds its own observations)."""
         out = self.pb.multi_dot(pairs, 0)[:, 2].contiguous()
@@ -315,15 +323,18 @@ class SchurTRF:
         t_mark = time.perf_counter()
         g_norm = None
         while True:
-            gh = g / si                                   # g_h = d * g, d = 1 / scale_inv
-            ghs = gh / si
-            u1 = pb.jvp(self._cams(x), self._pts(x), self._cams(ghs), self._pts(ghs))   # J (d g_h)
-            gmax = g.abs().max().reshape(1)
-            u1 = u1.reshape(-1)
-            d11_t = self._dots_sharded([(u1, u1)])
+            # g_h = d * g (d = 1 / scale_inv) and d * g_h in one pass that also yields |g_h|^2 and |g|_inf
+            gh, ghs = torch.empty_like(g), torch.empty_like(g)
+            r0 = pb.trf_fused(0, [g, si], [gh, ghs], split=nc)
+            gh2_t = self._combine(r0[:1]).contiguous()
             if self.allreduce is not None:
-                self.allreduce(gmax, op="max")
-            gh2_t = self._dots([(gh, gh)])
+                gmax_p = r0[1, 1:2].contiguous()
+                self.allreduce(gmax_p, op="max")
+                gmax = torch.maximum(r0[1, 0:1], gmax_p)
+            else:
+                gmax = r0[1, 2:3]
+            u1 = pb.jvp(self._cams(x), self._pts(x), self._cams(ghs), self._pts(ghs)).reshape(-1)   # J (d g_h)
+            d11_t = self._dots_sharded([(u1, u1)])
             if termination is not None or nfev == max_nfev:
                 g_norm = float(gmax.item())
                 if verbose == 2:
@@ -338,7 +349,6 @@ class SchurTRF:
             # raised floor is kept for the rest of the solve (a system that needed it once needs it again).
             damp = pb.trf_damping(gh2_t, d11_t, Delta, self.min_damping)
             reg_eff = damp[1:2]
-            gh_norm_t = torch.sqrt(gh2_t)
             gc, gp = self._cams(g), self._pts(g)
             for attempt in range(6):
                 Bd = torch.addcmul(B, sic2_36, reg_eff)   # B + reg diag(scale_inv^2), C + reg diag(...) (packed 6)
@@ -377,21 +387,22 @@ class SchurTRF:
                         v -= (ws - 1) * gc.reshape(-1)
                 if self.allreduce is not None or not hasattr(pb, "schur_solve"):
                     info = pb.chol_solve(S, v, half_bandwidth=half_bw)
-                q = torch.empty(n, **f64)                 # q = (J^T J + reg D^-2)^-1 g  (unscaled Gauss-Newton step)
-                q[:nc] = v
-                q[nc:] = pb.backsub(self._cams(x), self._pts(x), Cinv, gp, v.view(F, 6)).reshape(-1)
-                # orthonormal basis of span{g_h, gn_h} (trf.py:481-482), all on the device
-                gn = q * si                               # gn_h = q * scale_inv
-                q1 = gh / gh_norm_t
-                sc, gn2 = self._dots([(q1, gn), (gn, gn)])
-                w = torch.addcmul(gn, q1, sc, value=-1.0)  # gn - sc q1
-                wn2 = self._dots([(w, w)])
-                q2 = w / torch.sqrt(wn2)
-                s1, s2 = q1 / si, q2 / si                 # unscaled basis steps d * q
+                # q = [v ; dp] = (J^T J + reg D^-2)^-1 g, the unscaled Gauss-Newton step
+                dp = pb.backsub(self._cams(x), self._pts(x), Cinv, gp, v.view(F, 6)).reshape(-1)
+                # orthonormal basis of span{g_h, gn_h} (trf.py:481-482) in three fused passes:
+                #   gn_h = q * scale_inv, q1 = g_h / |g_h|            (+ <q1, gn_h>, |gn_h|^2)
+                #   w = gn_h - <q1, gn_h> q1                            (+ |w|^2)
+                #   q2 = w / |w|, s1 = d q1, s2 = d q2 (unscaled steps) (+ the five step inner products)
+                gn, q1, w = torch.empty_like(g), torch.empty_like(g), torch.empty_like(g)
+                r1 = self._combine(pb.trf_fused(1, [v, dp, si, gh], [gn, q1], [gh2_t], split=nc)[:2])
+                sc, gn2 = r1[0:1].contiguous(), r1[1]
+                wn2 = self._combine(pb.trf_fused(2, [gn, q1], [w], [sc], split=nc)[:1]).contiguous()
+                q2, s1, s2 = torch.empty_like(g), torch.empty_like(g), torch.empty_like(g)
+                nn = self._combine(pb.trf_fused(3, [w, q1, si, gh, x], [q2, s1, s2], [wn2], split=nc)[:5])
+                wn2 = wn2[0]
                 Jq2 = pb.jvp(self._cams(x), self._pts(x), self._cams(s2), self._pts(s2)).reshape(-1)
                 # J_h q1 = J (d q1) = u1 / |g_h|: <Jq1, Jq1> = d11 / |g_h|^2, <Jq1, Jq2> = <u1, Jq2> / |g_h|
                 bs = self._dots_sharded([(u1, Jq2), (Jq2, Jq2)])
-                nn = self._dots([(s1, s1), (s1, s2), (s2, s2), (q2, gh), (x, x)])
                 # ---- host sync A ----
                 vals = torch.cat([info.to(torch.float64), wn2.reshape(1), gn2.reshape(1), bs, nn, gmax,
                                   gh2_t.reshape(1), d11_t.reshape(1), reg_eff]).tolist()
@@ -426,7 +437,8 @@ class SchurTRF:
             while actual <= 0 and nfev < max_nfev:
                 p_S, _ = _solve_trust_region_2d(B_S, g_S, Delta)
                 predicted = -(0.5 * p_S @ B_S @ p_S + g_S @ p_S)
-                x_new = torch.add(x, s1, alpha=float(p_S[0])).add_(s2, alpha=float(p_S[1]))
+                x_new = torch.empty_like(x)
+                pb.trf_fused(4, [x, s1, s2], [x_new], h0=float(p_S[0]), h1=float(p_S[1]), split=nc)
                 cost_new = 0.5 * float(self._cost_dev(x_new).item())      # ---- host sync 3 (per trial step) ----
                 nfev += 1
                 step_h_norm = float(_norm(p_S))

@@ -114,3 +114,215 @@ int mm_multi_dot(mm_ctx *ctx, int k, const double *const *a, const double *const
 }
 
 }  // extern "C"
+
+// ---- fused vector updates of the trust-region driver -------------------------------------------------------------------
+// The 2-D subspace step of SciPy's TRF (trf.py:478-494) is a dozen element-wise passes over the parameter vector, each
+// followed by an inner product that the next pass needs.  Written with framework calls that is ~40 small launches per
+// iteration; here every pass also accumulates the inner products it is followed by (same deterministic reduction as
+// mm_multi_dot: fixed slices, fixed trees, last workgroup adds the partials in index order; sums reported as camera
+// part / point part / total so that a sharded run can all-reduce the point part).
+namespace {
+
+constexpr int FV_MAXK = 5;
+
+struct FusedArgs {
+    const double *in[6];
+    double *out[3];
+    const double *scalar[2];   // device scalars
+    double h0, h1;             // host scalars
+};
+
+// OP 0: gh = g / si, ghs = gh / si;                      sums: gh.gh           (+ max |g| in the extra slot)
+// OP 1: gn = q * si, q1 = gh / sqrt(gh2);                sums: q1.gn, gn.gn    (q = [v ; dp]: in[0] cameras, in[1] points)
+// OP 2: w = gn - sc * q1;                                sums: w.w
+// OP 3: q2 = w / sqrt(wn2), s1 = q1 / si, s2 = q2 / si;  sums: s1.s1, s1.s2, s2.s2, q2.gh, x.x
+// OP 4: x_new = x + h0 * s1 + h1 * s2;                   no sums
+template <int OP>
+struct FusedTraits;
+template <> struct FusedTraits<0> { static constexpr int K = 1; };
+template <> struct FusedTraits<1> { static constexpr int K = 2; };
+template <> struct FusedTraits<2> { static constexpr int K = 1; };
+template <> struct FusedTraits<3> { static constexpr int K = 5; };
+template <> struct FusedTraits<4> { static constexpr int K = 0; };
+
+template <int OP>
+__device__ __forceinline__ void fused_elem(const FusedArgs &a, int64_t i, int64_t split, double (&p)[FV_MAXK], double &mx) {
+    if constexpr (OP == 0) {
+        const double g = a.in[0][i], si = a.in[1][i];
+        const double gh = g / si;
+        a.out[0][i] = gh;
+        a.out[1][i] = gh / si;
+        p[0] = gh * gh;
+        mx = fmax(mx, fabs(g));
+    } else if constexpr (OP == 1) {
+        const double q = i < split ? a.in[0][i] : a.in[1][i - split];
+        const double gn = q * a.in[2][i];
+        const double q1 = a.in[3][i] / sqrt(a.scalar[0][0]);
+        a.out[0][i] = gn;
+        a.out[1][i] = q1;
+        p[0] = q1 * gn;
+        p[1] = gn * gn;
+    } else if constexpr (OP == 2) {
+        const double w = a.in[0][i] - a.scalar[0][0] * a.in[1][i];
+        a.out[0][i] = w;
+        p[0] = w * w;
+    } else if constexpr (OP == 3) {
+        const double si = a.in[2][i];
+        const double q2 = a.in[0][i] / sqrt(a.scalar[0][0]);
+        const double s1 = a.in[1][i] / si, s2 = q2 / si;
+        const double x = a.in[4][i];
+        a.out[0][i] = q2;
+        a.out[1][i] = s1;
+        a.out[2][i] = s2;
+        p[0] = s1 * s1;
+        p[1] = s1 * s2;
+        p[2] = s2 * s2;
+        p[3] = q2 * a.in[3][i];
+        p[4] = x * x;
+    } else {
+        a.out[0][i] = a.in[0][i] + a.h0 * a.in[1][i] + a.h1 * a.in[2][i];
+    }
+}
+
+template <int OP>
+__global__ __launch_bounds__(MD_THREADS) void fused_vec_kernel(FusedArgs args, int64_t n, int64_t split,
+                                                               double *__restrict__ partial, unsigned *__restrict__ counter,
+                                                               double *__restrict__ out) {
+    constexpr int K = FusedTraits<OP>::K;
+    constexpr int NA = 2 * K + 2;            // sums (camera, point) + the two maxima
+    __shared__ double sm[(MD_THREADS / 64) * (NA > 0 ? NA : 1)];
+    __shared__ int s_last;
+    double acc[NA];
+#pragma unroll
+    for (int q = 0; q < NA; ++q) acc[q] = 0.0;
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = per * blockIdx.x, hi = min(n, lo + per);
+    for (int64_t i = lo + threadIdx.x; i < hi; i += MD_THREADS) {
+        double p[FV_MAXK] = {0, 0, 0, 0, 0}, mx = 0.0;
+        fused_elem<OP>(args, i, split, p, mx);
+        const bool pts = i >= split;
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+            acc[2 * q] += pts ? 0.0 : p[q];
+            acc[2 * q + 1] += pts ? p[q] : 0.0;
+        }
+        acc[2 * K + (pts ? 1 : 0)] = fmax(acc[2 * K + (pts ? 1 : 0)], mx);
+    }
+    if constexpr (K == 0) return;
+    // maxima: reduce with max, sums with the fixed tree (the maxima are order-independent anyway)
+    double m0 = acc[2 * K], m1 = acc[2 * K + 1];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        m0 = fmax(m0, __shfl_down(m0, off, 64));
+        m1 = fmax(m1, __shfl_down(m1, off, 64));
+    }
+    block_sum_n<NA, MD_THREADS>(acc, sm);     // slots 2K, 2K+1 of `acc` are overwritten below
+    __shared__ double smax[2][MD_THREADS / 64];
+    if ((threadIdx.x & 63) == 0) {
+        smax[0][threadIdx.x >> 6] = m0;
+        smax[1][threadIdx.x >> 6] = m1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double b0 = 0.0, b1 = 0.0;
+        for (int w = 0; w < MD_THREADS / 64; ++w) {
+            b0 = fmax(b0, smax[0][w]);
+            b1 = fmax(b1, smax[1][w]);
+        }
+        acc[2 * K] = b0;
+        acc[2 * K + 1] = b1;
+#pragma unroll
+        for (int q = 0; q < NA; ++q)
+            __hip_atomic_store(partial + (size_t)blockIdx.x * NA + q, acc[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_last = atomicAdd(counter, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+#pragma unroll
+    for (int q = 0; q < NA; ++q) acc[q] = 0.0;
+    double g0 = 0.0, g1 = 0.0;
+    for (unsigned g = threadIdx.x; g < gridDim.x; g += MD_THREADS) {
+#pragma unroll
+        for (int q = 0; q < 2 * K; ++q)
+            acc[q] += __hip_atomic_load(partial + (size_t)g * NA + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        g0 = fmax(g0, __hip_atomic_load(partial + (size_t)g * NA + 2 * K, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        g1 = fmax(g1, __hip_atomic_load(partial + (size_t)g * NA + 2 * K + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        g0 = fmax(g0, __shfl_down(g0, off, 64));
+        g1 = fmax(g1, __shfl_down(g1, off, 64));
+    }
+    acc[2 * K] = 0.0;
+    acc[2 * K + 1] = 0.0;
+    block_sum_n<NA, MD_THREADS>(acc, sm);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        smax[0][threadIdx.x >> 6] = g0;
+        smax[1][threadIdx.x >> 6] = g1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+            out[3 * q] = acc[2 * q];
+            out[3 * q + 1] = acc[2 * q + 1];
+            out[3 * q + 2] = acc[2 * q] + acc[2 * q + 1];
+        }
+        double b0 = 0.0, b1 = 0.0;
+        for (int w = 0; w < MD_THREADS / 64; ++w) {
+            b0 = fmax(b0, smax[0][w]);
+            b1 = fmax(b1, smax[1][w]);
+        }
+        out[3 * K] = b0;
+        out[3 * K + 1] = b1;
+        out[3 * K + 2] = fmax(b0, b1);
+        *counter = 0;
+    }
+}
+
+template <int OP>
+int launch_fused(mm_ctx *ctx, const FusedArgs &args, int64_t n, int64_t split, double *partial, unsigned *counter, double *out) {
+    int64_t g = (n + 4 * MD_THREADS - 1) / (4 * MD_THREADS);
+    const int grid = (int)(g < 1 ? 1 : (g > MD_GRID ? MD_GRID : g));
+    MM_LAUNCH(ctx, "fused_vec_kernel", fused_vec_kernel<OP>, dim3(grid), dim3(MD_THREADS), 0, args, n, split, partial, counter, out);
+    return MM_OK;
+}
+
+}  // namespace
+
+extern "C" int mm_trf_fused(mm_ctx *ctx, int op, const double *const *in, double *const *outv, const double *const *scalars,
+                            double h0, double h1, int64_t n, int64_t split, double *out, void *ws, size_t ws_bytes) {
+    if (!ctx) return MM_ERR_ARG;
+    static const int n_in[5] = {2, 4, 2, 5, 3}, n_out[5] = {2, 2, 1, 3, 1}, n_sc[5] = {0, 1, 1, 1, 0};
+    if (op < 0 || op > 4 || !in || !outv || n < 0 || split < 0 || split > n) return mm_fail(ctx, MM_ERR_ARG, "mm_trf_fused: bad argument");
+    if (!ws || ws_bytes < mm_multi_dot_workspace_bytes() || ((uintptr_t)ws & 255))
+        return mm_fail(ctx, MM_ERR_WORKSPACE, "mm_trf_fused: workspace too small or misaligned");
+    FusedArgs a = {};
+    for (int q = 0; q < n_in[op]; ++q) {
+        if (!in[q]) return mm_fail(ctx, MM_ERR_ARG, "mm_trf_fused: null input %d", q);
+        a.in[q] = in[q];
+    }
+    for (int q = 0; q < n_out[op]; ++q) {
+        if (!outv[q]) return mm_fail(ctx, MM_ERR_ARG, "mm_trf_fused: null output %d", q);
+        a.out[q] = outv[q];
+    }
+    for (int q = 0; q < n_sc[op]; ++q) {
+        if (!scalars || !scalars[q]) return mm_fail(ctx, MM_ERR_ARG, "mm_trf_fused: null scalar %d", q);
+        a.scalar[q] = scalars[q];
+    }
+    if (op != 4 && !out) return mm_fail(ctx, MM_ERR_ARG, "mm_trf_fused: null result");
+    a.h0 = h0;
+    a.h1 = h1;
+    if (n == 0) return MM_OK;
+    unsigned *counter = (unsigned *)ws;
+    double *partial = (double *)((char *)ws + 256);
+    switch (op) {
+        case 0: return launch_fused<0>(ctx, a, n, split, partial, counter, out);
+        case 1: return launch_fused<1>(ctx, a, n, split, partial, counter, out);
+        case 2: return launch_fused<2>(ctx, a, n, split, partial, counter, out);
+        case 3: return launch_fused<3>(ctx, a, n, split, partial, counter, out);
+        default: return launch_fused<4>(ctx, a, n, split, partial, counter, out);
+    }
+}

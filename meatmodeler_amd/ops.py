@@ -387,6 +387,26 @@ class BADevice:
             self._mdot = MultiDot(self.device, self.ctx)
         return self._mdot(pairs, split)
 
+    _FUSED_ROWS = (2, 3, 2, 6, 0)
+
+    def trf_fused(self, op, ins, outs, scalars=(), h0=0.0, h1=0.0, split=0):
+        """One fused element-wise pass of the trust-region step with its inner products (mm_trf_fused).
+        -> device tensor [rows, 3] = (camera part, point part, total) per inner product, last row: maxima."""
+        if self._mdot is None:
+            self._mdot = MultiDot(self.device, self.ctx)
+        ws = self._mdot.ws
+        n = outs[0].numel()
+        for t in list(ins) + list(outs) + list(scalars):
+            assert t.dtype == torch.float64 and t.is_contiguous()
+        pin = (C.c_void_p * len(ins))(*[t.data_ptr() for t in ins])
+        pout = (C.c_void_p * len(outs))(*[t.data_ptr() for t in outs])
+        psc = (C.c_void_p * max(len(scalars), 1))(*[t.data_ptr() for t in scalars]) if scalars else None
+        rows = self._FUSED_ROWS[op]
+        res = torch.empty((max(rows, 1), 3), dtype=torch.float64, device=self.device)
+        self.ctx.check(lib.mm_trf_fused(self.ctx.h, op, pin, pout, psc, float(h0), float(h1), n, int(split), ptr(res), ptr(ws),
+                                        ws.numel()), "mm_trf_fused")
+        return res
+
     def trf_damping(self, gh2, d11, Delta, min_damping):
         """Device scalars -> tensor [reg, max(reg, min_damping)] (see ops.trf_damping)."""
         return trf_damping(gh2, d11, Delta, min_damping, self.ctx)

@@ -74,6 +74,41 @@ class NumpyBA:
         rows = [[torch.dot(a[:split], b[:split]), torch.dot(a[split:], b[split:]), torch.dot(a, b)] for a, b in pairs]
         return torch.stack([torch.stack(r) for r in rows])
 
+    def trf_fused(self, op, ins, outs, scalars=(), h0=0.0, h1=0.0, split=0):
+        """torch restatement of mm_trf_fused (see include/meatmodeler.h)."""
+        def rows(pairs, mx=None):
+            r = [[torch.dot(a[:split], b[:split]), torch.dot(a[split:], b[split:]), torch.dot(a, b)] for a, b in pairs]
+            if mx is None:
+                r.append([torch.zeros((), dtype=torch.float64)] * 3)
+            else:
+                m0 = mx[:split].abs().max() if split else torch.zeros((), dtype=torch.float64)
+                m1 = mx[split:].abs().max() if split < mx.numel() else torch.zeros((), dtype=torch.float64)
+                r.append([m0, m1, torch.maximum(m0, m1)])
+            return torch.stack([torch.stack(list(x)) for x in r])
+        if op == 0:
+            g, si = ins
+            outs[0].copy_(g / si)
+            outs[1].copy_(outs[0] / si)
+            return rows([(outs[0], outs[0])], g)
+        if op == 1:
+            v, dp, si, gh = ins
+            outs[0].copy_(torch.cat([v, dp]) * si)
+            outs[1].copy_(gh / torch.sqrt(scalars[0][0]))
+            return rows([(outs[1], outs[0]), (outs[0], outs[0])])
+        if op == 2:
+            gn, q1 = ins
+            outs[0].copy_(gn - scalars[0][0] * q1)
+            return rows([(outs[0], outs[0])])
+        if op == 3:
+            w, q1, si, gh, x = ins
+            outs[0].copy_(w / torch.sqrt(scalars[0][0]))
+            outs[1].copy_(q1 / si)
+            outs[2].copy_(outs[0] / si)
+            return rows([(outs[1], outs[1]), (outs[1], outs[2]), (outs[2], outs[2]), (outs[0], gh), (x, x)])
+        x, s1, s2 = ins
+        outs[0].copy_(x + h0 * s1 + h1 * s2)
+        return torch.zeros((1, 3), dtype=torch.float64)
+
     def trf_damping(self, gh2, d11, Delta, min_damping):
         """SciPy trf.py:473-477 (the product runs this as a one-thread kernel, mm_trf_damping)."""
         a, b = 0.5 * float(d11), -float(gh2)

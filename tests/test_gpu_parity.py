@@ -493,6 +493,40 @@ def test_multi_dot_vs_numpy(n, k, split):
     assert np.array_equal(out, out2)            # deterministic
 
 
+def test_trf_fused_passes_vs_torch():
+    """mm_trf_fused: the element-wise passes of the 2-D subspace step and the inner products they carry, against the
+    same formulas written with torch (outputs bit for bit: IEEE division / sqrt; sums to rounding)."""
+    rng = np.random.default_rng(3)
+    n, split = 200_003, 3000
+    pr = synth.make_ba_problem(6, 40, 4, seed=1)
+    pb = ops.BADevice(pr["K"], pr["fi"], pr["pi"], pr["obs"], 6, 40, DEV)
+    g, si, x = dev(rng.normal(size=n)), dev(rng.uniform(0.5, 2.0, size=n)), dev(rng.normal(size=n))
+    gh, ghs = torch.empty_like(g), torch.empty_like(g)
+    r0 = pb.trf_fused(0, [g, si], [gh, ghs], split=split)
+    assert torch.equal(gh, g / si) and torch.equal(ghs, (g / si) / si)
+    np.testing.assert_allclose(r0[0].cpu().numpy(), [float(gh[:split] @ gh[:split]), float(gh[split:] @ gh[split:]), float(gh @ gh)], rtol=1e-12)
+    assert r0[1].cpu().tolist() == [float(g[:split].abs().max()), float(g[split:].abs().max()), float(g.abs().max())]
+    gh2 = r0[0, 2:3].contiguous()
+    v, dp = dev(rng.normal(size=split)), dev(rng.normal(size=n - split))
+    gn, q1, w = torch.empty_like(g), torch.empty_like(g), torch.empty_like(g)
+    r1 = pb.trf_fused(1, [v, dp, si, gh], [gn, q1], [gh2], split=split)
+    assert torch.equal(gn, torch.cat([v, dp]) * si) and torch.equal(q1, gh / torch.sqrt(gh2))
+    np.testing.assert_allclose(r1[:2, 2].cpu().numpy(), [float(q1 @ gn), float(gn @ gn)], rtol=1e-11)
+    sc = r1[0, 2:3].contiguous()
+    r2 = pb.trf_fused(2, [gn, q1], [w], [sc], split=split)
+    np.testing.assert_allclose(w.cpu().numpy(), (gn - sc * q1).cpu().numpy(), rtol=0, atol=1e-15)   # (one FMA vs mul + sub)
+    np.testing.assert_allclose(float(r2[0, 2]), float(w @ w), rtol=1e-11)
+    wn2 = r2[0, 2:3].contiguous()
+    q2, s1, s2 = torch.empty_like(g), torch.empty_like(g), torch.empty_like(g)
+    r3 = pb.trf_fused(3, [w, q1, si, gh, x], [q2, s1, s2], [wn2], split=split)
+    assert torch.equal(q2, w / torch.sqrt(wn2)) and torch.equal(s1, q1 / si) and torch.equal(s2, q2 / si)
+    np.testing.assert_allclose(r3[:5, 2].cpu().numpy(), [float(s1 @ s1), float(s1 @ s2), float(s2 @ s2), float(q2 @ gh), float(x @ x)],
+                               rtol=1e-10, atol=1e-12)
+    xn = torch.empty_like(x)
+    pb.trf_fused(4, [x, s1, s2], [xn], h0=0.3, h1=-1.7, split=split)
+    np.testing.assert_allclose(xn.cpu().numpy(), (x + 0.3 * s1 - 1.7 * s2).cpu().numpy(), rtol=1e-15, atol=1e-15)
+
+
 def test_trf_damping_vs_scipy_formula():
     """mm_trf_damping == the scalar recipe of SciPy trf.py:473-477 (regulariser from the Cauchy-like model along g_h)."""
     rng = np.random.default_rng(5)
