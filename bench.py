@@ -42,7 +42,9 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--nfeatures", type=int, default=4000)
-    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--batch", type=int, default=512,
+                    help="frames per ORB launch set (the pyramid workspace is ~4.5 MB per frame; one set per clip avoids "
+                         "16 x 14 launch tails: detect 34.6 -> 28.7 ms)")
     ap.add_argument("--arc", type=float, default=None, help="orbit arc in degrees (default 0.72 deg/frame)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ba", action="store_true")
@@ -150,7 +152,7 @@ def main():
         ext[f, :, 3] += rng.normal(0, 2e-3, 3)
     torch.cuda.synchronize()
     t_render = time.time() - t0
-    pipe = ClipPipeline(H, W, N, batch=a.batch, device=dev, ctx=ctx)
+    pipe = ClipPipeline(H, W, N, batch=max(1, min(a.batch, -(-F // world) + 1)), device=dev, ctx=ctx)
     d = dist if use_dist else None
 
     def step(timers=None):
