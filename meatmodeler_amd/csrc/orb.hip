@@ -81,36 +81,79 @@ __global__ void orb_tables_kernel(OrbGeom g, uint8_t *ws) {
 }
 
 // ---- pyramid level l-1 -> l ---------------------------------------------------------------------------------------------
+// Output tile 256 x 16 per workgroup.  The source footprint (<= 24 rows x 320 bytes at any scale >= 1) is staged in LDS
+// with coalesced 4-byte loads; a thread keeps the x positions / weights of its four output pixels in registers for all
+// its rows (the x tables are read once per thread, not once per row), takes its bilinear taps from LDS and writes one
+// packed word per row.  (Tapping global memory directly cost 24 dependent byte loads per four output pixels:
+// 0.63 TB/s of algorithmic traffic; the arithmetic is unchanged, bit for bit.)
+constexpr int RZ_TW = 256, RZ_TH = 16, RZ_SR = 24, RZ_SW = 320;
+
 __global__ __launch_bounds__(256) void orb_resize_kernel(OrbGeom g, const uint8_t *__restrict__ imgs,
-                                                         uint8_t *__restrict__ ws, int l) {
+                                                         uint8_t *__restrict__ ws, int l, int tw, int th) {
+    // tw x th: output tile (tw <= RZ_TW multiple of 4, th <= RZ_TH), chosen on the host so that the source footprint fits T
+    __shared__ __attribute__((aligned(16))) uint8_t T[RZ_SR][RZ_SW];
     const int b = blockIdx.z;
-    const int xq = blockIdx.x * 64 + (threadIdx.x & 63);  // group of 4 output pixels
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int wd = g.w[l], hd = g.h[l], pd = g.pitch[l];
-    if (y >= hd || xq * 4 >= pd) return;
+    const int tx0 = blockIdx.x * tw, ty0 = blockIdx.y * th;
     int ps;
     const uint8_t *src = level_ptr(g, imgs, ws, l - 1, b, ps);
     uint8_t *dst = ws + g.pyr_off[l] + (size_t)b * g.pyr_bytes[l];
     const int32_t *tab = reinterpret_cast<const int32_t *>(ws + g.tab_off[l]);
     const int ws_ = g.w[l - 1], hs_ = g.h[l - 1];
-    const int y0 = tab[2 * wd + y], wy = tab[2 * wd + hd + y];
-    const int y1 = min(y0 + 1, hs_ - 1);
-    const uint8_t *r0 = src + (size_t)y0 * ps, *r1 = src + (size_t)y1 * ps;
-    uint32_t packed = 0;
+    const int txl = min(tx0 + tw, wd) - 1, tyl = min(ty0 + th, hd) - 1;   // last output column / row of the tile
+    if (txl < tx0) {  // tile entirely inside the row padding: zero fill
+        const int rl0 = threadIdx.x >> 6, cg0 = threadIdx.x & 63;
+        for (int j = 0; j < RZ_TH / 4; ++j) {
+            const int yy = rl0 + 4 * j;
+            if (yy < th && ty0 + yy < hd && 4 * cg0 < tw && tx0 + 4 * cg0 < pd)
+                *reinterpret_cast<uint32_t *>(dst + (size_t)(ty0 + yy) * pd + tx0 + 4 * cg0) = 0;
+        }
+        return;
+    }
+    const int sx_lo = tab[tx0] & ~3, sx_hi = min(tab[txl] + 1, ws_ - 1);
+    const int sy_lo = tab[2 * wd + ty0], sy_hi = min(tab[2 * wd + tyl] + 1, hs_ - 1);
+    const int nrow = sy_hi - sy_lo + 1, nw4 = (sx_hi - sx_lo) / 4 + 1;   // <= RZ_SR, <= RZ_SW / 4
+    for (int e = threadIdx.x; e < nrow * nw4; e += 256) {
+        const int r = e / nw4, c4 = e % nw4;
+        const int x = sx_lo + 4 * c4;
+        uint32_t v = 0;
+        if (x + 3 < ps) v = *reinterpret_cast<const uint32_t *>(src + (size_t)(sy_lo + r) * ps + x);
+        else
+            for (int k = 0; k < 4; ++k)
+                if (x + k < ps) v |= (uint32_t)src[(size_t)(sy_lo + r) * ps + x + k] << (8 * k);
+        *reinterpret_cast<uint32_t *>(&T[r][4 * c4]) = v;
+    }
+    const int cg = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    int c0[4], c1[4], wx[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int x = xq * 4 + k;
-        uint32_t v = 0;
-        if (x < wd) {
-            const int x0 = tab[x], wx = tab[wd + x];
-            const int x1 = min(x0 + 1, ws_ - 1);
-            const int top = r0[x0] * (2048 - wx) + r0[x1] * wx;
-            const int bot = r1[x0] * (2048 - wx) + r1[x1] * wx;
-            v = (uint32_t)(top * (2048 - wy) + bot * wy + (1 << 21)) >> 22;
-        }
-        packed |= v << (8 * k);
+        const int x = min(tx0 + 4 * cg + k, wd - 1);
+        const int x0 = tab[x];
+        wx[k] = tab[wd + x];
+        c0[k] = x0 - sx_lo;
+        c1[k] = min(x0 + 1, ws_ - 1) - sx_lo;
     }
-    *reinterpret_cast<uint32_t *>(dst + (size_t)y * pd + xq * 4) = packed;
+    __syncthreads();
+    if (4 * cg >= tw || tx0 + 4 * cg >= pd) return;
+#pragma unroll
+    for (int j = 0; j < RZ_TH / 4; ++j) {
+        const int y = ty0 + rl + 4 * j;
+        if (rl + 4 * j >= th || y >= hd) break;
+        const int y0 = tab[2 * wd + y], wy = tab[2 * wd + hd + y];
+        const uint8_t *r0 = T[y0 - sy_lo], *r1 = T[min(y0 + 1, hs_ - 1) - sy_lo];
+        uint32_t packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t v = 0;
+            if (tx0 + 4 * cg + k < wd) {
+                const int top = r0[c0[k]] * (2048 - wx[k]) + r0[c1[k]] * wx[k];
+                const int bot = r1[c0[k]] * (2048 - wx[k]) + r1[c1[k]] * wx[k];
+                v = (uint32_t)(top * (2048 - wy) + bot * wy + (1 << 21)) >> 22;
+            }
+            packed |= v << (8 * k);
+        }
+        *reinterpret_cast<uint32_t *>(dst + (size_t)y * pd + tx0 + 4 * cg) = packed;
+    }
 }
 
 // ---- FAST-9/16 + NMS ----------------------------------------------------------------------------------------------------
@@ -639,8 +682,14 @@ int mm_orb_detect_compute(mm_ctx *ctx, const uint8_t *imgs, int batch, int heigh
     if (g.nlevels > 1) {
         MM_LAUNCH(ctx, "orb_tables_kernel", orb_tables_kernel, dim3(g.nlevels - 1), dim3(256), 0, g, w8);
         for (int l = 1; l < g.nlevels; ++l) {
-            dim3 grid((g.pitch[l] / 4 + 63) / 64, (g.h[l] + 3) / 4, batch);
-            MM_LAUNCH(ctx, "orb_resize_kernel", orb_resize_kernel, grid, dim3(256), 0, g, imgs, w8, l);
+            // output tile whose source footprint fits the kernel's LDS tile (256 x 16 for any scale factor <= 1.2)
+            const double rx = (double)g.w[l - 1] / g.w[l], ry = (double)g.h[l - 1] / g.h[l];
+            int tw = (int)((RZ_SW - 8) / rx) & ~3, th = (int)((RZ_SR - 2) / ry);
+            tw = tw > RZ_TW ? RZ_TW : (tw < 4 ? 4 : tw);
+            th = th > RZ_TH ? RZ_TH : (th < 1 ? 1 : th);
+            if (rx > (RZ_SW - 8) / 4.0 || ry > RZ_SR - 2) return mm_fail(ctx, MM_ERR_ARG, "mm_orb_detect_compute: scale factor too large");
+            dim3 grid((g.pitch[l] + tw - 1) / tw, (g.h[l] + th - 1) / th, batch);
+            MM_LAUNCH(ctx, "orb_resize_kernel", orb_resize_kernel, grid, dim3(256), 0, g, imgs, w8, l, tw, th);
         }
     }
     if (g.tile_start[g.nlevels] > 0) {
