@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void orb_resize_kernel(OrbGeom g, const uint8_
 }
 
 // ---- FAST-9/16 + NMS ----------------------------------------------------------------------------------------------------
-constexpr int FT_W = 64, FT_H = 16;        // keypoint tile
+constexpr int FT_W = 64, FT_H = 64;        // keypoint tile
 constexpr int FP_W = 80, FP_H = FT_H + 8;  // pixel tile in LDS (80 = 72 needed + alignment slack)
 constexpr int FS_W = FT_W + 2, FS_H = FT_H + 2;
 
