@@ -315,7 +315,11 @@ extern "C" int mm_trf_fused(mm_ctx *ctx, int op, const double *const *in, double
     if (op != 4 && !out) return mm_fail(ctx, MM_ERR_ARG, "mm_trf_fused: null result");
     a.h0 = h0;
     a.h1 = h1;
-    if (n == 0) return MM_OK;
+    if (n == 0) {  // nothing to map; the sums (and maxima) of an empty vector are zero
+        static const int rows[5] = {2, 3, 2, 6, 0};
+        if (rows[op]) MM_HIP(ctx, hipMemsetAsync(out, 0, (size_t)rows[op] * 3 * sizeof(double), ctx->stream));
+        return MM_OK;
+    }
     unsigned *counter = (unsigned *)ws;
     double *partial = (double *)((char *)ws + 256);
     switch (op) {

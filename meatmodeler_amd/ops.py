@@ -402,6 +402,8 @@ class BADevice:
         pout = (C.c_void_p * len(outs))(*[t.data_ptr() for t in outs])
         psc = (C.c_void_p * max(len(scalars), 1))(*[t.data_ptr() for t in scalars]) if scalars else None
         rows = self._FUSED_ROWS[op]
+        if n == 0:
+            return torch.zeros((max(rows, 1), 3), dtype=torch.float64, device=self.device)
         res = torch.empty((max(rows, 1), 3), dtype=torch.float64, device=self.device)
         self.ctx.check(lib.mm_trf_fused(self.ctx.h, op, pin, pout, psc, float(h0), float(h1), n, int(split), ptr(res), ptr(ws),
                                         ws.numel()), "mm_trf_fused")
@@ -436,6 +438,9 @@ class MultiDot:
             chunk = pairs[i0:i0 + 8]
             k = len(chunk)
             n = chunk[0][0].numel()
+            if n == 0:      # (empty tensors have no storage to point at)
+                out_all.append(torch.zeros((k, 3), dtype=torch.float64, device=self.ws.device))
+                continue
             for a, b in chunk:
                 assert a.dtype == torch.float64 and b.dtype == torch.float64 and a.is_contiguous() and b.is_contiguous()
                 assert a.numel() == n and b.numel() == n

@@ -527,6 +527,16 @@ def test_trf_fused_passes_vs_torch():
     np.testing.assert_allclose(xn.cpu().numpy(), (x + 0.3 * s1 - 1.7 * s2).cpu().numpy(), rtol=1e-15, atol=1e-15)
 
 
+def test_vector_kernels_on_empty_vectors():
+    md = ops.MultiDot(DEV)
+    e = torch.empty(0, dtype=torch.float64, device=DEV)
+    assert md([(e, e), (e, e)], 0).cpu().tolist() == [[0.0, 0.0, 0.0], [0.0, 0.0, 0.0]]
+    pr = synth.make_ba_problem(4, 10, 3, seed=1)
+    pb = ops.BADevice(pr["K"], pr["fi"], pr["pi"], pr["obs"], 4, 10, DEV)
+    r = pb.trf_fused(0, [e, e], [e.clone(), e.clone()], split=0)
+    assert r.cpu().tolist() == [[0.0, 0.0, 0.0], [0.0, 0.0, 0.0]]
+
+
 def test_trf_damping_vs_scipy_formula():
     """mm_trf_damping == the scalar recipe of SciPy trf.py:473-477 (regulariser from the Cauchy-like model along g_h)."""
     rng = np.random.default_rng(5)
