@@ -932,6 +932,43 @@ def test_sliding_window_ba_equals_window_by_window_adjustment():
     assert np.array_equal(res["points"].cpu().numpy(), pts) and np.array_equal(res["cams"].cpu().numpy(), cams)
 
 
+def test_clip_pipeline_c2_shape_match_and_triangulate():
+    """BASELINE config "1080p, 2000 key points, BF match + 2-view triangulation" on a short clip: the batched pipeline's
+    matches of two frame pairs equal the oracle's (detect -> describe -> kNN-2 -> ratio, bit exact at 1080p), every
+    track's DLT point equals the oracle's DLT of its first / last observation, and well-conditioned tracks reproject
+    to their key points."""
+    F = 6
+    frames, ext, K = synth.render_orbit_frames_torch(F, 1920, 1080, DEV, arc_deg=0.72 * F)
+    pipe = ClipPipeline(1080, 1920, 2000, batch=F)
+    out = pipe.run(frames, K, ext, ba=False)
+    ClipPipeline.tracks_to_host(out)
+    host = frames.cpu().numpy()
+    o = {i: oo.detect_compute(host[i], 2000, brief_pattern()) for i in (0, 1, 2)}
+    for k in (0, 1):
+        idx, dist = oo.bf_knn2(o[k]["desc"], o[k + 1]["desc"])
+        want = oo.ratio_filter(idx, dist, 0.75)
+        assert out["match_count"][k] == len(want)
+    xy = out["xy_dev"].cpu().numpy()
+    for i in (0, 1, 2):
+        assert np.array_equal(xy[i, :o[i]["n"]], o[i]["xy"])
+    tp, of, ok = out["track_ptr"], out["obs_frame"], out["obs_kp"]
+    first, last = tp[:-1], tp[1:] - 1
+    proj = np.einsum("ij,fjk->fik", np.asarray(K, float), np.asarray(ext, float)[:, :3, :])
+    x0 = xy[of[first], ok[first]].astype(np.float64)
+    x1 = xy[of[last], ok[last]].astype(np.float64)
+    Xo = bo.triangulate_dlt(proj[of[first]], proj[of[last]], x0, x1)
+    X = out["points0"].cpu().numpy()
+    good = np.isfinite(Xo).all(1) & (np.abs(Xo).max(1) < 1e3) & (of[last] - of[first] >= 2)
+    assert good.sum() > 200
+    np.testing.assert_allclose(X[good], Xo[good], rtol=1e-6, atol=1e-7)
+    # reprojection of the triangulated point into its first view (a consistency property; mismatches are excluded
+    # by asking for the median)
+    Xh = np.hstack([X[good], np.ones((good.sum(), 1))])
+    u = np.einsum("nij,nj->ni", proj[of[first]][good], Xh)
+    err = np.linalg.norm(u[:, :2] / u[:, 2:3] - x0[good], axis=1)
+    assert np.median(err) < 2.0
+
+
 def test_clip_pipeline_with_ba_reduces_reprojection_error():
     frames, ext, K = synth.render_orbit_frames(6, 640, 480, arc_deg=8.0)
     pipe = ClipPipeline(480, 640, 1000, batch=6)
