@@ -92,28 +92,41 @@ __device__ __forceinline__ int block_exscan(const int (&flag)[LK_IPT], int (&ran
     return s_wave[16];
 }
 
+template <bool STATE_IN_LDS>
 __global__ __launch_bounds__(LK_THREADS) void link_kernel(int F, int cap, const int32_t *__restrict__ kp_count,
                                                           const int32_t *__restrict__ match_count,
                                                           const int32_t *__restrict__ matches, LinkWs ws,
-                                                          int32_t *__restrict__ track_ptr, int64_t *__restrict__ counts,
-                                                          int state_in_lds) {
+                                                          int32_t *__restrict__ track_ptr, int64_t *__restrict__ counts) {
     // The per-pair state (first-owner table, last-match table, hit positions, the two live lists: 9 arrays of `cap`
     // words) lives in LDS when it fits (cap <= 4096: 144 KB of the CU's 160 KB) -- every phase of a pair is a dependent
     // round trip to these arrays, ~2 us each through global memory, a few hundred ns through LDS.
+    // (A template parameter, not a run-time choice, and the two live lists addressed by offset rather than through an
+    // array of pointers indexed by `cur`: with one provenance per access the compiler emits ds_* instructions.  Flat
+    // accesses to LDS count on vmcnt as well, so every read of the live lists waited for the global stores issued just
+    // before it: 8 of the 14 us of a pair.)
     extern __shared__ int32_t lds_state[];
-    int32_t *owner = ws.owner, *lastm = ws.lastm, *hitpos = ws.hitpos;
-    int32_t *live_track[2] = {ws.live_track[0], ws.live_track[1]}, *live_kp[2] = {ws.live_kp[0], ws.live_kp[1]},
-            *live_node[2] = {ws.live_node[0], ws.live_node[1]};
-    if (state_in_lds) {
+    int32_t *owner, *lastm, *hitpos;
+    if constexpr (STATE_IN_LDS) {
         owner = lds_state;
         lastm = lds_state + cap;
         hitpos = lds_state + 2 * cap;
-        for (int b = 0; b < 2; ++b) {
-            live_track[b] = lds_state + (3 + 3 * b) * cap;
-            live_kp[b] = lds_state + (4 + 3 * b) * cap;
-            live_node[b] = lds_state + (5 + 3 * b) * cap;
-        }
+    } else {
+        owner = ws.owner;
+        lastm = ws.lastm;
+        hitpos = ws.hitpos;
     }
+    auto live_track = [&](int b, int i) -> int32_t & {
+        if constexpr (STATE_IN_LDS) return lds_state[(3 + 3 * b) * cap + i];
+        else return ws.live_track[b][i];
+    };
+    auto live_kp = [&](int b, int i) -> int32_t & {
+        if constexpr (STATE_IN_LDS) return lds_state[(4 + 3 * b) * cap + i];
+        else return ws.live_kp[b][i];
+    };
+    auto live_node = [&](int b, int i) -> int32_t & {
+        if constexpr (STATE_IN_LDS) return lds_state[(5 + 3 * b) * cap + i];
+        else return ws.live_node[b][i];
+    };
     __shared__ int s_wave[17];
     __shared__ int s_T, s_ntracks, s_popbase, s_nodebase, s_bad;
     const int tid = threadIdx.x;
@@ -138,7 +151,7 @@ __global__ __launch_bounds__(LK_THREADS) void link_kernel(int F, int cap, const 
         }
         __syncthreads();
         // A: first live position per canonical key point of frame k
-        for (int pos = tid; pos < T; pos += LK_THREADS) atomicMin(&owner[ck[live_kp[cur][pos]]], pos);
+        for (int pos = tid; pos < T; pos += LK_THREADS) atomicMin(&owner[ck[live_kp(cur, pos)]], pos);
         __syncthreads();
         // B: each match finds its track (or none); the last match on a track wins
         for (int m = tid; m < M; m += LK_THREADS) {
@@ -173,40 +186,57 @@ __global__ __launch_bounds__(LK_THREADS) void link_kernel(int F, int cap, const 
         const int n_surv = block_exscan(f_surv, r_surv, s_wave);
         const int n_pop = block_exscan(f_pop, r_pop, s_wave);
         const int n_new = block_exscan(f_new, r_new, s_wave);
-        // D: next live list, observation nodes, popped tracks
+        // D: next live list, observation nodes, popped tracks.  The ranks were computed on contiguous chunks per thread;
+        // written with that mapping, the node / list stores of a wave land 8 words apart (64 cache sectors per store
+        // instruction, and the one CU's store path was 40 % of a pair).  So the ranks go through LDS and phase D runs
+        // with the interleaved mapping i = tid + 1024 q: consecutive lanes, (mostly) consecutive destinations.
+        //   rank_live (in `hitpos`):  2 r_surv  |  2 r_pop + 1  |  -1 (no live track at this position)
+        //   rank_new  (in `owner`, free since phase B):  r_new  |  -1
         const int nxt = cur ^ 1;
 #pragma unroll
         for (int q = 0; q < LK_IPT; ++q) {
             const int i = tid * LK_IPT + q;
-            if (f_surv[q]) {
-                const int tr = live_track[cur][i];
-                const int t = mk[2 * l_last[q] + 1];
-                const int nid = node_base + r_surv[q];
+            if (i < cap) {
+                const int rn = f_new[q] ? r_new[q] : -1;
+                const int rl = f_surv[q] ? 2 * r_surv[q] : (f_pop[q] ? 2 * r_pop[q] + 1 : -1);
+                owner[i] = rn;
+                hitpos[i] = rl;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < cap; i += LK_THREADS) {
+            const int rl = hitpos[i], rn = owner[i];
+            if (rl >= 0 && !(rl & 1)) {
+                const int r = rl >> 1;
+                const int tr = live_track(cur, i);
+                const int t = mk[2 * lastm[i] + 1];
+                const int nid = node_base + r;
                 ws.node_kp[nid] = t;
                 ws.node_frame[nid] = k + 1;
-                ws.node_prev[nid] = live_node[cur][i];
-                live_track[nxt][r_surv[q]] = tr;
-                live_kp[nxt][r_surv[q]] = t;
-                live_node[nxt][r_surv[q]] = nid;
-                ws.track_len[tr] += 1;
-            } else if (f_pop[q]) {
-                const int tr = live_track[cur][i];
-                ws.final_order[pop_base + r_pop[q]] = tr;
-                ws.track_tail[tr] = live_node[cur][i];
+                ws.node_prev[nid] = live_node(cur, i);
+                live_track(nxt, r) = tr;
+                live_kp(nxt, r) = t;
+                live_node(nxt, r) = nid;
+                atomicAdd(&ws.track_len[tr], 1);   // (no result needed: fire and forget)
+            } else if (rl >= 0) {
+                const int tr = live_track(cur, i);
+                ws.final_order[pop_base + (rl >> 1)] = tr;
+                ws.track_tail[tr] = live_node(cur, i);
             }
-            if (f_new[q]) {
-                const int tr = n_tracks + r_new[q];
-                const int nid = node_base + n_surv + 2 * r_new[q];
-                ws.node_kp[nid] = mk[2 * i];
+            if (rn >= 0) {
+                const int tr = n_tracks + rn;
+                const int nid = node_base + n_surv + 2 * rn;
+                const int2 qt = *reinterpret_cast<const int2 *>(mk + 2 * i);
+                ws.node_kp[nid] = qt.x;
                 ws.node_frame[nid] = k;
                 ws.node_prev[nid] = -1;
-                ws.node_kp[nid + 1] = mk[2 * i + 1];
+                ws.node_kp[nid + 1] = qt.y;
                 ws.node_frame[nid + 1] = k + 1;
                 ws.node_prev[nid + 1] = nid;
-                const int p = n_surv + r_new[q];
-                live_track[nxt][p] = tr;
-                live_kp[nxt][p] = mk[2 * i + 1];
-                live_node[nxt][p] = nid + 1;
+                const int p = n_surv + rn;
+                live_track(nxt, p) = tr;
+                live_kp(nxt, p) = qt.y;
+                live_node(nxt, p) = nid + 1;
                 ws.track_len[tr] = 2;
             }
         }
@@ -223,9 +253,9 @@ __global__ __launch_bounds__(LK_THREADS) void link_kernel(int F, int cap, const 
     // the tracks still alive come last (processor.py:418)
     const int T = s_T, n_tracks = s_ntracks, pop_base = s_popbase;
     for (int pos = tid; pos < T; pos += LK_THREADS) {
-        const int tr = live_track[cur][pos];
+        const int tr = live_track(cur, pos);
         ws.final_order[pop_base + pos] = tr;
-        ws.track_tail[tr] = live_node[cur][pos];
+        ws.track_tail[tr] = live_node(cur, pos);
     }
     __syncthreads();
     // CSR offsets in final order: chunked block scan with a running base
@@ -324,18 +354,21 @@ int mm_link_tracks_device(mm_ctx *ctx, int n_frames, int cap, const int32_t *kp_
     if (ws_bytes < carve(w, (uint8_t *)ws, n_frames, cap)) return mm_fail(ctx, MM_ERR_WORKSPACE, "mm_link_tracks_device: workspace too small");
     MM_LAUNCH(ctx, "link_canon_kernel", link_canon_kernel, dim3((cap + 255) / 256, n_frames), dim3(256), 0, cap, kp_count,
               kp_xy, w.canon);
-    const int state_in_lds = cap <= 4096;
-    const size_t lds_bytes = state_in_lds ? (size_t)9 * cap * sizeof(int32_t) : 0;
-    if (lds_bytes > 48 * 1024) {
+    const bool state_in_lds = cap <= 4096;
+    if (state_in_lds) {
+        const size_t lds_bytes = (size_t)9 * cap * sizeof(int32_t);
         static size_t lds_set = 0;
-        if (lds_bytes > lds_set) {
-            MM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(link_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)lds_bytes));
+        if (lds_bytes > 48 * 1024 && lds_bytes > lds_set) {
+            MM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(link_kernel<true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
             lds_set = lds_bytes;
         }
+        MM_LAUNCH(ctx, "link_kernel", link_kernel<true>, dim3(1), dim3(LK_THREADS), lds_bytes, n_frames, cap, kp_count,
+                  match_count, matches, w, track_ptr, counts);
+    } else {
+        MM_LAUNCH(ctx, "link_kernel", link_kernel<false>, dim3(1), dim3(LK_THREADS), 0, n_frames, cap, kp_count, match_count,
+                  matches, w, track_ptr, counts);
     }
-    MM_LAUNCH(ctx, "link_kernel", link_kernel, dim3(1), dim3(LK_THREADS), lds_bytes, n_frames, cap, kp_count, match_count,
-              matches, w, track_ptr, counts, state_in_lds);
     const size_t max_tracks = (size_t)(n_frames - 1) * cap;
     MM_LAUNCH(ctx, "link_emit_kernel", link_emit_kernel, dim3((unsigned)((max_tracks + 255) / 256)), dim3(256), 0, w,
               (const int32_t *)track_ptr, (const int64_t *)counts, obs_frame, obs_kp);
