@@ -92,6 +92,60 @@ __device__ __forceinline__ int block_exscan(const int (&flag)[LK_IPT], int (&ran
     return s_wave[16];
 }
 
+// three exclusive scans at once (same tree, one set of barriers); totals in tot[]
+__device__ __forceinline__ void block_exscan3(const int (&f0)[LK_IPT], const int (&f1)[LK_IPT], const int (&f2)[LK_IPT],
+                                              int (&r0)[LK_IPT], int (&r1)[LK_IPT], int (&r2)[LK_IPT], int (&tot)[3],
+                                              int (*s_w)[17] /*[3][17]*/) {
+    int l0 = 0, l1 = 0, l2 = 0;
+#pragma unroll
+    for (int q = 0; q < LK_IPT; ++q) {
+        r0[q] = l0;
+        r1[q] = l1;
+        r2[q] = l2;
+        l0 += f0[q];
+        l1 += f1[q];
+        l2 += f2[q];
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int i0 = l0, i1 = l1, i2 = l2;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t0 = __shfl_up(i0, off, 64), t1 = __shfl_up(i1, off, 64), t2 = __shfl_up(i2, off, 64);
+        if (lane >= off) {
+            i0 += t0;
+            i1 += t1;
+            i2 += t2;
+        }
+    }
+    __syncthreads();
+    if (lane == 63) {
+        s_w[0][w] = i0;
+        s_w[1][w] = i1;
+        s_w[2][w] = i2;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        int run = 0;
+        for (int i = 0; i < LK_THREADS / 64; ++i) {
+            const int t = s_w[threadIdx.x][i];
+            s_w[threadIdx.x][i] = run;
+            run += t;
+        }
+        s_w[threadIdx.x][16] = run;
+    }
+    __syncthreads();
+    const int b0 = s_w[0][w] + i0 - l0, b1 = s_w[1][w] + i1 - l1, b2 = s_w[2][w] + i2 - l2;
+#pragma unroll
+    for (int q = 0; q < LK_IPT; ++q) {
+        r0[q] += b0;
+        r1[q] += b1;
+        r2[q] += b2;
+    }
+    tot[0] = s_w[0][16];
+    tot[1] = s_w[1][16];
+    tot[2] = s_w[2][16];
+}
+
 template <bool STATE_IN_LDS>
 __global__ __launch_bounds__(LK_THREADS) void link_kernel(int F, int cap, const int32_t *__restrict__ kp_count,
                                                           const int32_t *__restrict__ match_count,
@@ -128,6 +182,7 @@ __global__ __launch_bounds__(LK_THREADS) void link_kernel(int F, int cap, const 
         else return ws.live_node[b][i];
     };
     __shared__ int s_wave[17];
+    __shared__ int s_wave3[3][17];
     __shared__ int s_T, s_ntracks, s_popbase, s_nodebase, s_bad;
     const int tid = threadIdx.x;
     if (tid == 0) {
@@ -183,9 +238,9 @@ __global__ __launch_bounds__(LK_THREADS) void link_kernel(int F, int cap, const 
             f_pop[q] = live && !upd;
             f_new[q] = (i < M) && hitpos[i] == -1;
         }
-        const int n_surv = block_exscan(f_surv, r_surv, s_wave);
-        const int n_pop = block_exscan(f_pop, r_pop, s_wave);
-        const int n_new = block_exscan(f_new, r_new, s_wave);
+        int tot3[3];
+        block_exscan3(f_surv, f_pop, f_new, r_surv, r_pop, r_new, tot3, s_wave3);
+        const int n_surv = tot3[0], n_pop = tot3[1], n_new = tot3[2];
         // D: next live list, observation nodes, popped tracks.  The ranks were computed on contiguous chunks per thread;
         // written with that mapping, the node / list stores of a wave land 8 words apart (64 cache sectors per store
         // instruction, and the one CU's store path was 40 % of a pair).  So the ranks go through LDS and phase D runs
