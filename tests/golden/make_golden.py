@@ -134,6 +134,17 @@ def g4_sparsity():
          shape=np.array(A.shape))
 
 
+def _similarity_align(X, Y):
+    """Least-squares similarity (the 7-DoF gauge of a free bundle adjustment) mapping X onto Y."""
+    mx, my = X.mean(0), Y.mean(0)
+    Xc, Yc = X - mx, Y - my
+    U, S, Vt = np.linalg.svd(Yc.T @ Xc)
+    D = np.diag([1, 1, np.sign(np.linalg.det(U @ Vt))])
+    R = U @ D @ Vt
+    s = np.trace(np.diag(S) @ D) / (Xc ** 2).sum()
+    return s * Xc @ R.T + my
+
+
 def _run_adjust(pr):
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf), np.errstate(all="ignore"):
@@ -155,13 +166,26 @@ def g5_adjust_points():
         with contextlib.redirect_stdout(io.StringIO()):
             r1 = least_squares(ref_ba.pointFun, x0, jac_sparsity=A, verbose=2, x_scale="jac", ftol=1e-4,
                                method="trf", args=args)  # bundleAdjuster.py:180-192 verbatim settings
-            r2 = least_squares(ref_ba.pointFun, x0, jac_sparsity=A, verbose=0, x_scale="jac",
-                               ftol=1e-12, xtol=1e-12, gtol=1e-12, method="trf", args=args, max_nfev=400)
+            # G5(ii): the SAME reference cost function and sparsity driven to the minimiser.  With the reference's
+            # own settings (2-point differences, LSMR at its default 1e-6) a 400-evaluation run was still creeping
+            # (round 1: status 0), so the inner solve is tightened (LSMR atol = btol = 1e-14) and the differences are
+            # 3-point; the run then stops on ftol in 10-20 evaluations, and a second, differently configured run
+            # (2-point differences) lands on the same minimiser modulo the 7-DoF gauge: recorded as
+            # `tight_repro_aligned` (similarity-aligned max point difference / scene size, 4e-7..8e-7).
+            tight = dict(jac_sparsity=A, verbose=0, x_scale="jac", ftol=1e-13, xtol=1e-13, gtol=1e-13, method="trf",
+                         args=args, max_nfev=3000, tr_solver="lsmr", tr_options=dict(atol=1e-14, btol=1e-14))
+            r2 = least_squares(ref_ba.pointFun, x0, jac="3-point", **tight)
+            r3 = least_squares(ref_ba.pointFun, x0, jac="2-point", **tight)
+        assert r2.status > 0 and r3.status > 0, (r2.status, r3.status)
+        p2, p3 = r2.x[6 * F:].reshape(P, 3), r3.x[6 * F:].reshape(P, 3)
+        repro = float(np.abs(_similarity_align(p3, p2) - p2).max() / np.abs(p2).max())
+        assert repro < 1e-5, repro
         assert np.allclose(r1.x[6 * F:].reshape(P, 3), pts, rtol=0, atol=0)
         save(f"g5_adjust_points_{tag}.npz", F=F, P=P, L=L, seed=seed, x0=x0, points=pts, extrinsics=exts,
              x_ref=r1.x, cost_ref=r1.cost, nfev_ref=r1.nfev, njev_ref=r1.njev, optimality_ref=r1.optimality,
              status_ref=r1.status, x_tight=r2.x, cost_tight=r2.cost, nfev_tight=r2.nfev,
-             status_tight=r2.status, cost0=0.5 * float(r1.fun @ r1.fun) * 0 + 0.5 * float(
+             status_tight=r2.status, optimality_tight=r2.optimality, tight_repro_aligned=repro,
+             cost_tight_2pt=r3.cost, nfev_tight_2pt=r3.nfev, cost0=0.5 * float(r1.fun @ r1.fun) * 0 + 0.5 * float(
                  ref_ba.pointFun(x0, *args) @ ref_ba.pointFun(x0, *args)))
         meta[tag] = dict(table=table, nfev=int(r1.nfev), status=int(r1.status))
     meta["versions"] = VERS
@@ -268,13 +292,9 @@ def g8_track_api():
 
 
 if __name__ == "__main__":
-    g1_rotate_project()
-    g2_frame_parameters()
-    g3_point_pose_fun()
-    g4_sparsity()
-    g5_adjust_points()
-    g6_adjust_pose()
-    g7_point_tracking()
-    g8_track_api()
+    todo = dict(g1=g1_rotate_project, g2=g2_frame_parameters, g3=g3_point_pose_fun, g4=g4_sparsity,
+                g5=g5_adjust_points, g6=g6_adjust_pose, g7=g7_point_tracking, g8=g8_track_api)
+    for name in (sys.argv[1:] or list(todo)):          # `make_golden.py g5` regenerates one family
+        todo[name]()
     with open(os.path.join(HERE, "VERSIONS.json"), "w") as fh:
         json.dump(VERS, fh)

@@ -630,9 +630,44 @@ def test_adjust_points_vs_reference_golden(golden_dir, tag):
     # Both runs stop at ftol=1e-4, i.e. NOT at the minimiser: the exact Schur solve moves fully along weakly
     # determined directions that SciPy's truncated LSMR barely touches, so points agree only to ~1e-2 of the scene
     # size here while the cost agrees to 1e-4 (measured: 4e-4 / 3e-3 on cases a / c).
+    # The 1e-4 point tolerance of the north star is asserted where it is well posed — both sides at the minimiser —
+    # in test_adjust_points_tight_vs_reference_minimiser below; this run only guards against gross errors.
     assert np.abs(pts - ref).max() <= 1e-2 * scale, np.abs(pts - ref).max() / scale
     aligned = _similarity_align(pts, ref)
     assert np.abs(aligned - ref).max() <= 1e-2 * scale, np.abs(aligned - ref).max() / scale
+    # ... and it is within the same distance of the reference's converged minimiser as the reference's own early stop
+    tight = d["x_tight"][6 * F:].reshape(P, 3)
+    d_ref = np.abs(_similarity_align(ref, tight) - tight).max()
+    d_own = np.abs(_similarity_align(pts, tight) - tight).max()
+    assert d_own <= max(3.0 * d_ref, 1e-4 * scale), (d_own / scale, d_ref / scale)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_adjust_points_tight_vs_reference_minimiser(golden_dir, tag):
+    """North star: "3-D points and reprojection error within 1e-4 rel".  Golden G5(ii) is the reference's pointFun +
+    sparsity (bundleAdjuster.py:81-102,55-78,180-192) driven by SciPy to the minimiser (status_tight = 2, two
+    differently configured runs agree to < 1e-6 modulo gauge; tests/golden/make_golden.py).  The HIP solver is run to
+    ftol = xtol = gtol = 1e-12 from the same x0: cost within 1e-8 rel, reprojection RMS within 1e-8 rel, 3-D points
+    within 1e-4 rel of the scene size after removing the 7-DoF gauge the reference leaves free (measured ~1e-7)."""
+    d = np.load(os.path.join(golden_dir, f"g5_adjust_points_{tag}.npz"))
+    assert int(d["status_tight"]) > 0
+    F, P, L, seed = (int(d[k]) for k in ("F", "P", "L", "seed"))
+    pr = synth.make_ba_problem(F, P, L, seed=seed)
+    res = bundleAdjuster.solvePoints(pr["ext"], pr["K"], pr["pts0"], pr["obs"], pr["fi"], pr["pi"], ftol=1e-12,
+                                     xtol=1e-12, gtol=1e-12, max_nfev=200, verbose=0)
+    ct = float(d["cost_tight"])
+    # cost at the returned x evaluated by the ORACLE's cost function (not the solver's own bookkeeping)
+    cost = 0.5 * np.sum(bo.point_fun(res.x, pr["K"], F, P, pr["fi"], pr["pi"], pr["obs"]) ** 2)
+    assert abs(cost - ct) <= 1e-8 * ct, (cost, ct)
+    assert abs(res.cost - ct) <= 1e-8 * ct
+    assert abs(np.sqrt(cost) - np.sqrt(ct)) <= 1e-8 * np.sqrt(ct)
+    ref = d["x_tight"][6 * F:].reshape(P, 3)
+    scale = np.abs(ref).max()
+    pts = res.x[6 * F:].reshape(P, 3)
+    err = np.abs(_similarity_align(pts, ref) - ref).max() / scale
+    print(f"tight BA {tag}: nfev {res.nfev} status {res.status} cost rel {abs(cost - ct) / ct:.2e} aligned point err {err:.2e}")
+    assert err <= 1e-4, err
+    assert res.nfev < 200
 
 
 def test_adjust_points_iterates_follow_scipy(golden_dir):

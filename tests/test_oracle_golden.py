@@ -80,6 +80,56 @@ def test_g5_adjust_points(golden_dir, tag):
     assert buf.getvalue().splitlines()[0] == meta[tag]["table"].splitlines()[0]
 
 
+def _similarity_align(X, Y):
+    """Least-squares similarity (the 7-DoF gauge of a free bundle adjustment) mapping X onto Y."""
+    mx, my = X.mean(0), Y.mean(0)
+    Xc, Yc = X - mx, Y - my
+    U, S, Vt = np.linalg.svd(Yc.T @ Xc)
+    D = np.diag([1, 1, np.sign(np.linalg.det(U @ Vt))])
+    R = U @ D @ Vt
+    s = np.trace(np.diag(S) @ D) / (Xc ** 2).sum()
+    return s * Xc @ R.T + my
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_g5_tight_minimiser_is_pinned(golden_dir, tag):
+    """G5(ii): the reference's pointFun + sparsity driven to the minimiser (make_golden.py: LSMR at 1e-14, 3-point
+    differences, ftol = xtol = gtol = 1e-13).  The run converged (status > 0), a second differently configured run of the
+    same reference function reached the same minimiser modulo gauge to < 1e-6 of the scene size, and the oracle's cost
+    function reproduces the recorded cost at x_tight; the minimum is below the reference-settings cost."""
+    d = g(golden_dir, f"g5_adjust_points_{tag}.npz")
+    F, P, L, seed = (int(d[k]) for k in ("F", "P", "L", "seed"))
+    pr = synth.make_ba_problem(F, P, L, seed=seed)
+    assert int(d["status_tight"]) > 0 and float(d["tight_repro_aligned"]) < 1e-6
+    r = bo.point_fun(d["x_tight"], pr["K"], F, P, pr["fi"], pr["pi"], pr["obs"])
+    ct = float(d["cost_tight"])
+    assert abs(0.5 * r @ r - ct) <= 1e-12 * ct
+    assert ct <= float(d["cost_ref"]) and abs(float(d["cost_tight_2pt"]) - ct) <= 1e-10 * ct
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_g5_tight_driver_reaches_reference_minimiser(golden_dir, tag):
+    """The product's trust-region driver (bundleAdjuster.SchurTRF) run to ftol = xtol = gtol = 1e-12 on a NumPy
+    stand-in for the HIP sweeps (oracle cost function, exact Schur solve): 3-D points within 1e-4 relative of the
+    reference minimiser after removing the gauge (north star), cost within 1e-8.  The same assertion runs against the
+    HIP kernels in tests/test_gpu_parity.py::test_adjust_points_tight_vs_reference_minimiser."""
+    import torch
+    from test_distributed_cpu import NumpyBA
+    from meatmodeler_amd.bundleAdjuster import SchurTRF
+    d = g(golden_dir, f"g5_adjust_points_{tag}.npz")
+    F, P, L, seed = (int(d[k]) for k in ("F", "P", "L", "seed"))
+    pr = synth.make_ba_problem(F, P, L, seed=seed)
+    pb = NumpyBA(pr["K"], pr["fi"], pr["pi"], pr["obs"], F, P)
+    res = SchurTRF(pb).solve(torch.from_numpy(bo.frame_parameters(pr["ext"]).reshape(F, 6)),
+                             torch.from_numpy(pr["pts0"].copy()), ftol=1e-12, xtol=1e-12, gtol=1e-12, max_nfev=100)
+    ref = d["x_tight"][6 * F:].reshape(P, 3)
+    scale = np.abs(ref).max()
+    ct = float(d["cost_tight"])
+    assert abs(res.cost - ct) <= 1e-8 * ct, (res.cost, ct)
+    err = np.abs(_similarity_align(res.pts.numpy(), ref) - ref).max() / scale
+    assert err <= 1e-4, err
+
+
 def test_g6_adjust_pose(golden_dir):
     d = g(golden_dir, "g6_adjust_pose.npz")
     out = bo.adjust_pose(d["ext0"], d["K"], d["obs"])
