@@ -156,10 +156,10 @@ def main():
     d = dist if use_dist else None
 
     def step(timers=None):
-        if a.ba_window > 0 and not use_dist:
-            o = pipe.run(frames, K, ext, ba=False, dist=None, timers=timers)
+        if a.ba_window > 0:
+            o = pipe.run(frames, K, ext, ba=False, dist=d, timers=timers)
             o["windows"] = pipe.adjust_windows(o, K, ext, window=a.ba_window, stride=a.ba_stride or max(1, a.ba_window // 2),
-                                               ftol=1e-4, timers=timers)["windows"]
+                                               ftol=1e-4, timers=timers, dist=d)["windows"]
             return o
         return pipe.run(frames, K, ext, ba=not a.no_ba, ftol=1e-4, verbose=a.verbose, dist=d, timers=timers)
 

@@ -256,19 +256,20 @@ class SchurTRF:
         """[<a, b> for (a, b) in pairs] as a device vector; the camera part of the parameter vector is replicated on
         every rank, the point part is sharded."""
         out = self.pb.multi_dot(pairs, self.nc)          # [k, 3] = (camera part, point part, total), one launch
-        if self.allreduce is None:
-            return out[:, 2]
-        pts = out[:, 1].contiguous()
-        self.allreduce(pts)
-        return out[:, 0] + pts
+        return self._combine(out)
 
     def _combine(self, rows):
         """rows [k, 3] of a fused pass -> [k] totals (the point part is summed across ranks when sharded)."""
         if self.allreduce is None:
             return rows[:, 2]
-        pts = rows[:, 1].contiguous()
-        self.allreduce(pts)
-        return rows[:, 0] + pts
+        # The camera part is replicated, but its reduction tree depends on the LOCAL vector length (shards differ), so
+        # the ranks' copies differ in the last bit.  Rank 0's copy is the one that enters the sum: every rank then
+        # holds the same scalars bit for bit, takes the same accept / reject / terminate decisions and stays inside the
+        # same sequence of collectives.
+        t = (rows[:, 0] + rows[:, 1]) if getattr(self.allreduce, "rank", 0) == 0 else rows[:, 1].clone()
+        t = t.contiguous()
+        self.allreduce(t)
+        return t
 
     def _dots_sharded(self, pairs):
         """Inner products of residual-space vectors (every rank holds its own observations)."""
@@ -299,6 +300,13 @@ class SchurTRF:
         sip2_6[:, self.diag_idx] = (si[nc:] * si[nc:]).view(P, 3)
         return sic2_36, sip2_6
 
+    def _serial_fallback(self, x, Bd, Cd, gc, gp, half_bw, solve=True):
+        warnings.warn("mm_ba_schur_solve: kernels are being serialised; building and solving the reduced system one "
+                      "after the other from here on")
+        self.pb.overlap = False
+        if solve:
+            return self.pb.schur_solve(self._cams(x), self._pts(x), Bd, Cd, gc, gp, half_bw)
+
     def solve(self, cams0, pts0, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None, verbose=0, local_points_norm=None):
         pb = self.pb
         dev = pb.device
@@ -318,7 +326,15 @@ class SchurTRF:
         span = torch.tensor([float(pb.cam_span)], **f64)
         if self.allreduce is not None:
             self.allreduce(span, op="max")
-        half_bw = 6 * int(span.item()) + 5
+        span_all = int(span.item())
+        half_bw = 6 * span_all + 5
+        # Sharded: what is exchanged for the reduced camera system is decided from GLOBAL quantities only, so that every
+        # rank enters the same collective with the same size whatever its own shard looks like (a rank whose points
+        # include one very long track, or no observation at all, builds S with the general kernel; the others with the
+        # pair-list kernel).  Every rank's S is zero outside the lower band |i - j| <= half_bw or symmetric inside it,
+        # so the packed band [n, half_bw + 1] carries everything the factorisation reads.
+        band_exchange = (self.allreduce is not None and hasattr(pb, "band_view")
+                         and span_all <= getattr(pb, "max_band_span", 192) and half_bw < nc)
         nfev, njev = 1, 1
         B, C = self._normal(x, g)
         si = self._scale_inv(B, C)
@@ -380,16 +396,13 @@ class SchurTRF:
                         # serialises kernels starves the consumer, which then gives up with info = -1)
                         self._overlap_checked = True
                         if int(info.item()) < 0:
-                            warnings.warn("mm_ba_schur_solve: kernels are being serialised; building and solving the "
-                                          "reduced system one after the other from here on")
-                            pb.overlap = False
-                            info, v, Cinv = pb.schur_solve(self._cams(x), self._pts(x), Bd, Cd, gc, gp, half_bw)
+                            info, v, Cinv = self._serial_fallback(x, Bd, Cd, gc, gp, half_bw)
                 else:
                     S, v, Cinv = pb.schur(self._cams(x), self._pts(x), Bd, Cd, gc, gp)
                 if self.allreduce is not None:
                     # every rank added the full blockdiag(Bd) and gc: remove the duplicates after the sum
                     ws = self.allreduce.world_size
-                    if hasattr(pb, "band_view") and pb.n_pairs > 0:
+                    if band_exchange:
                         # only the lower band is populated (pair-list Schur kernel): exchange n x (hb + 1) doubles
                         # (12.7 MB at 500 cameras) instead of the dense 72 MB
                         band = pb.band_view(half_bw)
@@ -428,6 +441,12 @@ class SchurTRF:
                 if int(vals[0]) == 0:
                     break
                 if int(vals[0]) < 0:
+                    # the single-launch factorisation gave up waiting (its workgroups or the producer of S were not
+                    # co-resident: another tenant, a profiler attaching mid-run).  One GPU: redo this attempt with the
+                    # build and the solve one after the other and stay there; otherwise there is nothing to fall back to.
+                    if self.allreduce is None and getattr(pb, "overlap", False):
+                        self._serial_fallback(x, Bd, Cd, gc, gp, half_bw, solve=False)
+                        continue
                     raise MMError("mm_chol_solve: the fused banded factorisation was abandoned (info = -1)")
                 reg_eff = reg_eff * 100.0
                 if vals[-1] <= self.min_damping * (1.0 + 1e-12):      # failed AT the floor: the floor was too low

@@ -50,11 +50,62 @@ __device__ __forceinline__ bool coef_table_fill(CamCoef *tab, const double *__re
     return true;
 }
 
+// Camera parameters + rotation coefficients held as VALUES (11 doubles).  A wave that works on one camera makes them
+// wave-uniform with cam_vals_uniform(): they then live in scalar registers and reach the f64 FMAs as SGPR operands
+// instead of occupying 22 vector registers per camera.
+struct CamVals {
+    double rx, ry, rz, tx, ty, tz;
+    CamCoef k;
+};
+
+__device__ __forceinline__ double uniform_f64(double x) {
+    const unsigned long long u = __double_as_longlong(x);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((int)(u & 0xffffffffu));
+    const unsigned hi = __builtin_amdgcn_readfirstlane((int)(u >> 32));
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
+__device__ __forceinline__ CamVals cam_vals_uniform(const double *__restrict__ cam) {
+    const CamCoef k = cam_coef_of(cam);
+    CamVals v;
+    v.rx = uniform_f64(cam[0]);
+    v.ry = uniform_f64(cam[1]);
+    v.rz = uniform_f64(cam[2]);
+    v.tx = uniform_f64(cam[3]);
+    v.ty = uniform_f64(cam[4]);
+    v.tz = uniform_f64(cam[5]);
+    v.k.c = uniform_f64(k.c);
+    v.k.a = uniform_f64(k.a);
+    v.k.b = uniform_f64(k.b);
+    v.k.a1 = uniform_f64(k.a1);
+    v.k.b1 = uniform_f64(k.b1);
+    return v;
+}
+
+template <bool WANT_JC, bool WANT_JP>
+__device__ __forceinline__ void ba_eval_vals(const CamVals &cv, const double *__restrict__ Xp, const double *__restrict__ K,
+                                             double ox, double oy, Proj &o);
+
 template <bool WANT_JC, bool WANT_JP>
 __device__ __forceinline__ void ba_eval_cc(const double *__restrict__ cam, const CamCoef &cc,
                                            const double *__restrict__ Xp, const double *__restrict__ K, double ox,
                                            double oy, Proj &o) {
-    const double rx = cam[0], ry = cam[1], rz = cam[2];
+    CamVals cv;
+    cv.rx = cam[0];
+    cv.ry = cam[1];
+    cv.rz = cam[2];
+    cv.tx = cam[3];
+    cv.ty = cam[4];
+    cv.tz = cam[5];
+    cv.k = cc;
+    ba_eval_vals<WANT_JC, WANT_JP>(cv, Xp, K, ox, oy, o);
+}
+
+template <bool WANT_JC, bool WANT_JP>
+__device__ __forceinline__ void ba_eval_vals(const CamVals &cv, const double *__restrict__ Xp, const double *__restrict__ K,
+                                             double ox, double oy, Proj &o) {
+    const double rx = cv.rx, ry = cv.ry, rz = cv.rz;
+    const CamCoef &cc = cv.k;
     const double X0 = Xp[0], X1 = Xp[1], X2 = Xp[2];
     const double c = cc.c, a = cc.a, b = cc.b, a1 = cc.a1, b1 = cc.b1;
     // r x X and r.X
@@ -63,7 +114,7 @@ __device__ __forceinline__ void ba_eval_cc(const double *__restrict__ cam, const
     const double Xr0 = c * X0 + a * cx0 + b * rdx * rx;
     const double Xr1 = c * X1 + a * cx1 + b * rdx * ry;
     const double Xr2 = c * X2 + a * cx2 + b * rdx * rz;
-    const double Y0 = Xr0 + cam[3], Y1 = Xr1 + cam[4], Y2 = Xr2 + cam[5];
+    const double Y0 = Xr0 + cv.tx, Y1 = Xr1 + cv.ty, Y2 = Xr2 + cv.tz;
     const double u0 = K[0] * Y0 + K[1] * Y1 + K[2] * Y2;
     const double u1 = K[3] * Y0 + K[4] * Y1 + K[5] * Y2;
     const double u2 = K[6] * Y0 + K[7] * Y1 + K[8] * Y2;

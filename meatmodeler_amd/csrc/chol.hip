@@ -1152,11 +1152,10 @@ int mm_chol_solve_gated(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int 
     if (slab_ready && !mm_chol_fused_eligible(n, half_bandwidth))
         return mm_fail(ctx, MM_ERR_ARG, "mm_chol_solve_gated: gating needs the single-launch factorisation");
     if (fused_mode > 0 && nblk >= 2 && bwb >= 1 && bwb <= FUSED_MAX_BWB) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        if (!ctx->attr_chol_fused) {
             MM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(chol_band_fused_kernel<2>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS_BYTES));
-            attr_set = true;
+            ctx->attr_chol_fused = true;
         }
         int32_t *flags = (int32_t *)((char *)ytmp + mm_align_up((size_t)(n + NB) * sizeof(double), 256));
         const size_t nflags = 2 * (size_t)nblk * (bwb + 1) + 2 * nblk + 1;
@@ -1192,11 +1191,10 @@ int mm_chol_solve_gated(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int 
                       (const double *)(Linv + (size_t)k * NB * NB), bc, ytmp, n, k0, row_end);
         }
         if (fused_mode > 0 && nblk >= 2 && bwb >= 1 && bwb <= FUSED_MAX_BWB) {  // L^T x = y in one launch
-            static bool bwd_attr_set = false;
-            if (!bwd_attr_set) {
+            if (!ctx->attr_chol_bwd) {
                 MM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(chol_band_bwd_kernel),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_LDS_BYTES));
-                bwd_attr_set = true;
+                ctx->attr_chol_bwd = true;
             }
             int32_t *flags = (int32_t *)((char *)ytmp + mm_align_up((size_t)(n + NB) * sizeof(double), 256));
             double *contrib = (double *)((char *)flags + mm_align_up((2 * (size_t)nblk * (FUSED_MAX_BWB + 1) + 2 * nblk + 64) * sizeof(int32_t), 256));

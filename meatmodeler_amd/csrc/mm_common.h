@@ -23,6 +23,8 @@ struct mm_ctx {
     // second stream + fork/join events for overlapping the reduced-system build with its factorisation (lazily created)
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // one-time kernel attributes (dynamic LDS opt-in) are per device: remembered per context, not per process
+    bool attr_chol_fused = false, attr_chol_bwd = false;
 };
 
 // launches of the enclosed scope go to another stream of the context

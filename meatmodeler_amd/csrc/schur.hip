@@ -142,8 +142,8 @@ __global__ __launch_bounds__(64 * SP_WAVES, 2) void schur_pairs_kernel(mm_ba_pro
     const int seg = pb.seg_ids[sidx];
     const int i = seg / (pb.cam_span + 1), d = seg % (pb.cam_span + 1);
     const int f2 = i - d;
-    const double *ci_cam = cams + (size_t)i * 6, *c2_cam = cams + (size_t)f2 * 6;
-    const CamCoef cc_i = cam_coef_of(ci_cam), cc_2 = cam_coef_of(c2_cam);  // two cameras per chunk, not per pair
+    // two cameras per chunk, not per pair: parameters and rotation coefficients as wave-uniform scalars
+    const CamVals cv_i = cam_vals_uniform(cams + (size_t)i * 6), cv_2 = cam_vals_uniform(cams + (size_t)f2 * 6);
     double acc[42];
 #pragma unroll
     for (int q = 0; q < 42; ++q) acc[q] = 0.0;
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(64 * SP_WAVES, 2) void schur_pairs_kernel(mm_ba_pro
         const int p = pb.pi[o];
         const double *Xp = pts + (size_t)p * 3;
         Proj pr;
-        ba_eval_cc<true, true>(ci_cam, cc_i, Xp, Ks, pb.obs[2 * (size_t)o], pb.obs[2 * (size_t)o + 1], pr);
+        ba_eval_vals<true, true>(cv_i, Xp, Ks, pb.obs[2 * (size_t)o], pb.obs[2 * (size_t)o + 1], pr);
         const double *ci = Cinv + (size_t)p * 6;
         const double q00 = ci[0], q01 = ci[1], q02 = ci[2], q11 = ci[3], q12 = ci[4], q22 = ci[5];
         double Y[6][3];
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(64 * SP_WAVES, 2) void schur_pairs_kernel(mm_ba_pro
             for (int a = 0; a < 6; ++a) acc[36 + a] += Y[a][0] * g0 + Y[a][1] * g1 + Y[a][2] * g2;
         }
         Proj p2;
-        ba_eval_cc<true, true>(c2_cam, cc_2, Xp, Ks, pb.obs[2 * (size_t)o2], pb.obs[2 * (size_t)o2 + 1], p2);
+        ba_eval_vals<true, true>(cv_2, Xp, Ks, pb.obs[2 * (size_t)o2], pb.obs[2 * (size_t)o2 + 1], p2);
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
             const double x0 = p2.Jc[0][b] * p2.Jp[0][0] + p2.Jc[1][b] * p2.Jp[1][0];
@@ -425,7 +425,11 @@ extern "C" int mm_ba_schur_solve(mm_ctx *ctx, const mm_ba_problem *pb, const dou
     {   // the consumer goes first, so that its workgroups are resident before the producer floods the CUs
         mm_stream_swap sw(ctx, ctx->aux);
         int rc = mm_chol_solve_gated(ctx, S, n, v, 1, half_bandwidth, info, ws_chol, ws_chol_bytes, w.slab_ready, cams_per_slab, pb->F);
-        if (rc) return rc;
+        if (rc) {  // whatever did get enqueued on the second stream is joined before the error travels up
+            (void)hipEventRecord(ctx->ev_join, ctx->aux);
+            (void)hipStreamWaitEvent(sw.saved, ctx->ev_join, 0);
+            return rc;
+        }
         MM_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
     }
     // ONE launch builds all of S; chunks are ordered by camera, so the slabs complete roughly in ascending order and

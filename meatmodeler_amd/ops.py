@@ -131,6 +131,9 @@ def triangulate_dlt(proj, f0, f1, x0, x1, ctx=None):
     n = f0.shape[0]
     X = torch.empty((n, 3), dtype=torch.float64, device=proj.device)
     if n:
+        lim = torch.stack([f0.min(), f1.min(), f0.max(), f1.max()]).tolist()
+        if min(lim[:2]) < 0 or max(lim[2:]) >= proj.shape[0]:
+            raise IndexError("triangulate_dlt: frame index outside the projection table")
         ctx.check(lib.mm_triangulate_dlt(ctx.h, ptr(proj.contiguous()), ptr(_i32(f0)), ptr(_i32(f1)),
                                          ptr(x0.contiguous()), ptr(x1.contiguous()), n, ptr(X)), "mm_triangulate_dlt")
     return X
@@ -227,6 +230,7 @@ class BADevice:
         else:
             self.cam_obs = torch.zeros(0, dtype=torch.int32, device=dev)
         self.cam_span = 0
+        self.max_band_span = int(max_band_span)
         self.slabs = None
         # build + solve overlapped on two streams (mm_ba_schur_solve).  Needs concurrent kernel execution: tools that
         # serialise kernels (rocprofv3 --pmc, launch-blocking debug modes) make the consumer wait for a producer that

@@ -42,16 +42,39 @@ def partition_points(fi, pi, n_points, rank, world):
     return lo, hi, mask
 
 
-def partition_tracks(track_ptr, rank, world):
-    """Same split for CSR tracks (point-major observations): -> (p_lo, p_hi, o_lo, o_hi) — the rank's points and
-    the contiguous observation range that belongs to them."""
-    track_ptr = np.asarray(track_ptr)
-    P = len(track_ptr) - 1
-    total = int(track_ptr[-1])
-    bounds = [int(np.searchsorted(track_ptr, total * r / world, side="left")) for r in range(world)] + [P]
+def split_by_weight(cum, world):
+    """Contiguous split of items 0..n-1 into `world` parts balanced by weight.  cum [n+1] = exclusive running sum of the
+    weights (non-decreasing integers, cum[0] = 0; numpy array or device tensor).  -> list of world + 1 item bounds.
+    Part r starts at the first item whose running sum reaches total * r / world (integer arithmetic: ceil)."""
+    n = len(cum) - 1
+    try:
+        import torch
+        is_t = torch.is_tensor(cum)
+    except ImportError:
+        is_t = False
+    if is_t:
+        c = cum.to(torch.int64)
+        total = int(c[-1].item())
+        tg = torch.tensor([-(-total * r // world) for r in range(world)], dtype=torch.int64, device=c.device)
+        bounds = torch.searchsorted(c, tg, right=False).tolist() + [n]
+    else:
+        c = np.asarray(cum).astype(np.int64)
+        total = int(c[-1])
+        bounds = [int(np.searchsorted(c, -(-total * r // world), side="left")) for r in range(world)] + [n]
     bounds[0] = 0
     for r in range(1, world + 1):
-        bounds[r] = min(max(bounds[r], bounds[r - 1]), P)
+        bounds[r] = min(max(bounds[r], bounds[r - 1]), n)
+    if n >= world:          # no empty part as long as there are enough items (one very heavy item cannot starve a rank)
+        for r in range(1, world):
+            bounds[r] = min(max(bounds[r], bounds[r - 1] + 1), n - (world - r))
+    return bounds
+
+
+def partition_tracks(track_ptr, rank, world):
+    """Same split for CSR tracks (point-major observations): -> (p_lo, p_hi, o_lo, o_hi) — the rank's points and
+    the contiguous observation range that belongs to them.  `track_ptr` may be a device tensor (two small read-backs,
+    the CSR itself stays on the device)."""
+    bounds = split_by_weight(track_ptr, world)
     lo, hi = bounds[rank], bounds[rank + 1]
     return lo, hi, int(track_ptr[lo]), int(track_ptr[hi])
 
@@ -64,6 +87,7 @@ class AllReduce:
         self.dist = dist
         self.group = group
         self.world_size = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
 
     def __call__(self, tensor, op="sum"):
         if self.world_size == 1:
@@ -90,3 +114,20 @@ def gather_varlen(local, world, dist, group=None):
     outs = [torch.zeros_like(buf) for _ in range(world)]
     dist.all_gather(outs, buf, group=group)
     return [o[:s].cpu().numpy() for o, s in zip(outs, sizes)]
+
+
+def gather_blocks(local, counts, dist, group=None):
+    """All-gather of per-rank blocks of rows whose row counts are known everywhere (block partitions are pure
+    arithmetic on (n, world)): `local` [counts[rank], ...] device (or CPU) tensor -> [sum(counts), ...] on the same
+    device, rank order.  Stays on the device for "nccl" (RCCL over xGMI); no size exchange, no host copy."""
+    import torch
+    world = len(counts)
+    rank = dist.get_rank(group)
+    assert local.shape[0] == counts[rank], (local.shape, counts, rank)
+    m = max(max(counts), 1)
+    tail = tuple(local.shape[1:])
+    buf = torch.zeros((m,) + tail, dtype=local.dtype, device=local.device)
+    buf[:counts[rank]] = local
+    outs = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(outs, buf, group=group)
+    return torch.cat([o[:c] for o, c in zip(outs, counts)], 0)

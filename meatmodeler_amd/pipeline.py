@@ -131,7 +131,7 @@ class ClipPipeline:
             return inside
         return inside & (last_frame <= hi - 2)
 
-    def adjust_windows(self, out, K, extrinsics, window=50, stride=25, ftol=1e-4, verbose=0, timers=None):
+    def adjust_windows(self, out, K, extrinsics, window=50, stride=25, ftol=1e-4, verbose=0, timers=None, dist=None):
         """Incremental bundle adjustment over a sliding window of keyframes: the reference keeps this step as a
         commented hook (processor.py:395-408: after a keyframe whose tracks were popped, `managePoints(popped_tracks)`
         + `adjustPoints` over everything so far); bounding it to the last `window` keyframes is what makes the
@@ -140,8 +140,16 @@ class ClipPipeline:
         exactly the solver of `adjustPoints` (all window cameras and points free, ftol as given); camera parameters and
         points are written back and later windows start from them.
 
+        With `dist` (torch.distributed, every rank holding the same linked tracks as `run(..., dist=dist)` leaves them)
+        each window's points are split over the ranks by observation count, cameras are replicated, and the solver
+        all-reduces the camera-side blocks exactly as the global adjustment does ("C5 sliding
+        window: same, with F replaced by W"); the adjusted points of a window are re-assembled on every rank.
+
         `out` is the result of `run(..., ba=False)`.  -> dict(cams [F,6] device, points [T,3] device, windows=[...])."""
         d = self.device
+        world = dist.get_world_size() if dist is not None else 1
+        rank = dist.get_rank() if dist is not None else 0
+        allreduce = parallel.AllReduce() if world > 1 else None
         F = int(np.asarray(extrinsics).shape[0])
         tp, of_, ok = out["track_ptr_dev"], out["obs_frame_dev"], out["obs_kp_dev"]
         xy = out["xy_dev"]
@@ -165,6 +173,17 @@ class ClipPipeline:
             if P == 0:
                 continue
             lens = lens_all[sel]
+            P_all, p_lo, p_hi = P, 0, P
+            if world > 1 and P >= 4 * world:
+                # this rank's contiguous share of the window's points (balanced by observations); tiny windows are
+                # solved redundantly on every rank (identical, deterministic) rather than with empty shards
+                cum = torch.cat([torch.zeros(1, dtype=torch.int64, device=d), torch.cumsum(lens, 0)])
+                bounds = parallel.split_by_weight(cum, world)
+                p_lo, p_hi = bounds[rank], bounds[rank + 1]
+                sel_all, sel = sel, sel[p_lo:p_hi]
+                lens = lens[p_lo:p_hi]
+                P = p_hi - p_lo
+            sharded = world > 1 and P_all >= 4 * world
             O = int(lens.sum().item())
             # observation indices of the selected tracks, point-major (managePoints order)
             starts = tp64[sel]
@@ -174,10 +193,21 @@ class ClipPipeline:
             pi = torch.repeat_interleave(torch.arange(P, dtype=torch.int32, device=d), lens, output_size=O)
             coords = xy[of_[oi].long(), ok[oi].long()].to(torch.float64)
             pb = ops.BADevice(K, fi, pi, coords, hi - lo, P, d, self.ctx)
-            res = SchurTRF(pb).solve(cams[lo:hi].contiguous(), pts[sel].contiguous(), ftol=ftol, verbose=verbose)
+            res = SchurTRF(pb, allreduce=allreduce if sharded else None).solve(
+                cams[lo:hi].contiguous(), pts[sel].contiguous(), ftol=ftol, verbose=verbose if rank == 0 else 0)
             cams[lo:hi] = res.cams
-            pts[sel] = res.pts
-            stats.append(dict(lo=lo, hi=hi, points=P, observations=O, nfev=res.nfev, cost=res.cost, status=res.status))
+            if sharded:
+                buf = torch.zeros((P_all, 3), dtype=torch.float64, device=d)
+                buf[p_lo:p_hi] = res.pts
+                allreduce(buf)                                  # disjoint shards: the sum re-assembles the window
+                pts[sel_all] = buf
+                O_all = torch.tensor([float(O)], dtype=torch.float64, device=d)
+                allreduce(O_all)
+                O = int(O_all.item())
+            else:
+                pts[sel] = res.pts
+            stats.append(dict(lo=lo, hi=hi, points=P_all, observations=O, nfev=res.nfev, cost=res.cost,
+                              status=res.status))
         self.ctx.sync()
         if timers is not None:
             timers["ba_windows"] = timers.get("ba_windows", 0.0) + (time.perf_counter() - t0) * 1e3
@@ -221,32 +251,30 @@ class ClipPipeline:
             m = torch.zeros(0, dtype=torch.int32, device=self.device)
         toc("match")
         tic("link")
-        m_h = m.cpu().numpy()
-        n_h = det["n"].cpu().numpy() if det is not None else np.zeros(0, np.int32)
         if world > 1:
-            # every rank needs every frame's key points and every pair's matches to link identical tracks
-            mmax = int(m_h.max()) if m_h.size else 0
-            pairs_h = pairs[:, :max(mmax, 1)].cpu().numpy()
-            xy_h = det["xy"].cpu().numpy() if det is not None else np.zeros((0, self.cap, 2), np.float32)
-            own = p_hi - p_lo  # frames f_lo .. f_lo+own-1 are owned; the halo frame belongs to the next rank
-            last_rank_with_pairs = max(r for r in range(world) if parallel.block_range(F - 1, r, world)[1] >
-                                       parallel.block_range(F - 1, r, world)[0])
-            keep = own + (1 if rank == last_rank_with_pairs else 0)
-            g_n = parallel.gather_varlen(n_h[:keep], world, dist)
-            g_xy = parallel.gather_varlen(xy_h[:keep], world, dist)
-            g_m = parallel.gather_varlen(m_h, world, dist)
-            pad = np.full((len(m_h), self.cap, 2), -1, np.int32)
-            pad[:, :pairs_h.shape[1]] = pairs_h
-            g_p = parallel.gather_varlen(pad, world, dist)
-            n_h = np.concatenate(g_n).astype(np.int32)
-            m_h = np.concatenate(g_m).astype(np.int32)
-            xy_dev = torch.as_tensor(np.concatenate([a.reshape(-1, self.cap, 2) for a in g_xy]).astype(np.float32)).to(
-                self.device)
-            pairs_d = torch.as_tensor(np.concatenate([a.reshape(-1, self.cap, 2) for a in g_p]).astype(np.int32)).to(
-                self.device)
-            n_d, m_d = torch.as_tensor(n_h).to(self.device), torch.as_tensor(m_h).to(self.device)
+            # every rank needs every frame's key points and every pair's matches to link identical tracks.  The block
+            # partition is arithmetic on (F, world), so every rank knows every rank's row counts: fixed-shape device
+            # all-gathers (RCCL over xGMI under "nccl"), nothing goes through host memory.
+            blocks = [parallel.pair_block(F, r, world) for r in range(world)]
+            pair_counts = [b[0][1] - b[0][0] for b in blocks]
+            last_rank_with_pairs = max(r for r in range(world) if pair_counts[r] > 0)
+            # frames f_lo .. f_lo+own-1 are owned; the halo frame belongs to the next rank (the last one keeps it)
+            frame_counts = [pair_counts[r] + (1 if r == last_rank_with_pairs else 0) for r in range(world)]
+            keep = frame_counts[rank]
+            d = self.device
+            if det is not None:
+                xy_l, n_l = det["xy"][:keep], det["n"][:keep]
+            else:
+                xy_l = torch.zeros((0, self.cap, 2), dtype=torch.float32, device=d)
+                n_l = torch.zeros(0, dtype=torch.int32, device=d)
+            xy_dev = parallel.gather_blocks(xy_l.contiguous(), frame_counts, dist)
+            n_d = parallel.gather_blocks(n_l.contiguous(), frame_counts, dist)
+            m_d = parallel.gather_blocks(m.contiguous(), pair_counts, dist)
+            pairs_d = parallel.gather_blocks(pairs.contiguous(), pair_counts, dist)
         else:
             xy_dev, n_d, m_d, pairs_d = det["xy"], det["n"], m, pairs
+        m_h = m_d.cpu().numpy()
+        n_h = n_d.cpu().numpy()
         track_ptr, obs_frame, obs_kp, bad = ops.link_tracks_device(n_d, xy_dev, m_d, pairs_d, self.ctx)
         if bad:
             raise MMError("link: match index outside the key point tables")
@@ -269,7 +297,7 @@ class ClipPipeline:
         # managePoints order (point-major, insertion order inside a track), assembled on the device
         d = self.device
         if world > 1:
-            lo, hi, o_lo, o_hi = parallel.partition_tracks(track_ptr.cpu().numpy(), rank, world)
+            lo, hi, o_lo, o_hi = parallel.partition_tracks(track_ptr, rank, world)
         else:
             lo, hi, o_lo, o_hi = 0, P, 0, O
         of_d = obs_frame[o_lo:o_hi].contiguous()

@@ -123,12 +123,16 @@ class DeviceBackedDescriptors(np.ndarray):
     """ndarray [n,32] uint8 (what cv2 returns) that remembers its device twin."""
 
     def __new__(cls, desc_dev):
-        obj = np.asarray(desc_dev.cpu().numpy()).view(cls)
+        host = np.asarray(desc_dev.cpu().numpy())
+        host.setflags(write=False)          # the device twin stays valid only while the host copy cannot change
+        obj = host.view(cls)
         obj._dev = desc_dev
         return obj
 
     def __array_finalize__(self, obj):
-        self._dev = getattr(obj, "_dev", None) if obj is not None and getattr(obj, "shape", None) == self.shape else None
+        # views, slices, permutations and copies do NOT inherit the device twin (desc[::-1] or desc[perm] have the
+        # same shape but other rows): only the object made in __new__ carries it
+        self._dev = None
 
 
 def ORB_create(nfeatures=500, scaleFactor=1.2, nlevels=8, edgeThreshold=31, fastThreshold=20, **_ignored):
@@ -137,7 +141,7 @@ def ORB_create(nfeatures=500, scaleFactor=1.2, nlevels=8, edgeThreshold=31, fast
 
 def _device_descriptors(desc, device):
     dev = getattr(desc, "_dev", None)
-    if dev is not None and dev.shape[0] == len(desc):
+    if dev is not None and dev.shape[0] == len(desc) and not desc.flags.writeable:
         return dev
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device())
@@ -228,6 +232,11 @@ def triangulatePoints(tracks, projections):
         f0[i], f1[i] = a, b
         x0[i] = (pa[0], pa[1])
         x1[i] = (pb[0], pb[1])
+    n_proj = len(projections)
+    if min(f0.min(), f1.min()) < -n_proj or max(f0.max(), f1.max()) >= n_proj:
+        raise IndexError("list index out of range")          # what projections[frame_ID] raises, processor.py:257-258
+    f0[f0 < 0] += n_proj                                       # (a negative ID indexes from the end, as in the reference)
+    f1[f1 < 0] += n_proj
     ctx = default_context()
     dev = ctx.device
     proj = torch.as_tensor(np.ascontiguousarray(np.asarray(projections, np.float64).reshape(-1, 3, 4))).to(dev)
