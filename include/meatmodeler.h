@@ -246,6 +246,13 @@ int mm_ba_schur_solve(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, 
  * Narrow bands (<= 15 blocks of 64) are factored by ONE data-flow scheduled launch, everything else by three launches
  * per block column; MM_CHOL_FUSED=0 in the environment forces the latter. */
 size_t mm_chol_workspace_bytes(int n);
+/* Solution only: A x = b for ONE right-hand side, A destroyed (the layout of the factor it is overwritten with is
+ * unspecified).  both_triangles != 0: both triangles of the band hold A on input; 0: only the lower one (the band of the
+ * upper triangle is then filled from it first).  This freedom lets a narrow band be eliminated from BOTH ends at once
+ * (chain of ~(nblk + bwb) / 2 dependent block columns instead of nblk): what the bundle adjustment calls per
+ * trust-region iteration.  MM_CHOL_TWISTED=0 in the environment forces the one-ended elimination. */
+int mm_chol_solve_sym(mm_ctx *ctx, double *A /*dev*/, int n, double *b /*dev [n]*/, int half_bandwidth, int both_triangles,
+                      int32_t *info /*dev*/, void *ws, size_t ws_bytes);
 int mm_chol_solve(mm_ctx *ctx, double *A /*dev*/, int n, double *b /*dev*/, int nrhs, int half_bandwidth,
                   int32_t *info /*dev*/, void *ws, size_t ws_bytes);
 

@@ -418,7 +418,11 @@ class SchurTRF:
                         blk[f, :, f, :] -= (ws - 1) * Bd
                         v -= (ws - 1) * gc.reshape(-1)
                 if self.allreduce is not None or not hasattr(pb, "schur_solve"):
-                    info = pb.chol_solve(S, v, half_bandwidth=half_bw)
+                    if hasattr(pb, "chol_solve_sym"):
+                        # after a band exchange only the lower band is the sum; the dense exchange sums everything
+                        info = pb.chol_solve_sym(S, v, half_bw, both_triangles=not band_exchange)
+                    else:
+                        info = pb.chol_solve(S, v, half_bandwidth=half_bw)
                 # q = [v ; dp] = (J^T J + reg D^-2)^-1 g, the unscaled Gauss-Newton step
                 dp = pb.backsub(self._cams(x), self._pts(x), Cinv, gp, v.view(F, 6)).reshape(-1)
                 # orthonormal basis of span{g_h, gn_h} (trf.py:481-482) in three fused passes:

@@ -486,20 +486,78 @@ __global__ __launch_bounds__(256) void chol_update_kernel(double *__restrict__ A
 //   * the owner of the diagonal block (r, r) also owns (r, r - 1): the critical chain
 //     L_cc^-1 -> L_{c+1,c} -> S_{c+1,c+1} -> L_{c+1,c+1}^-1 stays inside one workgroup (LDS, no flag hop);
 //   * block (c + d, c) is alive for bwb - d + 1 columns, so that many workgroups per offset d (round robin over c) keep
-//     every live block resident: (bwb + 1) + bwb (bwb - 1) / 2 workgroups in total (46 for bwb = 9).
+//     every live block resident: (bwb + 1) + bwb (bwb - 1) / 2 workgroups per side (46 for bwb = 9).
 // Every workgroup walks its blocks in increasing column order and waits only for blocks of smaller (column, offset)
 // rank, so the unfinished block of smallest rank always has a running owner: no deadlock while all workgroups are
 // resident (the host only takes this path for grids far below one workgroup per CU).  Spins are bounded anyway: a
 // workgroup that gives up raises the abort flag, everybody leaves and the call reports MM_ERR_HIP.
+//
+// TWO-ENDED ("twisted") elimination.  The factorisation is a chain of nblk dependent block columns (~18 us each) and
+// nothing else: 47 columns at n = 3000.  With both triangles of the band available the elimination runs from BOTH ends
+// of the matrix at once: side 0 eliminates the block columns 0 .. a-1 downwards (T), side 1 the columns nblk-1 ..
+// a+m downwards in its own, fully reversed coordinates (Bt: index i <-> 64 nblk - 1 - i, so "lower triangle" of side 1
+// is the upper triangle of A and its factor lands there), and the m >= bwb middle columns (M), which separate the two
+// ends, are eliminated last by side 0 with the contributions of both: chain a + m instead of nblk (28 instead of 47).
+// This is the Cholesky factorisation of P A P^T for the permutation [T, reverse(Bt), M]; every entry of the factor is
+// stored at the position of the entry of A it replaces.  A second set of workgroups plays side 1; it never waits for
+// side 0, so the deadlock argument carries over.  n is padded to a multiple of 64 VIRTUALLY (identity rows that exist
+// only in the index arithmetic): side 1 then shares the block grid of side 0 and its first block has `pad` leading
+// identity rows -- the same trick as the partial last block of the one-ended scheme.
 constexpr long SPIN_LIMIT = 1L << 23;
-constexpr int FUSED_MAX_BWB = 15;  // 16 + 105 = 121 resident workgroups at most
+constexpr int FUSED_MAX_BWB = 15;  // 16 + 105 = 121 resident workgroups per side at most
 constexpr size_t FUSED_LDS_BYTES = (size_t)(2 * NB * LDT + 4 * 16 * 17 + 3 * NB) * sizeof(double);
 
-// Coherence between the workgroups (they sit on different XCDs, each with its own L2).  MODE 1 (measured, not shipped:
-// +4 % per factorisation; instantiate chol_band_fused_kernel<1> to compare): plain loads / stores
-// of the blocks, bracketed by agent-scope release / acquire fences (L2 write-back + invalidate per hand-over).
-// MODE 2: every shared block is written and read with agent-scope relaxed atomics (write-through stores, cache-bypassing
-// loads: `global_* ... sc1`), the writer drains its stores (s_waitcnt) before raising the flag: no cache maintenance.
+struct TwGeom {
+    int n, nblk, bwb;
+    int a, m, b;  // block columns eliminated by side 0 first (T), last (M), and by side 1 (Bt); b == 0: one-ended
+    int pad;      // 64 nblk - n virtual identity rows behind the matrix
+};
+
+// Element (row, col) of a 64 x 64 tile in either coordinate system: p + row sr + col sc, valid inside [r_lo, r_hi) x
+// [c_lo, c_hi) (outside: structural zero / identity padding, never dereferenced).
+struct TileRef {
+    double *p;
+    long sr;
+    int sc;
+    int r_lo, r_hi, c_lo, c_hi;
+    __device__ __forceinline__ double *at(int row, int col) const { return p + (long)row * sr + (long)col * sc; }
+    __device__ __forceinline__ bool rv(int row) const { return row >= r_lo && row < r_hi; }
+    __device__ __forceinline__ bool cv(int col) const { return col >= c_lo && col < c_hi; }
+};
+
+__device__ __forceinline__ TileRef tile_ref(double *A, const TwGeom &g, int side, int rb, int cb) {
+    TileRef t;
+    const long ld = g.n;
+    if (side == 0) {
+        t.p = A + (long)rb * NB * ld + (long)cb * NB;
+        t.sr = ld;
+        t.sc = 1;
+        t.r_lo = 0;
+        t.c_lo = 0;
+        t.r_hi = max(0, min(NB, g.n - rb * NB));
+        t.c_hi = max(0, min(NB, g.n - cb * NB));
+    } else {
+        const long N1 = (long)NB * g.nblk - 1;
+        t.p = A + (N1 - (long)rb * NB) * ld + (N1 - (long)cb * NB);
+        t.sr = -ld;
+        t.sc = -1;
+        t.r_lo = max(0, g.pad - rb * NB);
+        t.c_lo = max(0, g.pad - cb * NB);
+        t.r_hi = NB;
+        t.c_hi = NB;
+    }
+    return t;
+}
+
+// position of element i of block `blk` of a vector (right-hand side, y, x) in natural order; valid iff 0 <= . < n
+__device__ __forceinline__ long vec_index(const TwGeom &g, int side, int blk, int i) {
+    return side == 0 ? (long)NB * blk + i : (long)NB * g.nblk - 1 - (long)NB * blk - i;
+}
+
+// Coherence between the workgroups (they sit on different XCDs, each with its own L2): every shared block is written
+// and read with agent-scope relaxed atomics (write-through stores, cache-bypassing loads: `global_* ... sc1`), the
+// writer drains its stores (s_waitcnt) before raising the flag: no cache maintenance.  (Plain accesses bracketed by
+// agent-scope release / acquire fences measured +4 % per factorisation.)
 template <int MODE>
 __device__ __forceinline__ double ld_shared(const double *p) {
     if (MODE == 2) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -513,15 +571,16 @@ __device__ __forceinline__ void st_shared(double *p, double v) {
         *p = v;
 }
 
-// 64 x 64 tile of a published block -> LDS (zero rows >= rows); 16 coalesced 8-byte loads per thread, all in flight
+// 64 x 64 tile of a published block -> LDS (zero outside the valid range); 16 coalesced 8-byte loads per thread, all
+// in flight
 template <int MODE>
-__device__ __forceinline__ void load_tile_shared(double (*T)[LDT], const double *src, int ld, int rows) {
+__device__ __forceinline__ void load_tile_shared(double (*T)[LDT], const TileRef &t) {
     double v[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int e = threadIdx.x + 256 * q;
         const int r = e / NB, c = e % NB;
-        v[q] = r < rows ? ld_shared<MODE>(src + (size_t)r * ld + c) : 0.0;
+        v[q] = (t.rv(r) && t.cv(c)) ? ld_shared<MODE>(t.at(r, c)) : 0.0;
     }
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
@@ -636,8 +695,8 @@ __device__ __forceinline__ void trsm_update(double (*As)[LDT], const double (*Bs
 
 // P_j = W_j X_jj^T: block j of As in place, and to global memory
 template <int MODE, int J>
-__device__ __forceinline__ void trsm_finish(double (*As)[LDT], const double (*Xd)[16][17], double *tile, int n, int rows,
-                                            int row0, int lr, int lk) {
+__device__ __forceinline__ void trsm_finish(double (*As)[LDT], const double (*Xd)[16][17], const TileRef &t, int row0,
+                                            int lr, int lk) {
     double4_t pj = {0, 0, 0, 0};
 #pragma unroll
     for (int ss = 0; ss < 4; ++ss) {
@@ -650,7 +709,7 @@ __device__ __forceinline__ void trsm_finish(double (*As)[LDT], const double (*Xd
     for (int i = 0; i < 4; ++i) {
         const int row = row0 + lk + 4 * i, col = 16 * J + lr;
         As[row][col] = pj[i];
-        if (row < rows) st_shared<MODE>(tile + (size_t)row * n + col, pj[i]);
+        if (t.rv(row) && t.cv(col)) st_shared<MODE>(t.at(row, col), pj[i]);
     }
     wave_lds_sync();
 }
@@ -658,31 +717,31 @@ __device__ __forceinline__ void trsm_finish(double (*As)[LDT], const double (*Xd
 template <int MODE>
 __device__ __forceinline__ void finish_off_block_a(double (*As)[LDT], double (*Bs)[LDT], double (*Xd)[16][17],
                                                    const double4_t (&a0)[2][2], const double4_t (&acc)[2][2],
-                                                   const double *Lcc /*diag tile of A*/, const double *Linv_c,
-                                                   double *tile, int n, int rows) {
+                                                   const TileRef &Lcc /*diagonal tile of the column*/,
+                                                   const double *Linv_c, const TileRef &t) {
     MM_ACC_FOREACH(As[row][col] = a0[a][b][i] - acc[a][b][i];)
-    load_tile_shared<MODE>(Bs, Lcc, n, NB);
+    load_tile_shared<MODE>(Bs, Lcc);
     load_xdiag<MODE>(Xd, Linv_c, 0);
     __syncthreads();
     const int lane = threadIdx.x & 63, row0 = 16 * (threadIdx.x >> 6);
     const int lr = lane & 15, lk = lane >> 4;
-    trsm_finish<MODE, 0>(As, Xd, tile, n, rows, row0, lr, lk);
+    trsm_finish<MODE, 0>(As, Xd, t, row0, lr, lk);
     trsm_update<1, 0, 1>(As, Bs, row0, lr, lk);
-    trsm_finish<MODE, 1>(As, Xd, tile, n, rows, row0, lr, lk);
+    trsm_finish<MODE, 1>(As, Xd, t, row0, lr, lk);
     trsm_update<2, 0, 2>(As, Bs, row0, lr, lk);
     trsm_update<3, 0, 2>(As, Bs, row0, lr, lk);
 }
 
 template <int MODE>
 __device__ __forceinline__ void finish_off_block_b(double (*As)[LDT], double (*Bs)[LDT], double (*Xd)[16][17],
-                                                   const double *Linv_c, double *tile, int n, int rows) {
+                                                   const double *Linv_c, const TileRef &t) {
     load_xdiag<MODE>(Xd, Linv_c, 2);
     __syncthreads();
     const int lane = threadIdx.x & 63, row0 = 16 * (threadIdx.x >> 6);
     const int lr = lane & 15, lk = lane >> 4;
-    trsm_finish<MODE, 2>(As, Xd, tile, n, rows, row0, lr, lk);
+    trsm_finish<MODE, 2>(As, Xd, t, row0, lr, lk);
     trsm_update<3, 2, 3>(As, Bs, row0, lr, lk);
-    trsm_finish<MODE, 3>(As, Xd, tile, n, rows, row0, lr, lk);
+    trsm_finish<MODE, 3>(As, Xd, t, row0, lr, lk);
 }
 
 #define MM_FUSED_ABANDON                       \
@@ -691,12 +750,16 @@ __device__ __forceinline__ void finish_off_block_b(double (*As)[LDT], double (*B
         return;                                \
     }
 
+// flags (int32): [0] abort, then per side: flag[nblk][W] block (r, d) published | yflag[nblk] | cflag[nblk][W] forward
+// contribution of block (r, d) written | aflag[nblk] stage (A) of diagonal block r
+__device__ __forceinline__ size_t tw_side_flags(int nblk, int W) { return 2 * (size_t)nblk * W + 2 * (size_t)nblk; }
+
 // Forward substitution L y = b rides along (b_fwd != nullptr): the owner of block (r, c) multiplies it with y_c as
 // soon as that exists and hands the 64-vector to the owner of the diagonal block r, which adds the contributions in
 // a fixed order (deterministic), applies L_rr^-1 and publishes y_r.  The y chain trails the factorisation by a hop or
-// two, so the forward solve costs no extra time.
+// two, so the forward solve costs no extra time.  (Two-ended: the rows of M receive contributions from both sides.)
 template <int MODE>
-__global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, int n, int nblk, int bwb, double *Linv,
+__global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, TwGeom g, double *Linv,
                                                               int32_t *__restrict__ flags, int32_t *__restrict__ info,
                                                               const double *b_fwd, double *y,
                                                               double *contrib, const int32_t *slab_ready,
@@ -713,24 +776,35 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, int n, 
     double *R = smem + 2 * NB * LDT + 4 * 16 * 17;
     double *ys = R + NB, *rhs = R + 2 * NB;
     __shared__ int s_ok;
-    const int W = bwb + 1;
-    int32_t *abort_flag = flags + (size_t)nblk * W;
-    auto flag = [&](int r, int d) { return flags + (size_t)r * W + d; };
-    auto yflag = [&](int r) { return flags + (size_t)nblk * W + 1 + r; };
-    auto cflag = [&](int r, int d) { return flags + (size_t)nblk * W + 1 + nblk + (size_t)r * W + d; };
-    auto aflag = [&](int r) { return flags + 2 * (size_t)nblk * W + 1 + nblk + r; };   // stage (A) of diagonal block r
-    // Rows of A (and of the right-hand side) may still be under construction by a concurrent launch on another
-    // stream (the reduced camera system, built in camera slabs): block row r covers the cameras 64r/6 .. (64r+63)/6,
-    // i.e. at most two slabs, whose flags are raised by stream-ordered one-thread kernels after each slab.
-    auto rows_ready = [&](int r) -> bool {
+    const int bwb = g.bwb, W = bwb + 1, nblk = g.nblk, n = g.n;
+    const int G = W + bwb * (bwb - 1) / 2;  // workgroups per side
+    const int side = (int)blockIdx.x / G, lid = (int)blockIdx.x % G;
+    const bool tw = g.b > 0;
+    const int nrows = side == 0 ? (tw ? g.a + g.m : nblk) : g.b + g.m;  // block rows this side touches
+    const int ncols = side == 0 ? nrows : g.b;                         // block columns it eliminates
+    int32_t *abort_flag = flags;
+    int32_t *fb = flags + 1 + (size_t)side * tw_side_flags(nblk, W);        // this side's flags
+    int32_t *fo = flags + 1 + (size_t)(1 - side) * tw_side_flags(nblk, W);  // the other side's (read by side 0 only)
+    auto flag = [&](int32_t *base, int r, int d) { return base + (size_t)r * W + d; };
+    auto yflag = [&](int32_t *base, int r) { return base + (size_t)nblk * W + r; };
+    auto cflag = [&](int32_t *base, int r, int d) { return base + (size_t)nblk * W + nblk + (size_t)r * W + d; };
+    auto aflag = [&](int32_t *base, int r) { return base + 2 * (size_t)nblk * W + nblk + r; };
+    auto nat = [&](int s, int blk) { return s == 0 ? blk : nblk - 1 - blk; };  // block index in natural order
+    auto cslot = [&](int s, int r, int d) { return contrib + (((size_t)s * nblk + r) * W + d) * NB; };
+    auto linv = [&](int s, int blk) { return Linv + (size_t)nat(s, blk) * NB * NB; };
+    // Entries of A (and of the right-hand side) may still be under construction by a concurrent launch on another
+    // stream (the reduced camera system, built in camera slabs).  The entries (i, j) and (j, i), i >= j, are written
+    // together with camera row i / 6: a tile is complete when the slabs of its LARGER natural block index are
+    // (natural block q covers the cameras 64q/6 .. (64q+63)/6, i.e. at most two slabs).
+    auto rows_ready = [&](int q) -> bool {
         if (!slab_ready) return true;
-        const int s_lo = (NB * r / 6) / cams_per_slab, s_hi = min(n_cams - 1, (NB * r + NB - 1) / 6) / cams_per_slab;
+        const int s_lo = (NB * q / 6) / cams_per_slab, s_hi = min(n_cams - 1, (NB * q + NB - 1) / 6) / cams_per_slab;
         return wg_wait<MODE>(slab_ready + s_lo, s_hi != s_lo ? slab_ready + s_hi : nullptr, abort_flag, &s_ok);
     };
     // role of this workgroup: offset d (0 = row head: blocks (r, r-1) and (r, r)), first column / row j, period
-    int d = 0, j = blockIdx.x, period = W;
-    if ((int)blockIdx.x >= W) {
-        int b = blockIdx.x - W;
+    int d = 0, j = lid, period = W;
+    if (lid >= W) {
+        int b = lid - W;
         d = 2;
         while (b >= bwb - d + 1) {
             b -= bwb - d + 1;
@@ -741,73 +815,120 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, int n, 
     }
     double4_t acc[2][2], a0[2][2];
     if (d >= 2) {
-        for (int c = j; c + d < nblk; c += period) {
+        for (int c = j; c + d < nrows && c < ncols; c += period) {
             const int r = c + d;
-            const int rows = min(NB, n - r * NB);
-            double *tile = A + (size_t)r * NB * n + (size_t)c * NB;
+            const TileRef t = tile_ref(A, g, side, r, c);
             zero_acc(acc);
             for (int k = max(0, r - bwb); k < c; ++k) {
-                if (!wg_wait<MODE>(flag(r, r - k), flag(c, c - k), abort_flag, &s_ok)) MM_FUSED_ABANDON;
-                load_tile_shared<MODE>(As, A + (size_t)r * NB * n + (size_t)k * NB, n, rows);
-                load_tile_shared<MODE>(Bs, A + (size_t)c * NB * n + (size_t)k * NB, n, NB);
+                if (!wg_wait<MODE>(flag(fb, r, r - k), flag(fb, c, c - k), abort_flag, &s_ok)) MM_FUSED_ABANDON;
+                load_tile_shared<MODE>(As, tile_ref(A, g, side, r, k));
+                load_tile_shared<MODE>(Bs, tile_ref(A, g, side, c, k));
                 __syncthreads();
                 tile_gemm_nt(As, Bs, acc);
             }
+            if (tw && side == 0 && c >= g.a) {
+                // both block rows in M: add what the columns eliminated from the other end contribute.  Their blocks
+                // sit at their natural positions (upper triangle), so side 0 reads them with its own addressing.
+                const int rr = nblk - 1 - r, rc = nblk - 1 - c;  // the two rows in side 1's numbering (rr < rc)
+                for (int kt = max(0, rc - bwb); kt < g.b; ++kt) {
+                    if (!wg_wait<MODE>(flag(fo, rr, rr - kt), flag(fo, rc, rc - kt), abort_flag, &s_ok)) MM_FUSED_ABANDON;
+                    load_tile_shared<MODE>(As, tile_ref(A, g, 0, r, nblk - 1 - kt));
+                    load_tile_shared<MODE>(Bs, tile_ref(A, g, 0, c, nblk - 1 - kt));
+                    __syncthreads();
+                    tile_gemm_nt(As, Bs, acc);
+                }
+            }
             // the block's own entries are fetched as late as possible (their latency hides behind the wait for L_cc):
-            // when the matrix is still being produced by a concurrent launch, this owner needs row r only now
-            if (!rows_ready(r)) MM_FUSED_ABANDON;
-            MM_ACC_FOREACH(a0[a][b][i] = row < rows ? ld_shared<MODE>(tile + (size_t)row * n + col) : 0.0;)
-            if (!wg_wait<MODE>(aflag(c), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
-            finish_off_block_a<MODE>(As, Bs, T, a0, acc, A + (size_t)c * NB * n + (size_t)c * NB, Linv + (size_t)c * NB * NB,
-                                     tile, n, rows);
-            if (!wg_wait<MODE>(flag(c, 0), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
-            finish_off_block_b<MODE>(As, Bs, T, Linv + (size_t)c * NB * NB, tile, n, rows);
-            wg_publish<MODE>(flag(r, d));
+            // when the matrix is still being produced by a concurrent launch, this owner needs them only now
+            if (!rows_ready(side == 0 ? r : nat(1, c))) MM_FUSED_ABANDON;
+            MM_ACC_FOREACH(a0[a][b][i] = (t.rv(row) && t.cv(col)) ? ld_shared<MODE>(t.at(row, col)) : 0.0;)
+            if (!wg_wait<MODE>(aflag(fb, c), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
+            finish_off_block_a<MODE>(As, Bs, T, a0, acc, tile_ref(A, g, side, c, c), linv(side, c), t);
+            if (!wg_wait<MODE>(flag(fb, c, 0), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
+            finish_off_block_b<MODE>(As, Bs, T, linv(side, c), t);
+            wg_publish<MODE>(flag(fb, r, d));
             if (b_fwd) {  // L_rc y_c for the forward substitution (the block is still in As)
-                if (!wg_wait<MODE>(yflag(c), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
-                if (threadIdx.x < NB) ys[threadIdx.x] = ld_shared<MODE>(y + (size_t)c * NB + threadIdx.x);
+                if (!wg_wait<MODE>(yflag(fb, c), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
+                if (threadIdx.x < NB) {
+                    const long vi = vec_index(g, side, c, threadIdx.x);
+                    ys[threadIdx.x] = (vi >= 0 && vi < n) ? ld_shared<MODE>(y + vi) : 0.0;
+                }
                 __syncthreads();
-                const double t = tile_matvec<LDT>(As, ys);
-                if ((threadIdx.x & 3) == 0) st_shared<MODE>(contrib + ((size_t)r * W + d) * NB + (threadIdx.x >> 2), t);
-                wg_publish<MODE>(cflag(r, d));
+                const double tv = tile_matvec<LDT>(As, ys);
+                // a row of M is finished by side 0: hand the vector over in ITS element order
+                const int row = threadIdx.x >> 2, at = (side == 1 && r >= ncols) ? NB - 1 - row : row;
+                if ((threadIdx.x & 3) == 0) st_shared<MODE>(cslot(side, r, d) + at, tv);
+                wg_publish<MODE>(cflag(fb, r, d));
             }
         }
         return;
     }
     double4_t acc1[2][2], a1[2][2];
-    for (int r = j; r < nblk; r += period) {
-        const int nb = min(NB, n - r * NB);
+    for (int r = j; r < nrows; r += period) {
+        const bool diag_here = r < ncols;          // side 1 past its last column: only the block (b, b - 1) is left
+        if (!diag_here && r != ncols) continue;
         const bool has_sub = r >= 1 && bwb >= 1;
-        double *dtile = A + (size_t)r * NB * n + (size_t)r * NB;
-        double *stile = dtile - NB;  // block (r, r - 1)
+        if (!diag_here && !has_sub) continue;
+        const TileRef dt = tile_ref(A, g, side, r, r);
+        const TileRef st = tile_ref(A, g, side, r, has_sub ? r - 1 : r);  // block (r, r - 1)
         zero_acc(acc);
         zero_acc(acc1);
         for (int k = max(0, r - bwb); k + 1 < r; ++k) {
-            if (!wg_wait<MODE>(flag(r, r - k), flag(r - 1, r - 1 - k), abort_flag, &s_ok)) MM_FUSED_ABANDON;
-            load_tile_shared<MODE>(As, A + (size_t)r * NB * n + (size_t)k * NB, n, nb);
-            load_tile_shared<MODE>(Bs, A + (size_t)(r - 1) * NB * n + (size_t)k * NB, n, NB);
+            if (!wg_wait<MODE>(flag(fb, r, r - k), flag(fb, r - 1, r - 1 - k), abort_flag, &s_ok)) MM_FUSED_ABANDON;
+            load_tile_shared<MODE>(As, tile_ref(A, g, side, r, k));
+            load_tile_shared<MODE>(Bs, tile_ref(A, g, side, r - 1, k));
             __syncthreads();
             tile_gemm_nt(As, Bs, acc1);
-            tile_gemm_nt(As, As, acc);
+            if (diag_here) tile_gemm_nt(As, As, acc);
         }
-        if (!rows_ready(r)) MM_FUSED_ABANDON;  // (see the off-diagonal owner: fetched late, hidden behind the next wait)
-        MM_ACC_FOREACH(a0[a][b][i] = (row < nb && col < nb && col <= row) ? ld_shared<MODE>(dtile + (size_t)row * n + col) : 0.0;)
-        if (has_sub) MM_ACC_FOREACH(a1[a][b][i] = row < nb ? ld_shared<MODE>(stile + (size_t)row * n + col) : 0.0;)
+        if (tw && side == 0 && r >= g.a) {  // a row of M: the other end's columns
+            const int rr = nblk - 1 - r;     // (row r - 1 is rr + 1 over there)
+            for (int kt = max(0, rr - bwb); kt < g.b; ++kt) {
+                const bool with_sub = r - 1 >= g.a && rr + 1 - kt <= bwb;
+                if (!wg_wait<MODE>(flag(fo, rr, rr - kt), with_sub ? flag(fo, rr + 1, rr + 1 - kt) : nullptr, abort_flag, &s_ok))
+                    MM_FUSED_ABANDON;
+                load_tile_shared<MODE>(As, tile_ref(A, g, 0, r, nblk - 1 - kt));
+                if (with_sub) load_tile_shared<MODE>(Bs, tile_ref(A, g, 0, r - 1, nblk - 1 - kt));
+                __syncthreads();
+                if (with_sub) tile_gemm_nt(As, Bs, acc1);
+                tile_gemm_nt(As, As, acc);
+            }
+        }
+        // (see the off-diagonal owner: fetched late, hidden behind the next wait)
+        if (diag_here && !rows_ready(nat(side, r))) MM_FUSED_ABANDON;
+        if (side == 1 && has_sub && !rows_ready(nat(1, r - 1))) MM_FUSED_ABANDON;
+        if (diag_here)
+            MM_ACC_FOREACH(a0[a][b][i] = (dt.rv(row) && dt.cv(col) && col <= row) ? ld_shared<MODE>(dt.at(row, col)) : 0.0;)
+        if (has_sub) MM_ACC_FOREACH(a1[a][b][i] = (st.rv(row) && st.cv(col)) ? ld_shared<MODE>(st.at(row, col)) : 0.0;)
         if (has_sub) {
-            if (!wg_wait<MODE>(aflag(r - 1), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
-            finish_off_block_a<MODE>(As, Bs, T, a1, acc1, dtile - (size_t)NB * n - NB, Linv + (size_t)(r - 1) * NB * NB, stile,
-                                     n, nb);
-            if (!wg_wait<MODE>(flag(r - 1, 0), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
-            finish_off_block_b<MODE>(As, Bs, T, Linv + (size_t)(r - 1) * NB * NB, stile, n, nb);
-            wg_publish<MODE>(flag(r, 1));  // (its barrier also orders the LDS copy of the block)
-            tile_gemm_nt(As, As, acc);
+            if (!wg_wait<MODE>(aflag(fb, r - 1), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
+            finish_off_block_a<MODE>(As, Bs, T, a1, acc1, tile_ref(A, g, side, r - 1, r - 1), linv(side, r - 1), st);
+            if (!wg_wait<MODE>(flag(fb, r - 1, 0), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
+            finish_off_block_b<MODE>(As, Bs, T, linv(side, r - 1), st);
+            wg_publish<MODE>(flag(fb, r, 1));  // (its barrier also orders the LDS copy of the block)
+            if (diag_here) tile_gemm_nt(As, As, acc);
+        }
+        if (!diag_here) {  // side 1, block (b, b - 1): its row belongs to M, side 0 finishes it
+            if (b_fwd) {
+                if (!wg_wait<MODE>(yflag(fb, r - 1), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
+                if (threadIdx.x < NB) {
+                    const long vi = vec_index(g, side, r - 1, threadIdx.x);
+                    ys[threadIdx.x] = (vi >= 0 && vi < n) ? ld_shared<MODE>(y + vi) : 0.0;
+                }
+                __syncthreads();
+                const double tv = tile_matvec<LDT>(As, ys);
+                if ((threadIdx.x & 3) == 0) st_shared<MODE>(cslot(side, r, 1) + (NB - 1 - (threadIdx.x >> 2)), tv);
+                wg_publish<MODE>(cflag(fb, r, 1));
+            }
+            __syncthreads();
+            continue;
         }
         __syncthreads();  // As / Bs are reused as M / X from here
-        MM_ACC_FOREACH(M[row][col] = (row < nb && col < nb && col <= row) ? a0[a][b][i] - acc[a][b][i]
-                                                                          : ((row >= nb && row == col) ? 1.0 : 0.0);)
+        MM_ACC_FOREACH(M[row][col] = (dt.rv(row) && dt.cv(col) && col <= row) ? a0[a][b][i] - acc[a][b][i]
+                                                                             : ((!dt.rv(row) && row == col) ? 1.0 : 0.0);)
         __syncthreads();
         int bad = 0;
-        double *Lr = Linv + (size_t)r * NB * NB;
+        double *Lr = linv(side, r);
         // stage (A), by wave 2 during the last panel: the six 16 x 16 blocks of L_rr below its diagonal blocks and the
         // inverses X_00, X_11 -- what the blocks below need for all but the last 12 MFMA of their solve
         auto stage_a = [&]() {
@@ -818,7 +939,7 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, int n, 
 #pragma unroll
                 for (int h = 0; h < 4; ++h) {
                     const int rr = 16 * BI[q] + 4 * h + (lane >> 4), cc = 16 * BJ[q] + (lane & 15);
-                    if (rr < nb) st_shared<MODE>(dtile + (size_t)rr * n + cc, M[rr][cc]);
+                    if (dt.rv(rr) && dt.cv(cc)) st_shared<MODE>(dt.at(rr, cc), M[rr][cc]);
                 }
             }
 #pragma unroll
@@ -828,67 +949,92 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, int n, 
             }
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
-            if (lane == 0) __hip_atomic_store(aflag(r), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(aflag(fb, r), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
-        factor_block_lds(M, X, R, r * NB, bad, stage_a);
-        if (bad && threadIdx.x == 64) report_bad(info, bad);
+        factor_block_lds(M, X, R, 0, bad, stage_a);
+        if (bad && threadIdx.x == 64) {  // `bad` = 1-based position inside the block; report the natural column
+            const long col = vec_index(g, side, r, bad - 1);
+            report_bad(info, (int)(col >= 0 && col < n ? col + 1 : n));
+        }
         // stage (B): the inverses X_22, X_33
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int e = 512 + threadIdx.x + 256 * q, blk = e >> 8, rr = 16 * blk + ((e >> 4) & 15), cc = 16 * blk + (e & 15);
             st_shared<MODE>(Lr + rr * NB + cc, X[rr][cc]);
         }
-        wg_publish<MODE>(flag(r, 0));
+        wg_publish<MODE>(flag(fb, r, 0));
         for (int q = 0; q < 4; ++q) {  // diagonal 16 x 16 blocks of L_rr: only the later kernels read them
             const int e = threadIdx.x + 256 * q, blk = e >> 8, rr = 16 * blk + ((e >> 4) & 15), cc = 16 * blk + (e & 15);
-            if (rr < nb && cc <= rr) dtile[(size_t)rr * n + cc] = M[rr][cc];
+            if (dt.rv(rr) && dt.cv(cc) && cc <= rr) *dt.at(rr, cc) = M[rr][cc];
         }
         // the rest of L_rr^-1 (for the substitution kernels) is nobody's critical path
         inverse_offdiag_lds(M, X, T);
         for (int e = threadIdx.x; e < NB * NB; e += 256) {
             const int rr = e / NB, cc = e % NB;
-            if ((rr >> 4) != (cc >> 4)) Linv[(size_t)r * NB * NB + e] = X[rr][cc];
+            if ((rr >> 4) != (cc >> 4)) Lr[e] = X[rr][cc];
         }
         if (b_fwd) {  // y_r = L_rr^-1 (b_r - sum_d L_{r,r-d} y_{r-d})
-            if (threadIdx.x < NB) rhs[threadIdx.x] = (int)threadIdx.x < nb ? ld_shared<MODE>(b_fwd + (size_t)r * NB + threadIdx.x) : 0.0;
+            if (threadIdx.x < NB) {
+                const long vi = vec_index(g, side, r, threadIdx.x);
+                rhs[threadIdx.x] = (vi >= 0 && vi < n) ? ld_shared<MODE>(b_fwd + vi) : 0.0;
+            }
             if (has_sub) {  // this workgroup owns (r, r-1); its LDS copy is gone (M), read the block back
-                if (!wg_wait<MODE>(yflag(r - 1), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
-                load_tile_shared<MODE>(As, stile, n, nb);
-                if (threadIdx.x < NB) ys[threadIdx.x] = ld_shared<MODE>(y + (size_t)(r - 1) * NB + threadIdx.x);
+                if (!wg_wait<MODE>(yflag(fb, r - 1), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
+                load_tile_shared<MODE>(As, st);
+                if (threadIdx.x < NB) {
+                    const long vi = vec_index(g, side, r - 1, threadIdx.x);
+                    ys[threadIdx.x] = (vi >= 0 && vi < n) ? ld_shared<MODE>(y + vi) : 0.0;
+                }
                 __syncthreads();
-                const double t = tile_matvec<LDT>(As, ys);
-                if ((threadIdx.x & 3) == 0) rhs[threadIdx.x >> 2] -= t;
+                const double tv = tile_matvec<LDT>(As, ys);
+                if ((threadIdx.x & 3) == 0) rhs[threadIdx.x >> 2] -= tv;
             }
             for (int dd = 2; dd <= bwb && dd <= r; ++dd) {
-                if (!wg_wait<MODE>(cflag(r, dd), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
-                if (threadIdx.x < NB) rhs[threadIdx.x] -= ld_shared<MODE>(contrib + ((size_t)r * W + dd) * NB + threadIdx.x);
+                if (!wg_wait<MODE>(cflag(fb, r, dd), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
+                if (threadIdx.x < NB) rhs[threadIdx.x] -= ld_shared<MODE>(cslot(side, r, dd) + threadIdx.x);
+            }
+            if (tw && side == 0 && r >= g.a) {  // a row of M: what the other end's columns contribute (fixed order)
+                const int rr = nblk - 1 - r;
+                for (int dd = max(1, rr - g.b + 1); dd <= bwb && dd <= rr; ++dd) {
+                    if (!wg_wait<MODE>(cflag(fo, rr, dd), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
+                    if (threadIdx.x < NB) rhs[threadIdx.x] -= ld_shared<MODE>(cslot(1, rr, dd) + threadIdx.x);
+                }
             }
             __syncthreads();
             const double yr = tile_matvec<NB + 1>(X, rhs);
-            if ((threadIdx.x & 3) == 0 && (int)(threadIdx.x >> 2) < nb) st_shared<MODE>(y + (size_t)r * NB + (threadIdx.x >> 2), yr);
-            wg_publish<MODE>(yflag(r));
+            if ((threadIdx.x & 3) == 0) {
+                const long vi = vec_index(g, side, r, threadIdx.x >> 2);
+                if (vi >= 0 && vi < n) st_shared<MODE>(y + vi, yr);
+            }
+            wg_publish<MODE>(yflag(fb, r));
         }
         __syncthreads();  // M / X are overwritten by the next row's tiles
     }
 }
 
 // ---- backward substitution L^T x = y for a narrow band: ONE launch ------------------------------------------------------
-// Workgroup 0 owns the diagonal and the first sub-diagonal: x_k = L_kk^-T (y_k - sum_d L_{k+d,k}^T x_{k+d}), with the
-// d = 1 term computed locally right after x_{k+1}.  Workgroup d (2 <= d <= bwb) owns the blocks (k + d, k) and sends
-// its 64-vector L_{k+d,k}^T x_{k+d} to workgroup 0, which adds the terms in a fixed order.  No flags: x and the
+// Per side, workgroup 0 owns the diagonal and the first sub-diagonal: x_k = L_kk^-T (y_k - sum_d L_{k+d,k}^T x_{k+d}),
+// with the d = 1 term computed locally right after x_{k+1}.  Workgroup d (2 <= d <= bwb) owns the blocks (k + d, k) and
+// sends its 64-vector L_{k+d,k}^T x_{k+d} to workgroup 0, which adds the terms in a fixed order.  No flags: x and the
 // contribution buffer start out as a NaN sentinel (host memset 0xFF) and every reader polls the very 8 bytes it needs
 // (written by one write-through store), so a hand-over costs one memory latency instead of store-ack + flag + load.
 // Every tile a workgroup needs next is already in flight (registers) while it waits.
+// Two-ended: side 0 walks M then T upwards; side 1 starts from the x of M (polled like any other) and walks its own
+// columns in its reversed numbering -- the two chains of a + m and b steps run side by side.
 constexpr unsigned long long BWD_SENTINEL = ~0ull;
 constexpr size_t BWD_LDS_BYTES = (size_t)(2 * NB * LDT + 4 * NB + 2 * NB) * sizeof(double);
 
-__device__ __forceinline__ void tile_prefetch(double (&pre)[16], const double *__restrict__ src, int ld, int rows) {
+__device__ __forceinline__ void tile_prefetch(double (&pre)[16], const TileRef &t) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int e = threadIdx.x + 256 * q;
         const int r = e / NB, c = e % NB;
-        pre[q] = r < rows ? src[(size_t)r * ld + c] : 0.0;
+        pre[q] = (t.rv(r) && t.cv(c)) ? *t.at(r, c) : 0.0;
     }
+}
+__device__ __forceinline__ void tile_prefetch_dense(double (&pre)[16], const double *__restrict__ src) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) pre[q] = src[threadIdx.x + 256 * q];
 }
 __device__ __forceinline__ void tile_commit(double (*T)[LDT], const double (&pre)[16]) {
 #pragma unroll
@@ -920,24 +1066,35 @@ __device__ __forceinline__ double poll_value(const double *p, int32_t *abort_fla
     return 0.0;
 }
 
-__global__ __launch_bounds__(256) void chol_band_bwd_kernel(const double *__restrict__ A, int n, int nblk, int bwb,
-                                                            const double *__restrict__ Linv, const double *__restrict__ y,
-                                                            double *x, double *contrib, int32_t *__restrict__ abort_flag,
-                                                            int32_t *__restrict__ info) {
+__global__ __launch_bounds__(256) void chol_band_bwd_kernel(double *A, TwGeom g, const double *__restrict__ Linv,
+                                                            const double *__restrict__ y, double *x, double *contrib,
+                                                            int32_t *__restrict__ abort_flag, int32_t *__restrict__ info) {
     extern __shared__ double smem[];
     double (*T0)[LDT] = reinterpret_cast<double (*)[LDT]>(smem);
     double (*T1)[LDT] = reinterpret_cast<double (*)[LDT]>(smem + NB * LDT);
     double (*part)[NB] = reinterpret_cast<double (*)[NB]>(smem + 2 * NB * LDT);
     double *vec = smem + 2 * NB * LDT + 4 * NB, *vec2 = vec + NB;
-    const int W = bwb + 1;
+    const int bwb = g.bwb, W = bwb + 1, nblk = g.nblk, n = g.n;
+    const int GB = bwb >= 2 ? bwb : 1;  // workgroups per side
+    const int side = (int)blockIdx.x / GB, lid = (int)blockIdx.x % GB;
+    const bool tw = g.b > 0;
+    const int nrows = side == 0 ? (tw ? g.a + g.m : nblk) : g.b + g.m;
+    const int ncols = side == 0 ? nrows : g.b;
+    auto nat = [&](int blk) { return side == 0 ? blk : nblk - 1 - blk; };
+    auto cslot = [&](int k, int d) { return contrib + (((size_t)side * nblk + k) * W + d) * NB; };
+    // element threadIdx.x of vector block blk (natural storage); false: a virtual padding row
+    auto vpos = [&](int blk, long &vi) -> bool {
+        vi = vec_index(g, side, blk, threadIdx.x);
+        return vi >= 0 && vi < n;
+    };
     int failed = 0;
     // tiles are fetched two steps ahead (a step is shorter than a trip to memory): two register slots, loop unrolled by 2
-    if (blockIdx.x == 0) {
+    if (lid == 0) {
         double p0a[16], p1a[16], p0b[16], p1b[16];
         auto fetch = [&](int k, double (&p0)[16], double (&p1)[16]) {  // tiles of step k: L_kk^-1 and L_{k,k-1}
             if (k < 0) return;
-            tile_prefetch(p0, Linv + (size_t)k * NB * NB, NB, NB);
-            if (k > 0) tile_prefetch(p1, A + (size_t)k * NB * n + (size_t)(k - 1) * NB, n, min(NB, n - k * NB));
+            tile_prefetch_dense(p0, Linv + (size_t)nat(k) * NB * NB);
+            if (k > 0) tile_prefetch(p1, tile_ref(A, g, side, k, k - 1));
         };
         double local = 0.0;  // L_{k+1,k}^T x_{k+1}, element threadIdx.x (first 64 threads)
         bool dead = false;
@@ -946,15 +1103,14 @@ __global__ __launch_bounds__(256) void chol_band_bwd_kernel(const double *__rest
         double cv[FUSED_MAX_BWB + 1], yk = 0.0;
         auto request = [&](int k) {
             if (k < 0 || threadIdx.x >= NB) return;
-            yk = (int)threadIdx.x < min(NB, n - k * NB) ? y[(size_t)k * NB + threadIdx.x] : 0.0;
+            long vi;
+            yk = vpos(k, vi) ? y[vi] : 0.0;
 #pragma unroll
             for (int dd = 2; dd <= FUSED_MAX_BWB; ++dd)
-                if (dd <= bwb && k + dd < nblk)
-                    cv[dd] = __hip_atomic_load(contrib + ((size_t)k * W + dd) * NB + threadIdx.x, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT);
+                if (dd <= bwb && k + dd < nrows)
+                    cv[dd] = __hip_atomic_load(cslot(k, dd) + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
         auto step = [&](int k, double (&p0)[16], double (&p1)[16]) {
-            const int nb = min(NB, n - k * NB);
             tile_commit(T0, p0);
             if (k > 0) tile_commit(T1, p1);
             fetch(k - 2, p0, p1);
@@ -962,9 +1118,9 @@ __global__ __launch_bounds__(256) void chol_band_bwd_kernel(const double *__rest
                 double rhs = yk - local;
 #pragma unroll
                 for (int dd = 2; dd <= FUSED_MAX_BWB; ++dd)  // fixed summation order
-                    if (dd <= bwb && k + dd < nblk) {
+                    if (dd <= bwb && k + dd < nrows) {
                         if ((unsigned long long)__double_as_longlong(cv[dd]) == BWD_SENTINEL)
-                            cv[dd] = poll_value(contrib + ((size_t)k * W + dd) * NB + threadIdx.x, abort_flag, failed);
+                            cv[dd] = poll_value(cslot(k, dd) + threadIdx.x, abort_flag, failed);
                         rhs -= cv[dd];
                     }
                 vec[threadIdx.x] = rhs;
@@ -975,44 +1131,63 @@ __global__ __launch_bounds__(256) void chol_band_bwd_kernel(const double *__rest
             }
             const double xk = tile_matvec_t(T0, vec, part);
             if (threadIdx.x < NB) {
-                if ((int)threadIdx.x < nb) st_shared<2>(x + (size_t)k * NB + threadIdx.x, xk);
-                vec2[threadIdx.x] = (int)threadIdx.x < nb ? xk : 0.0;
+                long vi;
+                const bool ok = vpos(k, vi);
+                if (ok) st_shared<2>(x + vi, xk);
+                vec2[threadIdx.x] = ok ? xk : 0.0;
             }
             request(k - 1);
             __syncthreads();
             if (k > 0) local = tile_matvec_t(T1, vec2, part);
             __syncthreads();  // T0 / T1 / part are rewritten by the next step
         };
-        request(nblk - 1);
-        fetch(nblk - 1, p0a, p1a);
-        fetch(nblk - 2, p0b, p1b);
-        for (int k = nblk - 1; k >= 0 && !dead; k -= 2) {
+        const int ktop = ncols - 1;  // first block this chain solves for
+        if (ktop < 0) return;
+        if (side == 1 && ktop + 1 < nrows && bwb >= 1) {
+            // the row above the chain's first block belongs to M: x of that row comes from side 0, the block
+            // (ktop + 1, ktop) is this side's -> `local` for the first step
+            double pt[16];
+            tile_prefetch(pt, tile_ref(A, g, side, ktop + 1, ktop));
+            tile_commit(T1, pt);
+            if (threadIdx.x < NB) {
+                long vi;
+                vec2[threadIdx.x] = vpos(ktop + 1, vi) ? poll_value(x + vi, abort_flag, failed) : 0.0;
+            }
+            if (__syncthreads_or(failed)) MM_FUSED_ABANDON;
+            local = tile_matvec_t(T1, vec2, part);
+            __syncthreads();
+        }
+        request(ktop);
+        fetch(ktop, p0a, p1a);
+        fetch(ktop - 1, p0b, p1b);
+        for (int k = ktop; k >= 0 && !dead; k -= 2) {
             step(k, p0a, p1a);
             if (k - 1 >= 0 && !dead) step(k - 1, p0b, p1b);
         }
         if (dead) MM_FUSED_ABANDON;
         return;
     }
-    const int d = blockIdx.x + 1;  // 2 .. bwb
-    const int kfirst = nblk - 1 - d;
+    const int d = lid + 1;  // 2 .. bwb
+    const int kfirst = min(nrows - 1 - d, ncols - 1);
     if (kfirst < 0) return;
     double pa[16], pb[16];
     auto fetch = [&](int k, double (&pp)[16]) {
-        if (k >= 0) tile_prefetch(pp, A + (size_t)(k + d) * NB * n + (size_t)k * NB, n, min(NB, n - (k + d) * NB));
+        if (k >= 0) tile_prefetch(pp, tile_ref(A, g, side, k + d, k));
     };
     bool dead = false;
     auto step = [&](int k, double (&pp)[16]) {
         tile_commit(T0, pp);
         fetch(k - 2, pp);
-        const int rows = min(NB, n - (k + d) * NB);
-        if (threadIdx.x < NB)
-            vec[threadIdx.x] = (int)threadIdx.x < rows ? poll_value(x + (size_t)(k + d) * NB + threadIdx.x, abort_flag, failed) : 0.0;
+        if (threadIdx.x < NB) {
+            long vi;
+            vec[threadIdx.x] = vpos(k + d, vi) ? poll_value(x + vi, abort_flag, failed) : 0.0;
+        }
         if (__syncthreads_or(failed)) {
             dead = true;
             return;
         }
         const double t = tile_matvec_t(T0, vec, part);
-        if (threadIdx.x < NB) st_shared<2>(contrib + ((size_t)k * W + d) * NB + threadIdx.x, t);
+        if (threadIdx.x < NB) st_shared<2>(cslot(k, d) + threadIdx.x, t);
         __syncthreads();
     };
     fetch(kfirst, pa);
@@ -1022,6 +1197,16 @@ __global__ __launch_bounds__(256) void chol_band_bwd_kernel(const double *__rest
         if (k - 1 >= 0 && !dead) step(k - 1, pb);
     }
     if (dead) MM_FUSED_ABANDON;
+}
+
+// copy the band of the lower triangle into the upper triangle for the columns side 1 eliminates: (j, i) <- (i, j) for
+// i >= row0, 0 < i - j <= hb (callers of the two-ended path that only filled the lower triangle)
+__global__ __launch_bounds__(256) void chol_mirror_kernel(double *A, int n, int row0, int hb) {
+    const int i = row0 + blockIdx.x;
+    for (int o = 1 + threadIdx.x; o <= hb; o += 256) {
+        const int j = i - o;
+        if (j >= 0) A[(size_t)j * n + i] = A[(size_t)i * n + j];
+    }
 }
 
 // ---- solves -----------------------------------------------------------------------------------------------------------
@@ -1105,13 +1290,18 @@ extern "C" {
 size_t mm_chol_workspace_bytes(int n) {
     size_t nblk = (size_t)(n + NB - 1) / NB;
     return mm_align_up(nblk * NB * NB * sizeof(double), 256) + mm_align_up((size_t)(n + NB) * sizeof(double), 256) +
-           mm_align_up((2 * nblk * (FUSED_MAX_BWB + 1) + 2 * nblk + 64) * sizeof(int32_t), 256) +
-           mm_align_up(nblk * (FUSED_MAX_BWB + 1) * NB * sizeof(double), 256);
+           mm_align_up((2 * (2 * nblk * (FUSED_MAX_BWB + 1) + 2 * nblk) + 64) * sizeof(int32_t), 256) +
+           mm_align_up(2 * nblk * (FUSED_MAX_BWB + 1) * NB * sizeof(double), 256);
 }
 
 int mm_chol_solve(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int half_bandwidth, int32_t *info, void *ws,
                   size_t ws_bytes) {
-    return mm_chol_solve_gated(ctx, A, n, b, nrhs, half_bandwidth, info, ws, ws_bytes, nullptr, 1, 0);
+    return mm_chol_solve_gated(ctx, A, n, b, nrhs, half_bandwidth, info, ws, ws_bytes, nullptr, 1, 0, 0);
+}
+
+int mm_chol_solve_sym(mm_ctx *ctx, double *A, int n, double *b, int half_bandwidth, int both_triangles, int32_t *info,
+                      void *ws, size_t ws_bytes) {
+    return mm_chol_solve_gated(ctx, A, n, b, 1, half_bandwidth, info, ws, ws_bytes, nullptr, 1, 0, both_triangles ? 2 : 1);
 }
 
 }  // extern "C"
@@ -1124,6 +1314,14 @@ static int chol_fused_mode() {
     return mode;
 }
 
+static bool chol_twisted_enabled() {
+    static const bool on = [] {
+        const char *e = getenv("MM_CHOL_TWISTED");
+        return !e || atoi(e) != 0;
+    }();
+    return on;
+}
+
 bool mm_chol_fused_eligible(int n, int half_bandwidth) {
     const int nblk = (n + NB - 1) / NB;
     long bwb_l = ((long)half_bandwidth + NB - 1) / NB;
@@ -1131,9 +1329,12 @@ bool mm_chol_fused_eligible(int n, int half_bandwidth) {
     return chol_fused_mode() > 0 && nblk >= 2 && bwb >= 1 && bwb <= FUSED_MAX_BWB && !(n & 1);
 }
 
-// mm_chol_solve with the rows of A / b gated by slab flags (slab_ready == nullptr: everything is there already)
+// mm_chol_solve with the rows of A / b gated by slab flags (slab_ready == nullptr: everything is there already).
+// sym_mode 0: only the lower triangle is valid and it must come back as the plain Cholesky factor (mm_chol_solve);
+// 1: only the lower triangle is valid, the layout of the factor is free; 2: both triangles of the band are valid.
+// With 1 / 2 (and one right-hand side) a narrow band is eliminated from both ends at once.
 int mm_chol_solve_gated(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int half_bandwidth, int32_t *info, void *ws,
-                        size_t ws_bytes, const int32_t *slab_ready, int cams_per_slab, int n_cams) {
+                        size_t ws_bytes, const int32_t *slab_ready, int cams_per_slab, int n_cams, int sym_mode) {
     if (!ctx) return MM_ERR_ARG;
     if (n == 0) return MM_OK;
     if (!A || !info || n < 0 || nrhs < 0 || (nrhs > 0 && !b) || half_bandwidth < 0)
@@ -1151,20 +1352,33 @@ int mm_chol_solve_gated(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int 
     const int fused_mode = chol_fused_mode();
     if (slab_ready && !mm_chol_fused_eligible(n, half_bandwidth))
         return mm_fail(ctx, MM_ERR_ARG, "mm_chol_solve_gated: gating needs the single-launch factorisation");
-    if (fused_mode > 0 && nblk >= 2 && bwb >= 1 && bwb <= FUSED_MAX_BWB) {
+    const bool fused = fused_mode > 0 && nblk >= 2 && bwb >= 1 && bwb <= FUSED_MAX_BWB;
+    TwGeom g = {n, nblk, bwb, nblk, 0, 0, nblk * NB - n};
+    if (fused && sym_mode > 0 && nrhs == 1 && chol_twisted_enabled() && nblk - bwb >= 4) {
+        g.m = bwb;                       // the separator: no coupling across 64 m + 1 > half_bandwidth
+        g.a = (nblk - g.m + 1) / 2;
+        g.b = nblk - g.m - g.a;
+    }
+    int32_t *flags = (int32_t *)((char *)ytmp + mm_align_up((size_t)(n + NB) * sizeof(double), 256));
+    double *contrib = (double *)((char *)flags + mm_align_up((2 * (2 * (size_t)nblk * (FUSED_MAX_BWB + 1) + 2 * nblk) + 64) * sizeof(int32_t), 256));
+    const int sides = g.b > 0 ? 2 : 1;
+    if (fused) {
         if (!ctx->attr_chol_fused) {
             MM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(chol_band_fused_kernel<2>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS_BYTES));
             ctx->attr_chol_fused = true;
         }
-        int32_t *flags = (int32_t *)((char *)ytmp + mm_align_up((size_t)(n + NB) * sizeof(double), 256));
-        const size_t nflags = 2 * (size_t)nblk * (bwb + 1) + 2 * nblk + 1;
-        double *contrib = (double *)((char *)flags + mm_align_up((2 * (size_t)nblk * (FUSED_MAX_BWB + 1) + 2 * nblk + 64) * sizeof(int32_t), 256));
+        if (g.b > 0 && sym_mode == 1) {  // side 1 reads (and overwrites) the upper triangle of its columns: whole tiles,
+            const long reach = (long)NB * bwb + NB - 1;   // i.e. also the structural zeros between the band and the tile edge
+            MM_LAUNCH(ctx, "chol_mirror_kernel", chol_mirror_kernel, dim3(n - (g.a + g.m) * NB), dim3(256), 0, A, n,
+                      (g.a + g.m) * NB, (int)(reach < n - 1 ? reach : n - 1));
+        }
+        const size_t nflags = 1 + 2 * (2 * (size_t)nblk * (bwb + 1) + 2 * nblk);
         const double *b_fwd = nrhs >= 1 ? b : nullptr;  // the first right-hand side rides along
         MM_HIP(ctx, hipMemsetAsync(flags, 0, nflags * sizeof(int32_t), ctx->stream));
-        const int grid = (bwb + 1) + bwb * (bwb - 1) / 2;
-        MM_LAUNCH(ctx, "chol_band_fused_kernel", chol_band_fused_kernel<2>, dim3(grid), dim3(256), FUSED_LDS_BYTES, A, n, nblk,
-                  bwb, Linv, flags, info, b_fwd, ytmp, contrib, slab_ready, cams_per_slab, n_cams);
+        const int grid = sides * ((bwb + 1) + bwb * (bwb - 1) / 2);
+        MM_LAUNCH(ctx, "chol_band_fused_kernel", chol_band_fused_kernel<2>, dim3(grid), dim3(256), FUSED_LDS_BYTES, A, g, Linv,
+                  flags, info, b_fwd, ytmp, contrib, slab_ready, cams_per_slab, n_cams);
         fwd_done = b_fwd != nullptr;
     } else {
         for (int k = 0; k < nblk; ++k) {
@@ -1190,20 +1404,18 @@ int mm_chol_solve_gated(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int 
             MM_LAUNCH(ctx, "fwd_step_kernel", fwd_step_kernel, dim3(grid), dim3(256), 0, (const double *)A,
                       (const double *)(Linv + (size_t)k * NB * NB), bc, ytmp, n, k0, row_end);
         }
-        if (fused_mode > 0 && nblk >= 2 && bwb >= 1 && bwb <= FUSED_MAX_BWB) {  // L^T x = y in one launch
+        if (fused) {  // L^T x = y in one launch
             if (!ctx->attr_chol_bwd) {
                 MM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(chol_band_bwd_kernel),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_LDS_BYTES));
                 ctx->attr_chol_bwd = true;
             }
-            int32_t *flags = (int32_t *)((char *)ytmp + mm_align_up((size_t)(n + NB) * sizeof(double), 256));
-            double *contrib = (double *)((char *)flags + mm_align_up((2 * (size_t)nblk * (FUSED_MAX_BWB + 1) + 2 * nblk + 64) * sizeof(int32_t), 256));
             // x (the output) and the contribution buffer start as the NaN sentinel the kernel polls on
             MM_HIP(ctx, hipMemsetAsync(flags, 0, sizeof(int32_t), ctx->stream));
             MM_HIP(ctx, hipMemsetAsync(bc, 0xFF, (size_t)n * sizeof(double), ctx->stream));
-            MM_HIP(ctx, hipMemsetAsync(contrib, 0xFF, (size_t)nblk * (bwb + 1) * NB * sizeof(double), ctx->stream));
-            MM_LAUNCH(ctx, "chol_band_bwd_kernel", chol_band_bwd_kernel, dim3(bwb >= 2 ? bwb : 1), dim3(256), BWD_LDS_BYTES,
-                      (const double *)A, n, nblk, bwb, (const double *)Linv, (const double *)ytmp, bc, contrib, flags, info);
+            MM_HIP(ctx, hipMemsetAsync(contrib, 0xFF, (size_t)sides * nblk * (bwb + 1) * NB * sizeof(double), ctx->stream));
+            MM_LAUNCH(ctx, "chol_band_bwd_kernel", chol_band_bwd_kernel, dim3(sides * (bwb >= 2 ? bwb : 1)), dim3(256),
+                      BWD_LDS_BYTES, A, g, (const double *)Linv, (const double *)ytmp, bc, contrib, flags, info);
             continue;
         }
         for (int k = nblk - 1; k >= 0; --k) {  // L^T x = y

@@ -38,7 +38,7 @@ struct mm_stream_swap {
 // chol.hip internals used by the overlapped Schur + solve entry point (schur.hip)
 bool mm_chol_fused_eligible(int n, int half_bandwidth);
 int mm_chol_solve_gated(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int half_bandwidth, int32_t *info, void *ws,
-                        size_t ws_bytes, const int32_t *slab_ready, int cams_per_slab, int n_cams);
+                        size_t ws_bytes, const int32_t *slab_ready, int cams_per_slab, int n_cams, int sym_mode);
 
 static inline hipEvent_t mm_prof_event(mm_ctx *c) {
     hipEvent_t e = nullptr;

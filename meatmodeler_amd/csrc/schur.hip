@@ -114,7 +114,8 @@ __global__ __launch_bounds__(256) void schur_rows_kernel(mm_ba_problem pb, const
 // block segment (i, f2 = i - d): lanes stride over the segment's (o, o2) pairs, accumulate Y_o E_o2^T in 36 private
 // registers (+6 for the right-hand side on the self pairs) and a fixed shuffle tree adds the lanes, so every entry of
 // S is summed in the same order on every run — the trust-region iteration, which is chaotic on outlier-laden matches,
-// then repeats bit for bit.  No atomics; only the LOWER block triangle is produced (S is zero-filled first).
+// then repeats bit for bit.  No atomics; every block is written together with its mirror image, so both triangles of the
+// band are filled (S is zero-filled first).
 constexpr int SP_WAVES = 4;
 constexpr int MAX_SLABS = 64;
 // slab bookkeeping of the overlapped build + solve (all null / 0 when nobody consumes S concurrently)
@@ -211,6 +212,8 @@ __global__ __launch_bounds__(64 * SP_WAVES, 2) void schur_pairs_kernel(mm_ba_pro
             double val = -sum;
             if (d == 0) val += Bd[(size_t)i * 36 + lane];
             __hip_atomic_store(S + ((size_t)i * 6 + lane / 6) * n + (size_t)f2 * 6 + lane % 6, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d != 0)   // the mirror image: the two-ended factorisation eliminates the last cameras in the upper triangle
+                __hip_atomic_store(S + ((size_t)f2 * 6 + lane % 6) * n + (size_t)i * 6 + lane / 6, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else if (lane < 42 && d == 0) {
             __hip_atomic_store(v + (size_t)i * 6 + (lane - 36), gc[(size_t)i * 6 + (lane - 36)] - sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -220,6 +223,8 @@ __global__ __launch_bounds__(64 * SP_WAVES, 2) void schur_pairs_kernel(mm_ba_pro
             double val = -acc[q];
             if (d == 0) val += Bd[(size_t)i * 36 + q];
             __hip_atomic_store(S + ((size_t)i * 6 + q / 6) * n + (size_t)f2 * 6 + q % 6, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d != 0)
+                __hip_atomic_store(S + ((size_t)f2 * 6 + q % 6) * n + (size_t)i * 6 + q / 6, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (d == 0) {
 #pragma unroll
@@ -393,7 +398,8 @@ extern "C" int mm_ba_schur_solve(mm_ctx *ctx, const mm_ba_problem *pb, const dou
     if (!overlap) {
         int rc = mm_ba_schur(ctx, pb, cams, pts, Bd, Cd, gc, gp, S, v, Cinv, ws_schur, ws_schur_bytes);
         if (rc) return rc;
-        return mm_chol_solve(ctx, S, n, v, 1, half_bandwidth, info, ws_chol, ws_chol_bytes);
+        // (the pair-list build fills both triangles of the band; the general kernel all of S)
+        return mm_chol_solve_sym(ctx, S, n, v, half_bandwidth, 1, info, ws_chol, ws_chol_bytes);
     }
     if (!cams || !pts || !Bd || !Cd || !gc || !gp || !S || !v || !Cinv) return mm_fail(ctx, MM_ERR_ARG, "mm_ba_schur_solve: null pointer");
     if (!ws_schur || ws_schur_bytes < mm_ba_schur_workspace_bytes(pb)) return mm_fail(ctx, MM_ERR_WORKSPACE, "mm_ba_schur_solve: workspace too small");
@@ -424,7 +430,7 @@ extern "C" int mm_ba_schur_solve(mm_ctx *ctx, const mm_ba_problem *pb, const dou
     MM_HIP(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
     {   // the consumer goes first, so that its workgroups are resident before the producer floods the CUs
         mm_stream_swap sw(ctx, ctx->aux);
-        int rc = mm_chol_solve_gated(ctx, S, n, v, 1, half_bandwidth, info, ws_chol, ws_chol_bytes, w.slab_ready, cams_per_slab, pb->F);
+        int rc = mm_chol_solve_gated(ctx, S, n, v, 1, half_bandwidth, info, ws_chol, ws_chol_bytes, w.slab_ready, cams_per_slab, pb->F, 2);
         if (rc) {  // whatever did get enqueued on the second stream is joined before the error travels up
             (void)hipEventRecord(ctx->ev_join, ctx->aux);
             (void)hipStreamWaitEvent(sw.saved, ctx->ev_join, 0);

@@ -421,6 +421,10 @@ class BADevice:
         """In-place banded Cholesky solve of the reduced camera system (see ops.chol_solve)."""
         return chol_solve(S, v, self.ctx, half_bandwidth=half_bandwidth)
 
+    def chol_solve_sym(self, S, v, half_bandwidth, both_triangles):
+        """Solution only (S destroyed): lets a narrow band be eliminated from both ends (see ops.chol_solve_sym)."""
+        return chol_solve_sym(S, v, self.ctx, half_bandwidth, both_triangles)
+
     def backsub(self, cams, pts, Cinv, gp, dc):
         dp = torch.empty((self.P, 3), dtype=torch.float64, device=self.device)
         self.ctx.check(lib.mm_ba_backsub(self.ctx.h, C.byref(self.pb), ptr(cams), ptr(pts), ptr(Cinv), ptr(gp), ptr(dc),
@@ -477,4 +481,19 @@ def chol_solve(A, b, ctx=None, half_bandwidth=None):
     ws = torch.empty(wsb, dtype=torch.uint8, device=A.device)
     hb = n if half_bandwidth is None else int(min(half_bandwidth, n))
     ctx.check(lib.mm_chol_solve(ctx.h, ptr(A), n, ptr(b), nrhs, hb, ptr(info), ptr(ws), wsb), "mm_chol_solve")
+    return info
+
+
+def chol_solve_sym(A, b, ctx=None, half_bandwidth=None, both_triangles=True):
+    """In place, solution only: A [n,n] f64 SPD is destroyed, b [n] overwritten by x (mm_chol_solve_sym).
+    both_triangles: both triangles of the band hold A (else only the lower one).  Returns the device int32 info."""
+    ctx = ctx or default_context()
+    n = A.shape[0]
+    assert A.dtype == torch.float64 and A.is_contiguous() and b.is_contiguous() and b.dim() == 1 and b.shape[0] == n
+    info = torch.zeros(1, dtype=torch.int32, device=A.device)
+    wsb = lib.mm_chol_workspace_bytes(n)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=A.device)
+    hb = n if half_bandwidth is None else int(min(half_bandwidth, n))
+    ctx.check(lib.mm_chol_solve_sym(ctx.h, ptr(A), n, ptr(b), hb, 1 if both_triangles else 0, ptr(info), ptr(ws), wsb),
+              "mm_chol_solve_sym")
     return info

@@ -425,6 +425,40 @@ def test_chol_solve_banded(n, hb):
     np.testing.assert_allclose(L, np.linalg.cholesky(A), rtol=1e-9, atol=1e-10)
 
 
+@pytest.mark.parametrize("both", [True, False])
+@pytest.mark.parametrize("n,hb", [(3000, 528), (1000, 130), (770, 63), (320, 5), (500, 40), (1200, 300), (2048, 64),
+                                   (1500, 900)])
+def test_chol_solve_sym_two_ended(n, hb, both):
+    """mm_chol_solve_sym (solution only): narrow bands are eliminated from both ends of the matrix at once (two sets of
+    workgroups, the second in reversed coordinates in the upper triangle; n that is not a multiple of 64 is padded
+    virtually).  3000/528 is the reduced camera system of the 500-frame clip; 1500/900 is too wide for the
+    single-launch path and takes the launch-per-column factorisation.  `both` = False: only the lower triangle is
+    given (the upper one holds garbage that must be ignored / overwritten)."""
+    rng = np.random.default_rng(n + hb)
+    M = np.tril(np.triu(rng.normal(size=(n, n)), -hb // 2))
+    A = M @ M.T + n * np.eye(n)
+    b = rng.normal(size=n)
+    Ain = A if both else np.tril(A) + np.triu(rng.normal(size=(n, n)), 1)
+    ref = np.linalg.solve(A, b)
+    for rep in range(2):
+        Ad, bd = dev(Ain), dev(b)
+        info = ops.chol_solve_sym(Ad, bd, half_bandwidth=hb, both_triangles=both)
+        assert int(info) == 0
+        np.testing.assert_allclose(bd.cpu().numpy(), ref, rtol=1e-9, atol=1e-12)
+
+
+def test_chol_solve_sym_reports_non_spd():
+    n, hb = 1000, 130
+    rng = np.random.default_rng(5)
+    M = np.tril(np.triu(rng.normal(size=(n, n)), -hb // 2))
+    A = M @ M.T + n * np.eye(n)
+    for bad_col in (100, 930, 500):            # eliminated by side 0, by side 1 (reversed), in the middle block
+        Ab = A.copy()
+        Ab[bad_col, bad_col] = -1.0
+        info = ops.chol_solve_sym(dev(Ab), dev(np.ones(n)), half_bandwidth=hb, both_triangles=True)
+        assert int(info) > 0, (bad_col, int(info))
+
+
 @pytest.mark.parametrize("F,P,L", [(200, 6000, 12), (130, 2000, 40)])
 def test_schur_solve_overlapped_equals_sequential(F, P, L):
     """mm_ba_schur_solve (S built in camera slabs on one stream while the single-launch Cholesky consumes finished
@@ -440,8 +474,18 @@ def test_schur_solve_overlapped_equals_sequential(F, P, L):
     Cd[:, [0, 3, 5]] *= 1.0 + 1e-3
     hb = 6 * pb.cam_span + 5
     S, v, Cinv0 = pb.schur(cams, pts, Bd, Cd, gc, gp)
-    info0 = ops.chol_solve(S, v, half_bandwidth=hb)
+    Sh = S.cpu().numpy()
+    band = np.abs(np.subtract.outer(np.arange(6 * F), np.arange(6 * F))) <= hb
+    # both triangles of the band are produced: off-diagonal camera blocks as exact mirror images, the diagonal 6 x 6
+    # blocks (sum of Y E^T products, rounded entry by entry) symmetric to rounding
+    assert not Sh[~band].any()
+    blockdiag = np.kron(np.eye(F), np.ones((6, 6))).astype(bool)
+    assert np.array_equal(Sh[~blockdiag], Sh.T[~blockdiag])
+    np.testing.assert_allclose(Sh, Sh.T, rtol=1e-11, atol=1e-12 * np.abs(Sh).max())
+    info0 = ops.chol_solve_sym(S, v, half_bandwidth=hb, both_triangles=True)
     ref = v.clone()
+    np.testing.assert_allclose(ref.cpu().numpy(), np.linalg.solve(Sh, pb.schur(cams, pts, Bd, Cd, gc, gp)[1].cpu().numpy()),
+                               rtol=1e-7, atol=1e-12)
     for _ in range(3):      # repeated: the flags / workspaces are reused
         info, dc, Cinv = pb.schur_solve(cams, pts, Bd, Cd, gc, gp, hb)
         assert int(info) == 0 and int(info0) == 0
