@@ -778,17 +778,19 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, TwGeom 
     __shared__ int s_ok;
     const int bwb = g.bwb, W = bwb + 1, nblk = g.nblk, n = g.n;
     const int G = W + bwb * (bwb - 1) / 2;  // workgroups per side
-    const int side = (int)blockIdx.x / G, lid = (int)blockIdx.x % G;
+    const int side = (int)blockIdx.x / G, lid = (int)blockIdx.x % G;  // side 2: the pre-accumulators of M x M
     const bool tw = g.b > 0;
     const int nrows = side == 0 ? (tw ? g.a + g.m : nblk) : g.b + g.m;  // block rows this side touches
     const int ncols = side == 0 ? nrows : g.b;                         // block columns it eliminates
     int32_t *abort_flag = flags;
-    int32_t *fb = flags + 1 + (size_t)side * tw_side_flags(nblk, W);        // this side's flags
-    int32_t *fo = flags + 1 + (size_t)(1 - side) * tw_side_flags(nblk, W);  // the other side's (read by side 0 only)
+    int32_t *fb = flags + 1 + (size_t)(side & 1) * tw_side_flags(nblk, W);  // this side's flags
+    auto fb0 = [&]() { return flags + 1; };
+    auto fb1 = [&]() { return flags + 1 + tw_side_flags(nblk, W); };
     auto flag = [&](int32_t *base, int r, int d) { return base + (size_t)r * W + d; };
     auto yflag = [&](int32_t *base, int r) { return base + (size_t)nblk * W + r; };
     auto cflag = [&](int32_t *base, int r, int d) { return base + (size_t)nblk * W + nblk + (size_t)r * W + d; };
     auto aflag = [&](int32_t *base, int r) { return base + 2 * (size_t)nblk * W + nblk + r; };
+    auto pflag = [&](int i, int jj) { return flags + 1 + 2 * tw_side_flags(nblk, W) + (size_t)i * g.m + jj; };
     auto nat = [&](int s, int blk) { return s == 0 ? blk : nblk - 1 - blk; };  // block index in natural order
     auto cslot = [&](int s, int r, int d) { return contrib + (((size_t)s * nblk + r) * W + d) * NB; };
     auto linv = [&](int s, int blk) { return Linv + (size_t)nat(s, blk) * NB * NB; };
@@ -801,6 +803,51 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, TwGeom 
         const int s_lo = (NB * q / 6) / cams_per_slab, s_hi = min(n_cams - 1, (NB * q + NB - 1) / 6) / cams_per_slab;
         return wg_wait<MODE>(slab_ready + s_lo, s_hi != s_lo ? slab_ready + s_hi : nullptr, abort_flag, &s_ok);
     };
+    double4_t acc[2][2], a0[2][2];
+    if (side == 2) {
+        // Pre-accumulator of one block (r, c) of M x M.  What the columns of T and of the other end contribute to it
+        // is known long before the elimination reaches M, but its owner on side 0 walks its blocks in column order and
+        // would only start adding 2 bwb tile products when it gets there -- twice the work per block of the steady
+        // state, paid on the chain.  This workgroup adds them up as the columns appear and replaces the block of A by
+        // A_rc - sum; side 0 then eliminates M as a plain continuation of the band.
+        int i = 0, q = lid;
+        while (q > i) {
+            q -= i + 1;
+            ++i;
+        }
+        const int jj = q;  // block (i, jj) of M, jj <= i
+        if (i >= g.m) return;
+        const int r = g.a + i, c = g.a + jj;
+        const TileRef t = tile_ref(A, g, 0, r, c);
+        zero_acc(acc);
+        for (int k = max(0, r - bwb); k < g.a; ++k) {
+            if (r == c && k == r - 1) continue;  // (the head of row r adds L_{r,r-1} L_{r,r-1}^T itself, from its LDS copy)
+            if (!wg_wait<MODE>(flag(fb0(), r, r - k), r != c ? flag(fb0(), c, c - k) : nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
+            load_tile_shared<MODE>(As, tile_ref(A, g, 0, r, k));
+            if (r != c) load_tile_shared<MODE>(Bs, tile_ref(A, g, 0, c, k));
+            __syncthreads();
+            if (r != c)
+                tile_gemm_nt(As, Bs, acc);
+            else
+                tile_gemm_nt(As, As, acc);
+        }
+        // the other end's blocks sit at their natural positions (upper triangle): read with side 0's addressing
+        const int rr = nblk - 1 - r, rc = nblk - 1 - c;  // the two rows in side 1's numbering (rr <= rc)
+        for (int kt = max(0, rc - bwb); kt < g.b; ++kt) {
+            if (!wg_wait<MODE>(flag(fb1(), rr, rr - kt), r != c ? flag(fb1(), rc, rc - kt) : nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
+            load_tile_shared<MODE>(As, tile_ref(A, g, 0, r, nblk - 1 - kt));
+            if (r != c) load_tile_shared<MODE>(Bs, tile_ref(A, g, 0, c, nblk - 1 - kt));
+            __syncthreads();
+            if (r != c)
+                tile_gemm_nt(As, Bs, acc);
+            else
+                tile_gemm_nt(As, As, acc);
+        }
+        if (!rows_ready(r)) MM_FUSED_ABANDON;
+        MM_ACC_FOREACH(if (t.rv(row) && t.cv(col)) st_shared<MODE>(t.at(row, col), ld_shared<MODE>(t.at(row, col)) - acc[a][b][i]);)
+        wg_publish<MODE>(pflag(i, jj));
+        return;
+    }
     // role of this workgroup: offset d (0 = row head: blocks (r, r-1) and (r, r)), first column / row j, period
     int d = 0, j = lid, period = W;
     if (lid >= W) {
@@ -813,34 +860,27 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, TwGeom 
         j = b;
         period = bwb - d + 1;
     }
-    double4_t acc[2][2], a0[2][2];
     if (d >= 2) {
         for (int c = j; c + d < nrows && c < ncols; c += period) {
             const int r = c + d;
             const TileRef t = tile_ref(A, g, side, r, c);
             zero_acc(acc);
-            for (int k = max(0, r - bwb); k < c; ++k) {
+            // a block of M x M: the columns of T and of the other end have been taken care of by its pre-accumulator
+            const bool in_m = tw && side == 0 && c >= g.a;
+            for (int k = max(in_m ? g.a : 0, r - bwb); k < c; ++k) {
                 if (!wg_wait<MODE>(flag(fb, r, r - k), flag(fb, c, c - k), abort_flag, &s_ok)) MM_FUSED_ABANDON;
                 load_tile_shared<MODE>(As, tile_ref(A, g, side, r, k));
                 load_tile_shared<MODE>(Bs, tile_ref(A, g, side, c, k));
                 __syncthreads();
                 tile_gemm_nt(As, Bs, acc);
             }
-            if (tw && side == 0 && c >= g.a) {
-                // both block rows in M: add what the columns eliminated from the other end contribute.  Their blocks
-                // sit at their natural positions (upper triangle), so side 0 reads them with its own addressing.
-                const int rr = nblk - 1 - r, rc = nblk - 1 - c;  // the two rows in side 1's numbering (rr < rc)
-                for (int kt = max(0, rc - bwb); kt < g.b; ++kt) {
-                    if (!wg_wait<MODE>(flag(fo, rr, rr - kt), flag(fo, rc, rc - kt), abort_flag, &s_ok)) MM_FUSED_ABANDON;
-                    load_tile_shared<MODE>(As, tile_ref(A, g, 0, r, nblk - 1 - kt));
-                    load_tile_shared<MODE>(Bs, tile_ref(A, g, 0, c, nblk - 1 - kt));
-                    __syncthreads();
-                    tile_gemm_nt(As, Bs, acc);
-                }
-            }
             // the block's own entries are fetched as late as possible (their latency hides behind the wait for L_cc):
             // when the matrix is still being produced by a concurrent launch, this owner needs them only now
-            if (!rows_ready(side == 0 ? r : nat(1, c))) MM_FUSED_ABANDON;
+            if (in_m) {
+                if (!wg_wait<MODE>(pflag(r - g.a, c - g.a), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
+            } else if (!rows_ready(side == 0 ? r : nat(1, c))) {
+                MM_FUSED_ABANDON;
+            }
             MM_ACC_FOREACH(a0[a][b][i] = (t.rv(row) && t.cv(col)) ? ld_shared<MODE>(t.at(row, col)) : 0.0;)
             if (!wg_wait<MODE>(aflag(fb, c), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
             finish_off_block_a<MODE>(As, Bs, T, a0, acc, tile_ref(A, g, side, c, c), linv(side, c), t);
@@ -873,28 +913,23 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, TwGeom 
         const TileRef st = tile_ref(A, g, side, r, has_sub ? r - 1 : r);  // block (r, r - 1)
         zero_acc(acc);
         zero_acc(acc1);
+        // rows of M (two-ended, side 0): the diagonal block -- and the block left of it when that is in M too -- come
+        // pre-accumulated over the columns of T and of the other end; only the columns of M are left to add
+        const bool diag_pre = tw && side == 0 && r >= g.a, sub_pre = diag_pre && r - 1 >= g.a;
         for (int k = max(0, r - bwb); k + 1 < r; ++k) {
-            if (!wg_wait<MODE>(flag(fb, r, r - k), flag(fb, r - 1, r - 1 - k), abort_flag, &s_ok)) MM_FUSED_ABANDON;
+            const bool do_diag = diag_here && !(diag_pre && k < g.a), do_sub = !(sub_pre && k < g.a);
+            if (!do_diag && !do_sub) continue;
+            if (!wg_wait<MODE>(flag(fb, r, r - k), do_sub ? flag(fb, r - 1, r - 1 - k) : nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
             load_tile_shared<MODE>(As, tile_ref(A, g, side, r, k));
-            load_tile_shared<MODE>(Bs, tile_ref(A, g, side, r - 1, k));
+            if (do_sub) load_tile_shared<MODE>(Bs, tile_ref(A, g, side, r - 1, k));
             __syncthreads();
-            tile_gemm_nt(As, Bs, acc1);
-            if (diag_here) tile_gemm_nt(As, As, acc);
-        }
-        if (tw && side == 0 && r >= g.a) {  // a row of M: the other end's columns
-            const int rr = nblk - 1 - r;     // (row r - 1 is rr + 1 over there)
-            for (int kt = max(0, rr - bwb); kt < g.b; ++kt) {
-                const bool with_sub = r - 1 >= g.a && rr + 1 - kt <= bwb;
-                if (!wg_wait<MODE>(flag(fo, rr, rr - kt), with_sub ? flag(fo, rr + 1, rr + 1 - kt) : nullptr, abort_flag, &s_ok))
-                    MM_FUSED_ABANDON;
-                load_tile_shared<MODE>(As, tile_ref(A, g, 0, r, nblk - 1 - kt));
-                if (with_sub) load_tile_shared<MODE>(Bs, tile_ref(A, g, 0, r - 1, nblk - 1 - kt));
-                __syncthreads();
-                if (with_sub) tile_gemm_nt(As, Bs, acc1);
-                tile_gemm_nt(As, As, acc);
-            }
+            if (do_sub) tile_gemm_nt(As, Bs, acc1);
+            if (do_diag) tile_gemm_nt(As, As, acc);
         }
         // (see the off-diagonal owner: fetched late, hidden behind the next wait)
+        if (diag_pre) {
+            if (!wg_wait<MODE>(pflag(r - g.a, r - g.a), sub_pre ? pflag(r - g.a, r - 1 - g.a) : nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
+        }
         if (diag_here && !rows_ready(nat(side, r))) MM_FUSED_ABANDON;
         if (side == 1 && has_sub && !rows_ready(nat(1, r - 1))) MM_FUSED_ABANDON;
         if (diag_here)
@@ -996,7 +1031,7 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, TwGeom 
             if (tw && side == 0 && r >= g.a) {  // a row of M: what the other end's columns contribute (fixed order)
                 const int rr = nblk - 1 - r;
                 for (int dd = max(1, rr - g.b + 1); dd <= bwb && dd <= rr; ++dd) {
-                    if (!wg_wait<MODE>(cflag(fo, rr, dd), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
+                    if (!wg_wait<MODE>(cflag(fb1(), rr, dd), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
                     if (threadIdx.x < NB) rhs[threadIdx.x] -= ld_shared<MODE>(cslot(1, rr, dd) + threadIdx.x);
                 }
             }
@@ -1290,7 +1325,7 @@ extern "C" {
 size_t mm_chol_workspace_bytes(int n) {
     size_t nblk = (size_t)(n + NB - 1) / NB;
     return mm_align_up(nblk * NB * NB * sizeof(double), 256) + mm_align_up((size_t)(n + NB) * sizeof(double), 256) +
-           mm_align_up((2 * (2 * nblk * (FUSED_MAX_BWB + 1) + 2 * nblk) + 64) * sizeof(int32_t), 256) +
+           mm_align_up((2 * (2 * nblk * (FUSED_MAX_BWB + 1) + 2 * nblk) + 64 + FUSED_MAX_BWB * FUSED_MAX_BWB) * sizeof(int32_t), 256) +
            mm_align_up(2 * nblk * (FUSED_MAX_BWB + 1) * NB * sizeof(double), 256);
 }
 
@@ -1360,7 +1395,7 @@ int mm_chol_solve_gated(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int 
         g.b = nblk - g.m - g.a;
     }
     int32_t *flags = (int32_t *)((char *)ytmp + mm_align_up((size_t)(n + NB) * sizeof(double), 256));
-    double *contrib = (double *)((char *)flags + mm_align_up((2 * (2 * (size_t)nblk * (FUSED_MAX_BWB + 1) + 2 * nblk) + 64) * sizeof(int32_t), 256));
+    double *contrib = (double *)((char *)flags + mm_align_up((2 * (2 * (size_t)nblk * (FUSED_MAX_BWB + 1) + 2 * nblk) + 64 + FUSED_MAX_BWB * FUSED_MAX_BWB) * sizeof(int32_t), 256));
     const int sides = g.b > 0 ? 2 : 1;
     if (fused) {
         if (!ctx->attr_chol_fused) {
@@ -1373,10 +1408,12 @@ int mm_chol_solve_gated(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int 
             MM_LAUNCH(ctx, "chol_mirror_kernel", chol_mirror_kernel, dim3(n - (g.a + g.m) * NB), dim3(256), 0, A, n,
                       (g.a + g.m) * NB, (int)(reach < n - 1 ? reach : n - 1));
         }
-        const size_t nflags = 1 + 2 * (2 * (size_t)nblk * (bwb + 1) + 2 * nblk);
+        const size_t nflags = 1 + 2 * (2 * (size_t)nblk * (bwb + 1) + 2 * nblk) + (size_t)g.m * g.m;
         const double *b_fwd = nrhs >= 1 ? b : nullptr;  // the first right-hand side rides along
         MM_HIP(ctx, hipMemsetAsync(flags, 0, nflags * sizeof(int32_t), ctx->stream));
-        const int grid = sides * ((bwb + 1) + bwb * (bwb - 1) / 2);
+        const int G = (bwb + 1) + bwb * (bwb - 1) / 2;
+        // two-ended: a third group of workgroups, one per block of M x M (fewer than G: m = bwb), pre-accumulates
+        const int grid = g.b > 0 ? 2 * G + g.m * (g.m + 1) / 2 : G;
         MM_LAUNCH(ctx, "chol_band_fused_kernel", chol_band_fused_kernel<2>, dim3(grid), dim3(256), FUSED_LDS_BYTES, A, g, Linv,
                   flags, info, b_fwd, ytmp, contrib, slab_ready, cams_per_slab, n_cams);
         fwd_done = b_fwd != nullptr;

@@ -137,7 +137,10 @@ __global__ __launch_bounds__(64 * SP_WAVES, 2) void schur_pairs_kernel(mm_ba_pro
     if (threadIdx.x < 9) Ks[threadIdx.x] = pb.K[threadIdx.x];
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int64_t c = (int64_t)blockIdx.x * SP_WAVES + (threadIdx.x >> 6);
+    // chunks are ordered by camera; the workgroups take them alternately from the front and from the back, because the
+    // two-ended factorisation that may be consuming S concurrently starts at both ends and needs the middle last
+    const unsigned wg = (blockIdx.x & 1) ? gridDim.x - 1 - (blockIdx.x >> 1) : (blockIdx.x >> 1);
+    const int64_t c = (int64_t)wg * SP_WAVES + (threadIdx.x >> 6);
     if (c >= pb.n_chunks) return;  // wave-uniform; no workgroup barriers below
     const int sidx = pb.chunk_seg[c];
     const int seg = pb.seg_ids[sidx];
