@@ -125,8 +125,80 @@ struct SlabSync {
     int32_t seg_count[MAX_SLABS];
     int cams_per_slab;
 };
-// launch bound 2 waves per SIMD: 256 VGPRs (68 B of scratch) instead of 271 -> twice the waves to hide the f64 latency
-__global__ __launch_bounds__(64 * SP_WAVES, 2) void schur_pairs_kernel(mm_ba_problem pb, const double *__restrict__ cams,
+// Per-camera table for the pair kernel: parameters + rotation coefficients (11 doubles per camera), computed once
+// per build instead of a sincos / sqrt / four divisions in every chunk's prologue.
+constexpr int CAMTAB = 11;
+__global__ __launch_bounds__(64) void cam_table_kernel(int F, const double *__restrict__ cams, double *__restrict__ tab) {
+    const int f = blockIdx.x * 64 + threadIdx.x;
+    if (f >= F) return;
+    const double *c = cams + (size_t)f * 6;
+    const CamCoef k = cam_coef_of(c);
+    double *t = tab + (size_t)f * CAMTAB;
+    for (int q = 0; q < 6; ++q) t[q] = c[q];
+    t[6] = k.c;
+    t[7] = k.a;
+    t[8] = k.b;
+    t[9] = k.a1;
+    t[10] = k.b1;
+}
+
+__device__ __forceinline__ CamVals cam_vals_from_table(const double *__restrict__ t) {
+    CamVals v;
+    v.rx = uniform_f64(t[0]);
+    v.ry = uniform_f64(t[1]);
+    v.rz = uniform_f64(t[2]);
+    v.tx = uniform_f64(t[3]);
+    v.ty = uniform_f64(t[4]);
+    v.tz = uniform_f64(t[5]);
+    v.k.c = uniform_f64(t[6]);
+    v.k.a = uniform_f64(t[7]);
+    v.k.b = uniform_f64(t[8]);
+    v.k.a1 = uniform_f64(t[9]);
+    v.k.b1 = uniform_f64(t[10]);
+    return v;
+}
+
+// Sum over the 64 lanes of a wave of 42 per-lane values, in two rounds of 21 through a [21][65] LDS slab of the wave
+// (row stride 65: the 21 readers hit 21 different banks): every lane writes its values (conflict-free rows), lane q < 21
+// then adds row q in a FIXED order (four interleaved partial sums).  ~170 LDS operations per lane instead of the
+// 6 x 42 x 2 cross-lane shuffles of a butterfly, and the totals end up spread over lanes 0..20 -- the block of S is
+// then written by 21 lanes at once instead of one.  out0 = total of value lane, out1 = total of value 21 + lane.
+constexpr int RED_LD = 65;
+__device__ __forceinline__ void wave_lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ void wave_reduce_42(const double (&acc)[42], double *slab /*[21][65]*/, int lane, double &out0,
+                                               double &out1) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int q = 0; q < 21; ++q) slab[q * RED_LD + lane] = acc[21 * h + q];
+        wave_lds_barrier();
+        double s = 0.0;
+        if (lane < 21) {
+            const double *row = slab + lane * RED_LD;
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+            for (int j = 0; j < 64; j += 4) {
+                s0 += row[j];
+                s1 += row[j + 1];
+                s2 += row[j + 2];
+                s3 += row[j + 3];
+            }
+            s = (s0 + s1) + (s2 + s3);
+        }
+        if (h == 0)
+            out0 = s;
+        else
+            out1 = s;
+        wave_lds_barrier();
+    }
+}
+
+// launch bound 2 waves per SIMD (no scratch: the cameras' values live in scalar registers)
+__global__ __launch_bounds__(64 * SP_WAVES, 2) void schur_pairs_kernel(mm_ba_problem pb, const double *__restrict__ camtab,
                                                                     const double *__restrict__ pts,
                                                                     const double *__restrict__ Cinv,
                                                                     const double *__restrict__ gp,
@@ -134,6 +206,7 @@ __global__ __launch_bounds__(64 * SP_WAVES, 2) void schur_pairs_kernel(mm_ba_pro
                                                                     const double *__restrict__ gc, double *S, double *v,
                                                                     int32_t *seg_done, SlabSync slabs) {
     __shared__ double Ks[9];
+    __shared__ double red[SP_WAVES][21 * RED_LD];
     if (threadIdx.x < 9) Ks[threadIdx.x] = pb.K[threadIdx.x];
     __syncthreads();
     const int lane = threadIdx.x & 63;
@@ -142,16 +215,17 @@ __global__ __launch_bounds__(64 * SP_WAVES, 2) void schur_pairs_kernel(mm_ba_pro
     const unsigned wg = (blockIdx.x & 1) ? gridDim.x - 1 - (blockIdx.x >> 1) : (blockIdx.x >> 1);
     const int64_t c = (int64_t)wg * SP_WAVES + (threadIdx.x >> 6);
     if (c >= pb.n_chunks) return;  // wave-uniform; no workgroup barriers below
-    const int sidx = pb.chunk_seg[c];
-    const int seg = pb.seg_ids[sidx];
+    const int sidx = __builtin_amdgcn_readfirstlane(pb.chunk_seg[c]);
+    const int seg = __builtin_amdgcn_readfirstlane(pb.seg_ids[sidx]);
     const int i = seg / (pb.cam_span + 1), d = seg % (pb.cam_span + 1);
     const int f2 = i - d;
     // two cameras per chunk, not per pair: parameters and rotation coefficients as wave-uniform scalars
-    const CamVals cv_i = cam_vals_uniform(cams + (size_t)i * 6), cv_2 = cam_vals_uniform(cams + (size_t)f2 * 6);
+    const CamVals cv_i = cam_vals_from_table(camtab + (size_t)i * CAMTAB), cv_2 = cam_vals_from_table(camtab + (size_t)f2 * CAMTAB);
     double acc[42];
 #pragma unroll
     for (int q = 0; q < 42; ++q) acc[q] = 0.0;
-    for (int e = pb.chunk_begin[c] + lane; e < pb.chunk_end[c]; e += 64) {
+    const int e_end = __builtin_amdgcn_readfirstlane(pb.chunk_end[c]);
+    for (int e = __builtin_amdgcn_readfirstlane(pb.chunk_begin[c]) + lane; e < e_end; e += 64) {
         const int o = pb.pair_o[e], o2 = pb.pair_o2[e];
         const int p = pb.pi[o];
         const double *Xp = pts + (size_t)p * 3;
@@ -185,7 +259,10 @@ __global__ __launch_bounds__(64 * SP_WAVES, 2) void schur_pairs_kernel(mm_ba_pro
             for (int a = 0; a < 6; ++a) acc[a * 6 + b] += Y[a][0] * x0 + Y[a][1] * x1 + Y[a][2] * x2;
         }
     }
-    wave_sum_n<42>(acc);
+    // totals: lane q < 21 holds value q (tot0) and value 21 + q (tot1); values 0..35 = the 6 x 6 block (row-major),
+    // 36..41 = the right-hand side rows of the self segment
+    double tot0, tot1;
+    wave_reduce_42(acc, red[threadIdx.x >> 6], lane, tot0, tot1);
     // ---- finish the segment: the wave that completes its last chunk writes the block of S (and the rhs rows) ----
     // One chunk (the common case: ~160 pairs per segment): straight from the registers.  Several chunks: every wave
     // leaves its partial sums and counts up; the last one adds the partials IN CHUNK ORDER, so the result does not
@@ -195,44 +272,39 @@ __global__ __launch_bounds__(64 * SP_WAVES, 2) void schur_pairs_kernel(mm_ba_pro
     const size_t n = (size_t)pb.F * 6;
     bool writer = true;
     if (n_ch > 1) {
-        if (lane == 0) {
-#pragma unroll
-            for (int q = 0; q < 42; ++q)
-                __hip_atomic_store(partial + (size_t)c * 42 + q, acc[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane < 21) {
+            __hip_atomic_store(partial + (size_t)c * 42 + lane, tot0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(partial + (size_t)c * 42 + 21 + lane, tot1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
         int last = 0;
         if (lane == 0) last = atomicAdd(seg_done + sidx, 1) == n_ch - 1;
         writer = __shfl(last, 0, 64) != 0;
+        if (writer && lane < 21) {
+            tot0 = 0.0;
+            tot1 = 0.0;
+            for (int cc = 0; cc < n_ch; ++cc) {
+                tot0 += __hip_atomic_load(partial + (size_t)(c_first + cc) * 42 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                tot1 += __hip_atomic_load(partial + (size_t)(c_first + cc) * 42 + 21 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
     if (!writer) return;
-    if (n_ch > 1) {
-        double sum = 0.0;
-        if (lane < 42)
-            for (int cc = 0; cc < n_ch; ++cc)
-                sum += __hip_atomic_load(partial + (size_t)(c_first + cc) * 42 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (lane < 36) {
-            double val = -sum;
-            if (d == 0) val += Bd[(size_t)i * 36 + lane];
-            __hip_atomic_store(S + ((size_t)i * 6 + lane / 6) * n + (size_t)f2 * 6 + lane % 6, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (d != 0)   // the mirror image: the two-ended factorisation eliminates the last cameras in the upper triangle
-                __hip_atomic_store(S + ((size_t)f2 * 6 + lane % 6) * n + (size_t)i * 6 + lane / 6, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else if (lane < 42 && d == 0) {
-            __hip_atomic_store(v + (size_t)i * 6 + (lane - 36), gc[(size_t)i * 6 + (lane - 36)] - sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    } else if (lane == 0) {
+    if (lane < 21) {
 #pragma unroll
-        for (int q = 0; q < 36; ++q) {
-            double val = -acc[q];
-            if (d == 0) val += Bd[(size_t)i * 36 + q];
-            __hip_atomic_store(S + ((size_t)i * 6 + q / 6) * n + (size_t)f2 * 6 + q % 6, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (d != 0)
-                __hip_atomic_store(S + ((size_t)f2 * 6 + q % 6) * n + (size_t)i * 6 + q / 6, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (d == 0) {
-#pragma unroll
-            for (int q = 0; q < 6; ++q)
-                __hip_atomic_store(v + (size_t)i * 6 + q, gc[(size_t)i * 6 + q] - acc[36 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int h = 0; h < 2; ++h) {
+            const int q = 21 * h + lane;
+            const double sum = h == 0 ? tot0 : tot1;
+            if (q < 36) {
+                double val = -sum;
+                if (d == 0) val += Bd[(size_t)i * 36 + q];
+                __hip_atomic_store(S + ((size_t)i * 6 + q / 6) * n + (size_t)f2 * 6 + q % 6, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (d != 0)   // the mirror image: the two-ended factorisation eliminates the last cameras in the upper triangle
+                    __hip_atomic_store(S + ((size_t)f2 * 6 + q % 6) * n + (size_t)i * 6 + q / 6, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (d == 0) {
+                __hip_atomic_store(v + (size_t)i * 6 + (q - 36), gc[(size_t)i * 6 + (q - 36)] - sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
     if (slabs.ready) {  // a concurrent consumer waits for whole camera slabs: count finished segments per slab
@@ -328,12 +400,13 @@ extern "C" size_t mm_ba_schur_workspace_bytes(const mm_ba_problem *pb) {
     if (!pb || pb->n_chunks <= 0) return 0;
     return mm_align_up((size_t)pb->n_chunks * 42 * sizeof(double), 256) /* partial sums of multi-chunk segments */ +
            mm_align_up((size_t)pb->n_seg * sizeof(int32_t), 256) /* finished-chunk counters */ +
-           2 * MAX_SLABS * sizeof(int32_t) /* slab flags, slab counters */;
+           mm_align_up(2 * MAX_SLABS * sizeof(int32_t), 256) /* slab flags, slab counters */ +
+           mm_align_up((size_t)pb->F * CAMTAB * sizeof(double), 256) /* per-camera table */;
 }
 
 namespace {
 struct SchurWs {
-    double *partial;
+    double *partial, *camtab;
     int32_t *seg_done, *slab_ready, *slab_done;
 };
 SchurWs carve_schur_ws(const mm_ba_problem *pb, void *ws) {
@@ -345,6 +418,8 @@ SchurWs carve_schur_ws(const mm_ba_problem *pb, void *ws) {
     p += mm_align_up((size_t)pb->n_seg * sizeof(int32_t), 256);
     w.slab_ready = (int32_t *)p;
     w.slab_done = w.slab_ready + MAX_SLABS;
+    p += mm_align_up(2 * MAX_SLABS * sizeof(int32_t), 256);
+    w.camtab = (double *)p;
     return w;
 }
 }  // namespace
@@ -371,8 +446,9 @@ extern "C" int mm_ba_schur(mm_ctx *ctx, const mm_ba_problem *pb, const double *c
         const SchurWs w = carve_schur_ws(pb, ws);
         MM_HIP(ctx, hipMemsetAsync(w.seg_done, 0, (size_t)pb->n_seg * sizeof(int32_t), ctx->stream));
         SlabSync none = {};
-        MM_LAUNCH(ctx, "schur_pairs_kernel", schur_pairs_kernel, dim3((unsigned)wgs), dim3(64 * SP_WAVES), 0, *pb, cams,
-                  pts, (const double *)Cinv, gp, w.partial, Bd, gc, S, v, w.seg_done, none);
+        MM_LAUNCH(ctx, "cam_table_kernel", cam_table_kernel, dim3((pb->F + 63) / 64), dim3(64), 0, pb->F, cams, w.camtab);
+        MM_LAUNCH(ctx, "schur_pairs_kernel", schur_pairs_kernel, dim3((unsigned)wgs), dim3(64 * SP_WAVES), 0, *pb,
+                  (const double *)w.camtab, pts, (const double *)Cinv, gp, w.partial, Bd, gc, S, v, w.seg_done, none);
         return MM_OK;
     }
     const int nwin = (pb->F + SR_WIN - 1) / SR_WIN;
@@ -417,12 +493,13 @@ extern "C" int mm_ba_schur_solve(mm_ctx *ctx, const mm_ba_problem *pb, const dou
         MM_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     }
     const SchurWs w = carve_schur_ws(pb, ws_schur);
+    MM_LAUNCH(ctx, "point_inverse_kernel", point_inverse_kernel, dim3((pb->P + 255) / 256), dim3(256), 0, pb->P, Cd, Cinv);
     SlabSync slabs = {};
     slabs.ready = w.slab_ready;
     slabs.done = w.slab_done;
     slabs.cams_per_slab = cams_per_slab;
     for (int sl = 0; sl < n_slabs; ++sl) slabs.seg_count[sl] = (int32_t)(slab_seg_ptr[sl + 1] - slab_seg_ptr[sl]);
-    MM_LAUNCH(ctx, "point_inverse_kernel", point_inverse_kernel, dim3((pb->P + 255) / 256), dim3(256), 0, pb->P, Cd, Cinv);
+    MM_LAUNCH(ctx, "cam_table_kernel", cam_table_kernel, dim3((pb->F + 63) / 64), dim3(64), 0, pb->F, cams, w.camtab);
     MM_HIP(ctx, hipMemsetAsync(S, 0, (size_t)n * n * sizeof(double), ctx->stream));
     MM_HIP(ctx, hipMemsetAsync(w.seg_done, 0, (size_t)pb->n_seg * sizeof(int32_t), ctx->stream));
     MM_HIP(ctx, hipMemsetAsync(w.slab_ready, 0, 2 * MAX_SLABS * sizeof(int32_t), ctx->stream));
@@ -444,7 +521,8 @@ extern "C" int mm_ba_schur_solve(mm_ctx *ctx, const mm_ba_problem *pb, const dou
     // ONE launch builds all of S; chunks are ordered by camera, so the slabs complete roughly in ascending order and
     // the waves that finish a slab's last segment raise its flag (no kernel boundaries inside the build)
     MM_LAUNCH(ctx, "schur_pairs_kernel", schur_pairs_kernel, dim3((unsigned)((pb->n_chunks + SP_WAVES - 1) / SP_WAVES)),
-              dim3(64 * SP_WAVES), 0, *pb, cams, pts, (const double *)Cinv, gp, w.partial, Bd, gc, S, v, w.seg_done, slabs);
+              dim3(64 * SP_WAVES), 0, *pb, (const double *)w.camtab, pts, (const double *)Cinv, gp, w.partial, Bd, gc, S, v,
+              w.seg_done, slabs);
     MM_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     return MM_OK;
 }

@@ -235,7 +235,10 @@ class BADevice:
         # build + solve overlapped on two streams (mm_ba_schur_solve).  Needs concurrent kernel execution: tools that
         # serialise kernels (rocprofv3 --pmc, launch-blocking debug modes) make the consumer wait for a producer that
         # cannot start; its bounded spins then give up (info = -1) and the driver falls back to one after the other.
-        self.overlap = os.environ.get("MM_SCHUR_OVERLAP", "1") != "0"
+        # Off by default since the factorisation became two-ended: its 137 workgroups use the whole register file of
+        # their CUs (one wave per SIMD), the build slows down by 1.6x beside them and build-then-solve (0.32 + 0.59 ms at
+        # 500 cameras) beats the overlapped pair (0.93 ms).  MM_SCHUR_OVERLAP=1 selects the overlapped path.
+        self.overlap = os.environ.get("MM_SCHUR_OVERLAP", "0") != "0"
         self.pb = BAProblem(F, P, O, ptr(self.K), ptr(self.fi), ptr(self.pi), ptr(self.obs),
                             ptr(self.pt_ptr), ptr(self.pt_obs), ptr(self.cam_ptr), ptr(self.cam_obs),
                             0, 0, 0, None, None, 0, None, None, None, None, None)

@@ -33,8 +33,16 @@ for s, e, n in rows[1:]:
         g[1] += s - end
     if e > end:
         end, last = e, n
+by_kernel = defaultdict(lambda: [0, 0])
+for s_, e_, n_ in rows:
+    by_kernel[n_][0] += 1
+    by_kernel[n_][1] += e_ - s_
 span = end - t0
 idle = sum(g[1] for g in gaps.values())
 print(f"window {span / 1e6:.2f} ms, idle {idle / 1e6:.2f} ms ({100 * idle / span:.1f} %), {len(rows)} launches")
 for (p, n), (c, t) in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:25]:
     print(f"{t / 1e6:8.3f} ms  {c:6d} x {t / max(c, 1) / 1e3:7.1f} us   {p[:40]:40s} -> {n[:40]}")
+n_it = max(by_kernel.get("ba_point_blocks_kernel", [1])[0] - 1, 1)
+print(f"--- kernel time inside the window ({n_it} iterations, {span / 1e3 / n_it:.0f} us each) ---")
+for n_, (c, t) in sorted(by_kernel.items(), key=lambda kv: -kv[1][1])[:30]:
+    print(f"{t / 1e6:8.3f} ms  {c:6d} x {t / max(c, 1) / 1e3:7.1f} us  = {t / 1e3 / n_it:7.1f} us/iteration   {n_[:60]}")
