@@ -3,14 +3,21 @@
 // Replaces cv2.FlannBasedMatcher(...).knnMatch(prev_desc, new_desc, k=2) and the ratio filter of
 // processor.featureTracking (reference processor.py:132-137) by the exact search FLANN-LSH approximates.
 //
-// Mapping to the hardware (DESIGN.md §"bf_knn2"):
-//  * one lane owns QPL query descriptors (8 VGPRs each); a wave covers 64*QPL queries;
-//  * the train descriptor is wave-uniform, so it is fetched with scalar loads (s_load_dwordx8) and fed to
-//    v_xor_b32 as an SGPR operand: per descriptor pair 8 v_xor_b32 + 8 v_bcnt_u32_b32 (popcount-accumulate)
-//    + 1 v_lshl_or_b32 (key = dist<<20 | train) + min / med3 to keep the two smallest keys.  No LDS, no
-//    cross-lane traffic; the bound is VALU integer issue, HBM traffic is 0.02 B/pair.
-//  * ties resolve to the lowest train index because the index is the low part of the key.
-//  * small launches split the train range over blockIdx.y and merge partial top-2 keys in a second kernel.
+// Mapping to the hardware:
+//  * one lane owns one query descriptor (8 VGPRs); a wave covers 64 queries, a workgroup 256;
+//  * the workgroup stages 128 train descriptors at a time in LDS (double buffered, the next chunk's global loads fly
+//    during the current chunk's compute); every lane reads the same train with two same-address ds_read_b128 (LDS
+//    broadcast) so that the eight v_xor_b32 take VGPR operands (2.6 cycles per wave instruction; 4.1 with an SGPR
+//    operand, measured: profiles/r01_valu_issue_rates.txt); 8 v_bcnt_u32_b32 accumulate the popcounts;
+//  * trains are handled in groups of four: a candidate can only enter the two smallest keys (key = dist << 20 | train
+//    index, ties -> lowest train index) if its distance is below the current second-best distance, so the group's
+//    minimum is tested and the min / med3 bookkeeping sits behind a wave-uniform, rarely taken branch:
+//    18.8 VALU instructions per descriptor pair, 16 of them the xor / popcount floor;
+//  * no cross-lane traffic, 0.02 B of HBM per pair: the bound is VALU integer issue.  Measured
+//    with the SQ counters (profiles/r02_bf_pmc.txt): 3.84 cycles per VALU instruction at the 2.1 GHz the chip holds
+//    under this load = 91 % of the issue roof of this instruction mix (v_bcnt / v_min issue at quarter rate);
+//  * small launches split the train range over blockIdx.y and merge partial top-2 keys in a second kernel;
+//  * the SGPR-fed variants (train descriptor by scalar loads, bf_knn2_kernel) are kept for MM_BF_VARIANT tuning runs.
 #include "mm_common.h"
 #include <cstdlib>
 
@@ -142,12 +149,13 @@ __device__ __forceinline__ void top2_insert_med3(uint32_t key, uint32_t &b0, uin
     b1 = m;
 }
 
-template <int BF_QPL>
+template <int BF_QPL, int TCH = BF_TCHUNK>
 __global__ __launch_bounds__(BF_THREADS) void bf_knn2_lds_kernel(
     const uint8_t *__restrict__ q, const int32_t *__restrict__ nq_dev, int nq_cap, size_t q_stride,
     const uint8_t *__restrict__ t, const int32_t *__restrict__ nt_dev, int nt_cap, size_t t_stride, int n_splits,
     uint32_t *__restrict__ part, int32_t *__restrict__ idx, int32_t *__restrict__ dist) {
-    __shared__ uint4 tl[2][BF_TCHUNK * 2];
+    constexpr int NST = TCH / 128;  // 16-byte pieces per thread and stage
+    __shared__ uint4 tl[2][TCH * 2];
     const int pair = blockIdx.z;
     const int split = blockIdx.y;
     int nq = nq_dev ? min(nq_dev[pair], nq_cap) : nq_cap;
@@ -180,17 +188,24 @@ __global__ __launch_bounds__(BF_THREADS) void bf_knn2_lds_kernel(
 
     const uint4 *__restrict__ tp = reinterpret_cast<const uint4 *>(t + (size_t)pair * t_stride);
     // stage 0
-    uint4 stage = make_uint4(0, 0, 0, 0);
-    if (2 * j0 + (int)threadIdx.x < 2 * j1) stage = tp[2 * j0 + threadIdx.x];
-    tl[0][threadIdx.x] = stage;
+    uint4 stage[NST];
+#pragma unroll
+    for (int z = 0; z < NST; ++z) {
+        const int e = 2 * j0 + z * BF_THREADS + (int)threadIdx.x;
+        stage[z] = e < 2 * j1 ? tp[e] : make_uint4(0, 0, 0, 0);
+        tl[0][z * BF_THREADS + threadIdx.x] = stage[z];
+    }
     __syncthreads();
     int buf = 0;
-    for (int c0 = j0; c0 < j1; c0 += BF_TCHUNK) {
-        const int cn = min(BF_TCHUNK, j1 - c0);
-        const int nxt = c0 + BF_TCHUNK;
+    for (int c0 = j0; c0 < j1; c0 += TCH) {
+        const int cn = min(TCH, j1 - c0);
+        const int nxt = c0 + TCH;
         if (nxt < j1) {  // prefetch the next chunk into registers (in flight during the compute below)
-            stage = make_uint4(0, 0, 0, 0);
-            if (2 * nxt + (int)threadIdx.x < 2 * j1) stage = tp[2 * nxt + threadIdx.x];
+#pragma unroll
+            for (int z = 0; z < NST; ++z) {
+                const int e = 2 * nxt + z * BF_THREADS + (int)threadIdx.x;
+                stage[z] = e < 2 * j1 ? tp[e] : make_uint4(0, 0, 0, 0);
+            }
         }
         const uint4 *tb = tl[buf];
         int k = 0;
@@ -227,7 +242,8 @@ __global__ __launch_bounds__(BF_THREADS) void bf_knn2_lds_kernel(
             }
         }
         if (nxt < j1) {
-            tl[buf ^ 1][threadIdx.x] = stage;
+#pragma unroll
+            for (int z = 0; z < NST; ++z) tl[buf ^ 1][z * BF_THREADS + threadIdx.x] = stage[z];
             __syncthreads();
             buf ^= 1;
         }
@@ -374,6 +390,14 @@ int mm_bf_knn2_batched(mm_ctx *ctx, const uint8_t *q, const int32_t *nq, int nq_
     MM_LAUNCH(ctx, "bf_knn2_kernel", (bf_knn2_lds_kernel<Q>), grid, dim3(BF_THREADS), 0, q, nq, nq_cap, q_set_stride, t, \
               nt, nt_cap, t_set_stride, s, (uint32_t *)ws, idx, dist)
         case 114: BF_GO_LDS(1); break;
+        case 115:
+            MM_LAUNCH(ctx, "bf_knn2_kernel", (bf_knn2_lds_kernel<1, 512>), grid, dim3(BF_THREADS), 0, q, nq, nq_cap, q_set_stride,
+                      t, nt, nt_cap, t_set_stride, s, (uint32_t *)ws, idx, dist);
+            break;
+        case 125:
+            MM_LAUNCH(ctx, "bf_knn2_kernel", (bf_knn2_lds_kernel<2, 512>), grid, dim3(BF_THREADS), 0, q, nq, nq_cap, q_set_stride,
+                      t, nt, nt_cap, t_set_stride, s, (uint32_t *)ws, idx, dist);
+            break;
         case 124: BF_GO_LDS(2); break;
         case 134: BF_GO_LDS(3); break;
         case 144: BF_GO_LDS(4); break;

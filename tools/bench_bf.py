@@ -15,7 +15,7 @@ F, N = int(os.environ.get("BF_F", 500)), int(os.environ.get("BF_N", 4000))
 g = torch.Generator(device="cpu").manual_seed(0)
 desc = torch.randint(0, 256, (F, N, 32), dtype=torch.uint8, generator=g).to(dev)
 pairs = (F - 1) * N * N
-variants = [24, 28, 48, 114, 124, 134, 144]
+variants = [114] if os.environ.get('BF_ONLY') else [24, 114, 115, 124]
 res = {v: [] for v in variants}
 t = Timer(ctx)
 ref = None
