@@ -218,6 +218,8 @@ int mm_multi_dot(mm_ctx *ctx, int k, const double *const *a, const double *const
  *   op 3: in {w, q1, si, gh, x}  scalars {wn2}  outv {q2 = w/sqrt(wn2), s1 = q1/si, s2 = q2/si}
  *                                                                              rows: s1.s1, s1.s2, s2.s2, q2.gh, x.x | -
  *   op 4: in {x, s1, s2}  h0, h1      outv {x + h0 s1 + h1 s2}                 (no result rows)
+ *   op 5: in {x, s1, s2}  scalars {p[2]}  outv {x + p[0] s1 + p[1] s2}  with p in device memory (mm_trf_step2d);
+ *         p[1] == 0 skips s2 (one-dimensional subspace)                        (no result rows)
  * out [(K+1), 3] dev; workspace as for mm_multi_dot (zero-filled once). */
 int mm_trf_fused(mm_ctx *ctx, int op, const double *const *in, double *const *outv, const double *const *scalars,
                  double h0, double h1, int64_t n, int64_t split, double *out, void *ws, size_t ws_bytes);
@@ -238,6 +240,21 @@ int mm_ba_schur_solve(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, 
                       int half_bandwidth, int32_t *info, void *ws_schur, size_t ws_schur_bytes, void *ws_chol,
                       size_t ws_chol_bytes, int n_slabs, int cams_per_slab, const int64_t *slab_seg_ptr,
                       const int64_t *slab_chunk_ptr);
+/* Block glue of the trust-region driver (one launch each instead of a handful of tensor-library kernels):
+ * scale_update: scale_inv [6F+3P] = sqrt of the diagonal of J^T J taken from B [F,6,6] and C [P,6] (packed upper
+ *   triangle); first != 0: zeros become 1 (SciPy compute_jac_scale), else the running maximum with the stored value;
+ * damp: Bd = B + reg diag(scale_inv_c^2), Cd = C + reg diag(scale_inv_p^2), reg [1] in device memory. */
+int mm_ba_scale_update(mm_ctx *ctx, int F, int P, const double *B, const double *C, double *scale_inv /*in/out*/, int first);
+int mm_ba_damp(mm_ctx *ctx, int F, int P, const double *B, const double *C, const double *scale_inv, const double *reg /*dev [1]*/,
+               double *Bd, double *Cd);
+/* The 2-D trust-region subproblem of a TRF iteration solved on the device (SciPy trf.py:481-494, common.py:171-219) from
+ * the results of the fused passes, all still in device memory: r0 [2,3] (op 0), d11 [1,3] = <J g_hs, J g_hs>, r1 [3,3]
+ * (op 1), r2 [2,3] (op 2), r3 [6,3] (op 3), bs [2,3] = {<u1, J s2>, <J s2, J s2>} (the "total" column of each is used),
+ * reg [1] the damping in use, info [1] the factorisation status.  board [14] receives p0, p1 (step in the orthonormal
+ * basis; feed them to mm_trf_fused op 5), predicted reduction, |p|, unscaled step norm, degenerate flag, info, and the
+ * scalars the host-side bookkeeping needs (wn2, gn2, |x|^2, |g|_inf, |g_h|^2, d11, reg): one read-back per trial step. */
+int mm_trf_step2d(mm_ctx *ctx, const double *r0, const double *d11, const double *r1, const double *r2, const double *r3,
+                  const double *bs, const double *reg, const int32_t *info, double Delta, double *board /*dev [14]*/);
 /* SPD solve A x = b by blocked Cholesky (f64 MFMA trailing updates).  A [n,n] row-major, lower triangle is
  * overwritten by L; b [nrhs,n] is overwritten by x.  half_bandwidth: A[i][j] == 0 whenever i - j > half_bandwidth
  * (pass n for a dense matrix); the factorisation and the substitutions skip blocks outside the band.

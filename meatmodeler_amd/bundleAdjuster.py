@@ -279,6 +279,11 @@ class SchurTRF:
 
     def _normal(self, x, g):
         """Block normal equations at x; the gradient goes straight into the flat buffer g."""
+        if self._native:      # the sweeps write B / C into the persistent blocks and g_c / g_p into the two halves of g
+            out = (self._B, self._cams(g), self._C, self._pts(g))
+            B, gc, C, gp = self.pb.normal_eq(self._cams(x), self._pts(x), out=out)
+            self._ar(B, gc)
+            return B, C
         B, gc, C, gp = self.pb.normal_eq(self._cams(x), self._pts(x))
         self._ar(B, gc)          # camera blocks are sums over all observations; point blocks are local
         g[:self.nc] = gc.reshape(-1)
@@ -286,19 +291,23 @@ class SchurTRF:
         return B, C
 
     def _scale_inv(self, B, C, old=None):
+        if self._native:      # one launch: sqrt of the block diagonals, zeros -> 1 / running maximum, in place
+            return self.pb.scale_update(B, C, self._si, old is None)
         si = torch.cat([torch.diagonal(B, dim1=1, dim2=2).reshape(-1), C[:, self.diag_idx].reshape(-1)]).sqrt_()
         if old is None:
             si[si == 0] = 1.0
             return si
         return torch.maximum(si, old)
 
-    def _damping_patterns(self, si):
-        """scale_inv^2 laid out like the blocks it is added to: [F,6,6] diagonal and the packed [P,6] upper triangle."""
+    def _damped_blocks(self, B, C, si, reg):
+        """B + reg diag(scale_inv^2), C + reg diag(scale_inv^2) (packed 6)."""
+        if self._native:
+            return self.pb.damp(B, C, si, reg, self._Bd, self._Cd)
         nc, F, P = self.nc, self.pb.F, self.pb.P
         sic2_36 = torch.diag_embed((si[:nc] * si[:nc]).view(F, 6))
         sip2_6 = torch.zeros((P, 6), dtype=si.dtype, device=si.device)
         sip2_6[:, self.diag_idx] = (si[nc:] * si[nc:]).view(P, 3)
-        return sic2_36, sip2_6
+        return torch.addcmul(B, sic2_36, reg), torch.addcmul(C, sip2_6, reg)
 
     def _serial_fallback(self, x, Bd, Cd, gc, gp, half_bw, solve=True):
         warnings.warn("mm_ba_schur_solve: kernels are being serialised; building and solving the reduced system one "
@@ -317,6 +326,12 @@ class SchurTRF:
         x = torch.cat([cams0.reshape(-1), pts0.reshape(-1)]).to(**f64).contiguous()
         g = torch.empty(n, **f64)
         self.diag_idx = torch.tensor([0, 3, 5], device=dev)
+        # block glue as single launches on persistent buffers when the problem object provides them (ops.BADevice)
+        self._native = hasattr(pb, "damp") and hasattr(pb, "scale_update")
+        if self._native:
+            self._B, self._C = torch.empty((F, 6, 6), **f64), torch.empty((P, 6), **f64)
+            self._Bd, self._Cd = torch.empty((F, 6, 6), **f64), torch.empty((P, 6), **f64)
+            self._si = torch.empty(n, **f64)
 
         c2 = self._cost_dev(x)
         cost = 0.5 * float(c2.item())
@@ -336,9 +351,10 @@ class SchurTRF:
         band_exchange = (self.allreduce is not None and hasattr(pb, "band_view")
                          and span_all <= getattr(pb, "max_band_span", 192) and half_bw < nc)
         nfev, njev = 1, 1
+        if self._native and self.allreduce is None and hasattr(pb, "trf_step2d") and hasattr(pb, "schur_solve"):
+            return self._solve_single_gpu(x, g, cost, half_bw, ftol, xtol, gtol, max_nfev, verbose)
         B, C = self._normal(x, g)
         si = self._scale_inv(B, C)
-        sic2_36, sip2_6 = self._damping_patterns(si)
         xs = x * si
         Delta = float(torch.sqrt(self._dots([(xs, xs)])[0]).item())
         if Delta == 0:
@@ -386,8 +402,7 @@ class SchurTRF:
             reg_eff = damp[1:2]
             gc, gp = self._cams(g), self._pts(g)
             for attempt in range(6):
-                Bd = torch.addcmul(B, sic2_36, reg_eff)   # B + reg diag(scale_inv^2), C + reg diag(...) (packed 6)
-                Cd = torch.addcmul(C, sip2_6, reg_eff)
+                Bd, Cd = self._damped_blocks(B, C, si, reg_eff)
                 if self.allreduce is None and hasattr(pb, "schur_solve"):
                     # one GPU: the build of S and its factorisation overlap (mm_ba_schur_solve)
                     info, v, Cinv = pb.schur_solve(self._cams(x), self._pts(x), Bd, Cd, gc, gp, half_bw)
@@ -503,7 +518,6 @@ class SchurTRF:
                 B, C = self._normal(x, g)
                 njev += 1
                 si = self._scale_inv(B, C, si)
-                sic2_36, sip2_6 = self._damping_patterns(si)
             else:
                 step_norm = 0
                 actual = 0
@@ -513,6 +527,136 @@ class SchurTRF:
         return BAResult(cams=self._cams(x).clone(), pts=self._pts(x).clone(), cost=cost, optimality=g_norm, nfev=nfev,
                         njev=njev, status=termination, message=_MESSAGES[termination], success=termination > 0,
                         iterations=iteration, host_segments_ms={k: 1e3 * v for k, v in seg.items()})
+
+
+def _solve_single_gpu(self, x, g, cost, half_bw, ftol, xtol, gtol, max_nfev, verbose):
+    """The same iteration as `SchurTRF.solve`'s generic loop (which serves the sharded path and the CPU stand-in), for ONE
+    GPU with everything device resident: the 2-D trust-region subproblem is solved by a kernel from the fused passes'
+    results (mm_trf_step2d), the trial point is formed from its output and the host reads one small board of scalars
+    per trial step -- after the trial cost is known -- instead of synchronising twice per iteration."""
+    pb = self.pb
+    F, P, nc = pb.F, pb.P, self.nc
+    n = nc + 3 * P
+    f64 = dict(dtype=torch.float64, device=pb.device)
+    cams, pts = self._cams, self._pts
+    nfev, njev = 1, 1
+    B, C = self._normal(x, g)
+    si = self._scale_inv(B, C)
+    xs = x * si
+    Delta = float(torch.sqrt(pb.multi_dot([(xs, xs)], nc)[0, 2]).item())
+    del xs
+    if Delta == 0:
+        Delta = 1.0
+    if max_nfev is None:
+        max_nfev = n * 100
+    gh, ghs, gn, q1, w, q2, s1, s2, x_new = (torch.empty_like(g) for _ in range(9))
+    board = torch.zeros(16, **f64)
+    cost_slot = board[14:15]
+    alpha = 0.0
+    termination, iteration, step_norm, actual, g_norm = None, 0, None, None, None
+    if verbose == 2:
+        _print_header()
+    seg = {"to_syncA": 0.0, "syncA_to_accept": 0.0}
+    t_mark = time.perf_counter()
+    while True:
+        r0 = pb.trf_fused(0, [g, si], [gh, ghs], split=nc)                  # rows: |g_h|^2 ; max |g|
+        gh2_t = r0[0, 2:3]
+        u1 = pb.jvp(cams(x), pts(x), cams(ghs), pts(ghs)).reshape(-1)       # J (d g_h)
+        d11 = pb.multi_dot([(u1, u1)], 0)
+        if termination is not None or nfev == max_nfev:
+            g_norm = float(r0[1, 2].item())
+            if verbose == 2:
+                _print_iteration(iteration, nfev, cost, actual, step_norm, g_norm)
+            break
+        damp = pb.trf_damping(gh2_t, d11[0, 2:3], Delta, self.min_damping)
+        reg_eff = damp[1:2]
+        gc, gp = cams(g), pts(g)
+        vals = None
+        for attempt in range(6):
+            Bd, Cd = self._damped_blocks(B, C, si, reg_eff)
+            info, v, Cinv = pb.schur_solve(cams(x), pts(x), Bd, Cd, gc, gp, half_bw)
+            dp = pb.backsub(cams(x), pts(x), Cinv, gp, v.view(F, 6)).reshape(-1)
+            # orthonormal basis of span{g_h, gn_h} (trf.py:481-482) in three fused passes (see the generic loop)
+            r1 = pb.trf_fused(1, [v, dp, si, gh], [gn, q1], [gh2_t], split=nc)
+            r2 = pb.trf_fused(2, [gn, q1], [w], [r1[0, 2:3]], split=nc)
+            r3 = pb.trf_fused(3, [w, q1, si, gh, x], [q2, s1, s2], [r2[0, 2:3]], split=nc)
+            Jq2 = pb.jvp(cams(x), pts(x), cams(s2), pts(s2)).reshape(-1)
+            bs = pb.multi_dot([(u1, Jq2), (Jq2, Jq2)], 0)
+
+            def trial(Delta_):
+                pb.trf_step2d(r0, d11, r1, r2, r3, bs, reg_eff, info, Delta_, board)
+                pb.trf_fused(5, [x, s1, s2], [x_new], [board], split=nc)
+                pb.residual(cams(x_new), pts(x_new), cost_out=cost_slot)
+                return board.tolist()                                     # ---- the host sync of a trial step ----
+
+            vals = trial(Delta)          # enqueued before the host knows whether the factorisation succeeded
+            inf = int(vals[6])
+            if inf == 0:
+                break
+            if inf < 0:
+                # the single-launch factorisation gave up waiting (see the generic loop): build and solve one after
+                # the other from here on
+                if getattr(pb, "overlap", False):
+                    self._serial_fallback(x, Bd, Cd, gc, gp, half_bw, solve=False)
+                    continue
+                raise MMError("mm_chol_solve: the fused banded factorisation was abandoned (info = -1)")
+            if vals[13] <= self.min_damping * (1.0 + 1e-12):      # failed AT the floor: the floor was too low
+                self.min_damping *= 100.0
+            reg_eff = reg_eff * 100.0
+        else:
+            raise MMError(f"reduced camera system is not positive definite (pivot {int(vals[6])})")
+        g_norm, xx = vals[10], vals[9]
+        t_now = time.perf_counter()
+        seg["to_syncA"] += t_now - t_mark
+        t_mark = t_now
+        if g_norm < gtol:                              # (checked before the step is used, as trf.py:443 does; the
+            termination = 1                            # trial point enqueued above is simply dropped)
+        if verbose == 2:
+            _print_iteration(iteration, nfev, cost, actual, step_norm, g_norm)
+        if termination is not None:
+            break
+        x_norm = np.sqrt(xx)
+        actual = -1.0
+        have = True
+        while actual <= 0 and nfev < max_nfev:
+            if not have:
+                vals = trial(Delta)
+            have = False
+            predicted, step_h_norm, step_norm_dev = vals[2], vals[3], vals[4]
+            cost_new = 0.5 * vals[14]
+            nfev += 1
+            if not np.isfinite(cost_new):
+                Delta = 0.25 * step_h_norm
+                continue
+            actual = cost - cost_new
+            Delta_new, ratio = _update_tr_radius(Delta, actual, predicted, step_h_norm, step_h_norm > 0.95 * Delta)
+            step_norm = float(step_norm_dev)
+            termination = _check_termination(actual, cost, step_norm, x_norm, ratio, ftol, xtol)
+            if termination is not None:
+                break
+            alpha *= Delta / Delta_new
+            Delta = Delta_new
+        t_now = time.perf_counter()
+        seg["syncA_to_accept"] += t_now - t_mark
+        t_mark = t_now
+        if actual > 0:
+            x, x_new = x_new, x
+            cost = cost_new
+            B, C = self._normal(x, g)
+            njev += 1
+            si = self._scale_inv(B, C, si)
+        else:
+            step_norm = 0
+            actual = 0
+        iteration += 1
+    if termination is None:
+        termination = 0
+    return BAResult(cams=cams(x).clone(), pts=pts(x).clone(), cost=cost, optimality=g_norm, nfev=nfev,
+                    njev=njev, status=termination, message=_MESSAGES[termination], success=termination > 0,
+                    iterations=iteration, host_segments_ms={k: 1e3 * v for k, v in seg.items()})
+
+
+SchurTRF._solve_single_gpu = _solve_single_gpu
 
 
 def _finish_verbose(res, cost0, verbose):

@@ -137,6 +137,8 @@ struct FusedArgs {
 // OP 2: w = gn - sc * q1;                                sums: w.w
 // OP 3: q2 = w / sqrt(wn2), s1 = q1 / si, s2 = q2 / si;  sums: s1.s1, s1.s2, s2.s2, q2.gh, x.x
 // OP 4: x_new = x + h0 * s1 + h1 * s2;                   no sums
+// OP 5: the same with (h0, h1) = scalar[0][0..1] read from device memory (mm_trf_step2d); h1 == 0 skips s2 entirely
+//       (a one-dimensional subspace leaves s2 = w / |w| with |w| = 0 undefined)
 template <int OP>
 struct FusedTraits;
 template <> struct FusedTraits<0> { static constexpr int K = 1; };
@@ -144,6 +146,7 @@ template <> struct FusedTraits<1> { static constexpr int K = 2; };
 template <> struct FusedTraits<2> { static constexpr int K = 1; };
 template <> struct FusedTraits<3> { static constexpr int K = 5; };
 template <> struct FusedTraits<4> { static constexpr int K = 0; };
+template <> struct FusedTraits<5> { static constexpr int K = 0; };
 
 template <int OP>
 __device__ __forceinline__ void fused_elem(const FusedArgs &a, int64_t i, int64_t split, double (&p)[FV_MAXK], double &mx) {
@@ -179,8 +182,13 @@ __device__ __forceinline__ void fused_elem(const FusedArgs &a, int64_t i, int64_
         p[2] = s2 * s2;
         p[3] = q2 * a.in[3][i];
         p[4] = x * x;
-    } else {
+    } else if constexpr (OP == 4) {
         a.out[0][i] = a.in[0][i] + a.h0 * a.in[1][i] + a.h1 * a.in[2][i];
+    } else {
+        const double h0 = a.scalar[0][0], h1 = a.scalar[0][1];
+        double v = a.in[0][i] + h0 * a.in[1][i];
+        if (h1 != 0.0) v += h1 * a.in[2][i];
+        a.out[0][i] = v;
     }
 }
 
@@ -295,8 +303,8 @@ int launch_fused(mm_ctx *ctx, const FusedArgs &args, int64_t n, int64_t split, d
 extern "C" int mm_trf_fused(mm_ctx *ctx, int op, const double *const *in, double *const *outv, const double *const *scalars,
                             double h0, double h1, int64_t n, int64_t split, double *out, void *ws, size_t ws_bytes) {
     if (!ctx) return MM_ERR_ARG;
-    static const int n_in[5] = {2, 4, 2, 5, 3}, n_out[5] = {2, 2, 1, 3, 1}, n_sc[5] = {0, 1, 1, 1, 0};
-    if (op < 0 || op > 4 || !in || !outv || n < 0 || split < 0 || split > n) return mm_fail(ctx, MM_ERR_ARG, "mm_trf_fused: bad argument");
+    static const int n_in[6] = {2, 4, 2, 5, 3, 3}, n_out[6] = {2, 2, 1, 3, 1, 1}, n_sc[6] = {0, 1, 1, 1, 0, 1};
+    if (op < 0 || op > 5 || !in || !outv || n < 0 || split < 0 || split > n) return mm_fail(ctx, MM_ERR_ARG, "mm_trf_fused: bad argument");
     if (!ws || ws_bytes < mm_multi_dot_workspace_bytes() || ((uintptr_t)ws & 255))
         return mm_fail(ctx, MM_ERR_WORKSPACE, "mm_trf_fused: workspace too small or misaligned");
     FusedArgs a = {};
@@ -312,11 +320,11 @@ extern "C" int mm_trf_fused(mm_ctx *ctx, int op, const double *const *in, double
         if (!scalars || !scalars[q]) return mm_fail(ctx, MM_ERR_ARG, "mm_trf_fused: null scalar %d", q);
         a.scalar[q] = scalars[q];
     }
-    if (op != 4 && !out) return mm_fail(ctx, MM_ERR_ARG, "mm_trf_fused: null result");
+    if (op < 4 && !out) return mm_fail(ctx, MM_ERR_ARG, "mm_trf_fused: null result");
     a.h0 = h0;
     a.h1 = h1;
     if (n == 0) {  // nothing to map; the sums (and maxima) of an empty vector are zero
-        static const int rows[5] = {2, 3, 2, 6, 0};
+        static const int rows[6] = {2, 3, 2, 6, 0, 0};
         if (rows[op]) MM_HIP(ctx, hipMemsetAsync(out, 0, (size_t)rows[op] * 3 * sizeof(double), ctx->stream));
         return MM_OK;
     }
@@ -327,6 +335,217 @@ extern "C" int mm_trf_fused(mm_ctx *ctx, int op, const double *const *in, double
         case 1: return launch_fused<1>(ctx, a, n, split, partial, counter, out);
         case 2: return launch_fused<2>(ctx, a, n, split, partial, counter, out);
         case 3: return launch_fused<3>(ctx, a, n, split, partial, counter, out);
-        default: return launch_fused<4>(ctx, a, n, split, partial, counter, out);
+        case 4: return launch_fused<4>(ctx, a, n, split, partial, counter, out);
+        default: return launch_fused<5>(ctx, a, n, split, partial, counter, out);
     }
+}
+
+
+// ---- block glue of the trust-region driver ---------------------------------------------------------------------------------
+// scale_inv (SciPy x_scale='jac', common.py:598-610): si_i = sqrt((J^T J)_ii) from the diagonals of the camera blocks
+// B [F,6,6] and of the packed point blocks C [P,6] (xx,xy,xz,yy,yz,zz); first call: zeros become 1, later calls: running
+// maximum with the previous value.  One launch instead of diagonal / index / cat / sqrt / maximum.
+namespace {
+__global__ __launch_bounds__(256) void ba_scale_update_kernel(int64_t nc, int64_t n, const double *__restrict__ B,
+                                                              const double *__restrict__ C, double *__restrict__ si,
+                                                              int first) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double d;
+    if (i < nc) {
+        const int64_t f = i / 6, a = i % 6;
+        d = B[f * 36 + a * 7];
+    } else {
+        const int64_t j = i - nc, p = j / 3, a = j % 3;
+        d = C[p * 6 + (a == 0 ? 0 : (a == 1 ? 3 : 5))];
+    }
+    double v = sqrt(d);
+    if (first)
+        v = v == 0.0 ? 1.0 : v;
+    else
+        v = fmax(v, si[i]);
+    si[i] = v;
+}
+
+// damped blocks  Bd = B + reg diag(si_c^2),  Cd = C + reg diag(si_p^2)  (reg read from device memory)
+__global__ __launch_bounds__(256) void ba_damp_kernel(int64_t F, int64_t P, const double *__restrict__ B,
+                                                      const double *__restrict__ C, const double *__restrict__ si,
+                                                      const double *__restrict__ reg_p, double *__restrict__ Bd,
+                                                      double *__restrict__ Cd) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const double reg = reg_p[0];
+    const int64_t nb = F * 36;
+    if (i < nb) {
+        const int64_t f = i / 36, e = i % 36;
+        double v = B[i];
+        if (e % 7 == 0) {
+            const double s = si[f * 6 + e / 7];
+            v = fma(s * s, reg, v);
+        }
+        Bd[i] = v;
+    } else if (i < nb + P * 6) {
+        const int64_t j = i - nb, p = j / 6, e = j % 6;
+        double v = C[j];
+        if (e == 0 || e == 3 || e == 5) {
+            const double s = si[F * 6 + p * 3 + (e == 0 ? 0 : (e == 3 ? 1 : 2))];
+            v = fma(s * s, reg, v);
+        }
+        Cd[j] = v;
+    }
+}
+}  // namespace
+
+extern "C" int mm_ba_scale_update(mm_ctx *ctx, int F, int P, const double *B, const double *C, double *scale_inv, int first) {
+    if (!ctx) return MM_ERR_ARG;
+    if (F < 0 || P < 0 || (F > 0 && !B) || (P > 0 && !C) || !scale_inv) return mm_fail(ctx, MM_ERR_ARG, "mm_ba_scale_update: bad argument");
+    const int64_t n = (int64_t)F * 6 + (int64_t)P * 3;
+    if (n == 0) return MM_OK;
+    MM_LAUNCH(ctx, "ba_scale_update_kernel", ba_scale_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (int64_t)F * 6,
+              n, B, C, scale_inv, first);
+    return MM_OK;
+}
+
+extern "C" int mm_ba_damp(mm_ctx *ctx, int F, int P, const double *B, const double *C, const double *scale_inv,
+                          const double *reg, double *Bd, double *Cd) {
+    if (!ctx) return MM_ERR_ARG;
+    if (F < 0 || P < 0 || !scale_inv || !reg || (F > 0 && (!B || !Bd)) || (P > 0 && (!C || !Cd)))
+        return mm_fail(ctx, MM_ERR_ARG, "mm_ba_damp: bad argument");
+    const int64_t n = (int64_t)F * 36 + (int64_t)P * 6;
+    if (n == 0) return MM_OK;
+    MM_LAUNCH(ctx, "ba_damp_kernel", ba_damp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (int64_t)F, (int64_t)P, B, C,
+              scale_inv, reg, Bd, Cd);
+    return MM_OK;
+}
+
+
+// ---- the 2-D trust-region subproblem on the device ---------------------------------------------------------------------------
+// SciPy solves  min 0.5 p^T B p + g^T p,  |p| <= Delta  in the plane span{g_h, gn_h} (trf.py:481-494 via
+// common.py:171-219): Cholesky attempt for the interior solution, otherwise the stationary points of the model on the
+// circle as the real roots of a quartic in tan(phi / 2).  Here the scalars that define B and g stay in device memory
+// (they are results of the fused passes), one wave solves the subproblem and the trial point is formed from its
+// output, so the host no longer has to read them back between building the subspace and the trial step: ONE host
+// synchronisation per trial step instead of two.  Boundary case: the derivative of the model along the circle is
+// sampled at 128 angles; every sign change is narrowed by 64-ary search across the lanes (9 rounds reach the
+// resolution of a double) and the stationary point with the smallest model value wins -- the same minimiser as the
+// quartic's, to rounding.
+namespace {
+struct Step2dIn {
+    const double *r0, *d11, *r1, *r2, *r3, *bs, *reg;
+    const int32_t *info;
+};
+
+__device__ __forceinline__ double model_2d(double b00, double b01, double b11, double g0, double g1, double p0, double p1) {
+    return 0.5 * (p0 * (b00 * p0 + b01 * p1) + p1 * (b01 * p0 + b11 * p1)) + (g0 * p0 + g1 * p1);
+}
+
+__global__ __launch_bounds__(64) void trf_step2d_kernel(Step2dIn in, double Delta, double *__restrict__ board) {
+    const int lane = threadIdx.x;
+    const double gh2 = in.r0[2], gmax = in.r0[5], d11 = in.d11[2], gn2 = in.r1[5], wn2 = in.r2[2];
+    double n11 = in.r3[2], n12 = in.r3[5], n22 = in.r3[8], g2 = in.r3[11];
+    const double xx = in.r3[14];
+    const double u1Jq2 = in.bs[2];
+    double b22 = in.bs[5];
+    const double gh_norm = sqrt(gh2);
+    const double b11 = d11 / gh2;
+    double b12 = u1Jq2 / gh_norm;
+    const bool degenerate = !(wn2 > 1e-28 * fmax(gn2, 1e-300));  // gn_h parallel to g_h: the subspace is one-dimensional
+    if (degenerate) {
+        b12 = 0.0;
+        b22 = 1.0;
+        n12 = 0.0;
+        n22 = 0.0;
+        g2 = 0.0;
+    }
+    const double b00 = b11, b01 = b12, bb = b22, g0 = gh_norm, g1 = g2;
+    double p0 = 0.0, p1 = 0.0;
+    bool interior = false;
+    {   // interior solution if B is positive definite and the Newton point lies inside
+        const double det = b00 * bb - b01 * b01;
+        if (b00 > 0.0 && det > 0.0) {
+            const double l00 = sqrt(b00), l10 = b01 / l00, l11sq = bb - l10 * l10;
+            if (l11sq > 0.0) {
+                const double l11 = sqrt(l11sq);
+                const double y0 = -g0 / l00, y1 = (-g1 - l10 * y0) / l11;   // L y = -g
+                p1 = y1 / l11;
+                p0 = (y0 - l10 * p1) / l00;                                   // L^T p = y
+                interior = p0 * p0 + p1 * p1 <= Delta * Delta;
+            }
+        }
+    }
+    if (!interior) {
+        // derivative of the model along p = Delta (cos phi, sin phi)
+        auto dmodel = [&](double phi) {
+            double s, c;
+            sincos(phi, &s, &c);
+            return Delta * Delta * ((bb - b00) * c * s + b01 * (c * c - s * s)) + Delta * (-g0 * s + g1 * c);
+        };
+        const double two_pi = 6.283185307179586476925286766559;
+        const double h = two_pi / 128.0;
+        // lane l owns the sample intervals [2l, 2l+1] and [2l+1, 2l+2] (x h)
+        const double f_a = dmodel(h * (2 * lane)), f_b = dmodel(h * (2 * lane + 1)), f_c = dmodel(h * (2 * lane + 2));
+        const unsigned long long m0 = __ballot((f_a <= 0.0) != (f_b <= 0.0));
+        const unsigned long long m1 = __ballot((f_b <= 0.0) != (f_c <= 0.0));
+        double best_val = 1.0e308, best_p0 = Delta, best_p1 = 0.0;
+        for (int half = 0; half < 2; ++half) {
+            unsigned long long m = half == 0 ? m0 : m1;
+            while (m) {
+                const int src = __builtin_ctzll(m);
+                m &= m - 1;
+                double lo = h * (2 * src + half), hi = lo + h;
+                bool lo_neg = dmodel(lo) <= 0.0;   // (wave-uniform: every lane evaluates the same point)
+                for (int round = 0; round < 9; ++round) {
+                    const double w = (hi - lo) / 64.0;
+                    const double x0 = lo + w * lane;
+                    const bool neg = dmodel(x0) <= 0.0;
+                    // the sign change sits behind the LAST lane whose sample still has the sign of `lo`
+                    const unsigned long long same = __ballot(neg == lo_neg);
+                    int k = 0;
+                    while (k < 63 && ((same >> (k + 1)) & 1ull)) ++k;   // leading run of equal signs (lane 0 is `lo` itself)
+                    lo = lo + w * k;
+                    hi = lo + w;
+                }
+                const double phi = 0.5 * (lo + hi);
+                double s, c;
+                sincos(phi, &s, &c);
+                const double q0 = Delta * c, q1 = Delta * s;
+                const double val = model_2d(b00, b01, bb, g0, g1, q0, q1);
+                if (val < best_val) {
+                    best_val = val;
+                    best_p0 = q0;
+                    best_p1 = q1;
+                }
+            }
+        }
+        p0 = best_p0;
+        p1 = best_p1;
+    }
+    if (degenerate) p1 = 0.0;
+    if (lane == 0) {
+        const double predicted = -model_2d(b00, b01, bb, g0, g1, p0, p1);
+        board[0] = p0;
+        board[1] = p1;
+        board[2] = predicted;
+        board[3] = sqrt(p0 * p0 + p1 * p1);
+        board[4] = sqrt(fmax(p0 * p0 * n11 + 2.0 * p0 * p1 * n12 + p1 * p1 * n22, 0.0));
+        board[5] = degenerate ? 1.0 : 0.0;
+        board[6] = (double)in.info[0];
+        board[7] = wn2;
+        board[8] = gn2;
+        board[9] = xx;
+        board[10] = gmax;
+        board[11] = gh2;
+        board[12] = d11;
+        board[13] = in.reg[0];
+    }
+}
+}  // namespace
+
+extern "C" int mm_trf_step2d(mm_ctx *ctx, const double *r0, const double *d11, const double *r1, const double *r2, const double *r3,
+                             const double *bs, const double *reg, const int32_t *info, double Delta, double *board) {
+    if (!ctx) return MM_ERR_ARG;
+    if (!r0 || !d11 || !r1 || !r2 || !r3 || !bs || !reg || !info || !board || !(Delta >= 0.0))
+        return mm_fail(ctx, MM_ERR_ARG, "mm_trf_step2d: bad argument");
+    Step2dIn in = {r0, d11, r1, r2, r3, bs, reg, info};
+    MM_LAUNCH(ctx, "trf_step2d_kernel", trf_step2d_kernel, dim3(1), dim3(64), 0, in, Delta, board);
+    return MM_OK;
 }

@@ -302,10 +302,11 @@ class BADevice:
         self._schur_ws = None
         self._chol_ws = None
 
-    def residual(self, cams, pts, want_res=False):
-        """-> (sum of squared residuals as a 1-element device tensor, res [O,2] or None)."""
+    def residual(self, cams, pts, want_res=False, cost_out=None):
+        """-> (sum of squared residuals as a 1-element device tensor, res [O,2] or None).  cost_out: where to put the
+        sum (a 1-element f64 device tensor, e.g. a slot of the trust-region driver's scalar board)."""
         res = torch.empty((self.O, 2), dtype=torch.float64, device=self.device) if want_res else None
-        cost2 = torch.empty(1, dtype=torch.float64, device=self.device)
+        cost2 = cost_out if cost_out is not None else torch.empty(1, dtype=torch.float64, device=self.device)
         self.ctx.check(lib.mm_ba_residual(self.ctx.h, C.byref(self.pb), ptr(cams), ptr(pts), ptr(res), ptr(cost2),
                                           ptr(self._ws), self._ws.numel()), "mm_ba_residual")
         return cost2, res
@@ -317,12 +318,19 @@ class BADevice:
                        "mm_ba_jacobian")
         return Jc, Jp
 
-    def normal_eq(self, cams, pts, want_cams=True, want_pts=True):
+    def normal_eq(self, cams, pts, want_cams=True, want_pts=True, out=None):
+        """-> (B [F,6,6], gc [F,6], C [P,6], gp [P,3]); `out` = the four tensors to fill (any contiguous storage of
+        the right size, e.g. the two halves of the flat gradient vector for gc / gp)."""
         d = self.device
-        B = torch.empty((self.F, 6, 6), dtype=torch.float64, device=d) if want_cams else None
-        gc = torch.empty((self.F, 6), dtype=torch.float64, device=d) if want_cams else None
-        Cb = torch.empty((self.P, 6), dtype=torch.float64, device=d) if want_pts else None
-        gp = torch.empty((self.P, 3), dtype=torch.float64, device=d) if want_pts else None
+        if out is not None:
+            B, gc, Cb, gp = out
+            for t_ in out:
+                assert t_ is None or (t_.dtype == torch.float64 and t_.is_contiguous())
+        else:
+            B = torch.empty((self.F, 6, 6), dtype=torch.float64, device=d) if want_cams else None
+            gc = torch.empty((self.F, 6), dtype=torch.float64, device=d) if want_cams else None
+            Cb = torch.empty((self.P, 6), dtype=torch.float64, device=d) if want_pts else None
+            gp = torch.empty((self.P, 3), dtype=torch.float64, device=d) if want_pts else None
         self.ctx.check(lib.mm_ba_normal_eq(self.ctx.h, C.byref(self.pb), ptr(cams), ptr(pts), ptr(B), ptr(gc), ptr(Cb),
                                            ptr(gp)), "mm_ba_normal_eq")
         return B, gc, Cb, gp
@@ -394,7 +402,7 @@ class BADevice:
             self._mdot = MultiDot(self.device, self.ctx)
         return self._mdot(pairs, split)
 
-    _FUSED_ROWS = (2, 3, 2, 6, 0)
+    _FUSED_ROWS = (2, 3, 2, 6, 0, 0)
 
     def trf_fused(self, op, ins, outs, scalars=(), h0=0.0, h1=0.0, split=0):
         """One fused element-wise pass of the trust-region step with its inner products (mm_trf_fused).
@@ -416,6 +424,11 @@ class BADevice:
                                         ws.numel()), "mm_trf_fused")
         return res
 
+    def trf_step2d(self, r0, d11, r1, r2, r3, bs, reg, info, Delta, board):
+        """2-D trust-region subproblem on the device from the fused passes' results (mm_trf_step2d) -> board[0:14]."""
+        self.ctx.check(lib.mm_trf_step2d(self.ctx.h, ptr(r0), ptr(d11), ptr(r1), ptr(r2), ptr(r3), ptr(bs), ptr(reg),
+                                         ptr(info), float(Delta), ptr(board)), "mm_trf_step2d")
+
     def trf_damping(self, gh2, d11, Delta, min_damping):
         """Device scalars -> tensor [reg, max(reg, min_damping)] (see ops.trf_damping)."""
         return trf_damping(gh2, d11, Delta, min_damping, self.ctx)
@@ -423,6 +436,19 @@ class BADevice:
     def chol_solve(self, S, v, half_bandwidth=None):
         """In-place banded Cholesky solve of the reduced camera system (see ops.chol_solve)."""
         return chol_solve(S, v, self.ctx, half_bandwidth=half_bandwidth)
+
+    def scale_update(self, B, Cb, si, first):
+        """si <- sqrt(diag(J^T J)) (first: zeros -> 1) or max(si, sqrt(diag)) in one launch (mm_ba_scale_update)."""
+        self.ctx.check(lib.mm_ba_scale_update(self.ctx.h, self.F, self.P, ptr(B), ptr(Cb), ptr(si), 1 if first else 0),
+                       "mm_ba_scale_update")
+        return si
+
+    def damp(self, B, Cb, si, reg, Bd, Cd):
+        """Bd = B + reg diag(si_c^2), Cd = C + reg diag(si_p^2); reg: 1-element device tensor (mm_ba_damp)."""
+        assert reg.dtype == torch.float64 and reg.numel() == 1
+        self.ctx.check(lib.mm_ba_damp(self.ctx.h, self.F, self.P, ptr(B), ptr(Cb), ptr(si), ptr(reg), ptr(Bd), ptr(Cd)),
+                       "mm_ba_damp")
+        return Bd, Cd
 
     def chol_solve_sym(self, S, v, half_bandwidth, both_triangles):
         """Solution only (S destroyed): lets a narrow band be eliminated from both ends (see ops.chol_solve_sym)."""
