@@ -67,7 +67,8 @@ def algorithmic_work(name, cfg):
     kp = cfg.get("kp_total_local", F * N)
     if name == "bf_knn2_kernel":
         pairs = cfg["pair_evals_local"]
-        return cfg["pairs_local"] * (32 * 2 * N + 16 * N), pairs * 20.6, 0
+        # 8 v_xor_b32 + 8 v_bcnt_u32_b32 = 16 lane-ops per descriptor pair is the unit of the roof
+        return cfg["pairs_local"] * (32 * 2 * N + 16 * N), pairs * 16.0, 0
     if name == "orb_fast_kernel":
         return F * (sum(px) + 4 * cfg.get("cand_per_frame", 0)), F * sum(px) * 80, 0
     if name == "orb_resize_kernel":
@@ -257,17 +258,20 @@ def main():
         in_timed = dom_full["kernel"] in timed
         pmc = {}
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"].get(dom["kernel"], {})
+            pmc_file = next(f for f in ("r02_pmc_traffic.json", "r01_pmc_traffic.json")
+                            if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))["kernels"].get(dom["kernel"], {})
         except Exception:
-            pass
+            pmc_file = None
         traffic = None
         if F == 500 and N == 4000 and "FETCH_SIZE_KB_per_launch" in pmc and "WRITE_SIZE_KB_per_launch" in pmc:
             traffic = (pmc["FETCH_SIZE_KB_per_launch"] + pmc["WRITE_SIZE_KB_per_launch"]) * 1024.0
         if dom["kernel"] == "chol_band_fused_kernel":
-            note = ("single-launch banded Cholesky: a chain of %d dependent 64-column steps (factor 64x64 -> solve -> "
-                    "update), bound by the latency of that chain, not by MFMA throughput; on one GPU it runs concurrently "
-                    "with the build of the matrix (schur_pairs_kernel, other stream) and its duration includes waiting for "
-                    "finished row slabs -- alone it takes 0.84 ms (tools/bench_chol.py)" % ((6 * F + 63) // 64))
+            nblk_ = (6 * F + 63) // 64
+            bwb_ = min((6 * cfg.get("cam_span", F) + 5 + 63) // 64, nblk_)
+            note = ("single-launch banded Cholesky, eliminated from both ends of the band at once: a chain of %d dependent "
+                    "64-column steps (factor 64x64 -> solve -> update; %d one-ended), bound by the latency of that chain, "
+                    "not by MFMA throughput" % ((nblk_ - bwb_ + 1) // 2 + bwb_ if nblk_ - bwb_ >= 4 else nblk_, nblk_))
         else:
             note = None
         if "mfma_f64_TFLOPs" in dom:
@@ -286,9 +290,21 @@ def main():
         if note:
             roofline["note"] = note
         if traffic is not None:
-            roofline["traffic_note"] = ("FETCH_SIZE + WRITE_SIZE per launch from separate rocprofv3 --pmc passes "
-                                        "(profiles/r01_pmc_traffic.json); FETCH not doubled: 8-byte gathers are uncalibrated")
+            roofline["traffic_note"] = ("NOT measured by this run: FETCH_SIZE + WRITE_SIZE per launch read from the committed "
+                                        "file profiles/%s (separate rocprofv3 --pmc passes of this same command, "
+                                        "tools/gpu_evidence.sh); FETCH not doubled: 8-byte gathers are uncalibrated" % pmc_file)
     bf = next((k for k in kernels if k["kernel"] == "bf_knn2_kernel"), None)
+    if bf is not None and "valu_Tlops" in bf:
+        bf = dict(bf)
+        # the roof SURVEY section 8(d) fixes (16 lane-ops per pair at the nominal 78.6 T lane-ops/s = 4.9 T pairs/s) ...
+        bf["valu_frac_of_16op_roof"] = bf["valu_Tlops"] / VALU_PEAK_TLOPS
+        bf["T_pairs_per_s"] = bf["valu_Tlops"] / 16.0
+        # ... and the issue roof of the instruction mix the kernel really executes, from the SQ counters of
+        # profiles/r02_bf_pmc.txt: 18.83 VALU instructions per pair (8 xor at 2.63 + 10.83 quarter-rate ops at 4.14 cycles)
+        bf["instr_per_pair_measured"] = 18.83
+        bf["issue_cycles_per_pair_roof"] = 8 * 2.63 + 10.83 * 4.14
+        bf["note"] = ("VALU-integer issue bound, 0.02 B of HBM per pair; counters: 3.84 cycles per VALU instruction at the "
+                      "2.1 GHz held under this load = 91 % of the issue roof of the mix (profiles/r02_bf_pmc.txt)")
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -335,24 +351,47 @@ def main():
 
 def cpu_baseline(frames, nfeatures, n_frames):
     """The CPU oracle ("port" of the reference's CPU path: the C restatement of ORB + BF matching, and the reference's
-    own SciPy TRF/LSMR recipe on the NumPy restatement of pointFun) timed on this box's host cores, single thread,
-    on a bounded sample of the same workload."""
+    own SciPy TRF/LSMR recipe on the NumPy restatement of pointFun) timed on this box's host cores on a bounded sample
+    of the same workload: one frame / one pair on one core, then one frame / pair per available core in parallel
+    (threads around the C calls, which release the GIL) for the all-core rate; BA on 100 frames / 20 000 points."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import orb_oracle as oo
     from oracle import ba_oracle as bo
     from meatmodeler_amd import synth
     from meatmodeler_amd.orb_pattern import brief_pattern
-    ns = min(2, frames.shape[0])
-    host = frames[:ns].cpu().numpy()
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 32, frames.shape[0]))
+    host = frames[:cores].cpu().numpy()
+    pat = brief_pattern()
+    oo.detect_compute(host[0][:64, :64].copy(), 50, pat)           # (builds / loads the library outside the timings)
     t0 = time.perf_counter()
-    dets = [oo.detect_compute(host[i], nfeatures, brief_pattern()) for i in range(ns)]
-    t_orb = (time.perf_counter() - t0) / ns
+    d0 = oo.detect_compute(host[0], nfeatures, pat)
+    t_orb1 = time.perf_counter() - t0
     t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        dets = list(ex.map(lambda im: oo.detect_compute(im, nfeatures, pat), host))
+    t_orb_all = (time.perf_counter() - t0) / len(host)             # wall time per frame with all cores busy
     a_, b_ = dets[0]["desc"], dets[-1]["desc"]
+    t0 = time.perf_counter()
     idx, dist_ = oo.bf_knn2(a_, b_)
     oo.ratio_filter(idx, dist_, 0.75)
-    t_match = time.perf_counter() - t0
+    t_match1 = time.perf_counter() - t0
     pairs = float(len(a_)) * float(len(b_))
-    pr = synth.make_ba_problem(40, 4000, 6, seed=1)
+
+    def one_pair(k):
+        i_, d_ = oo.bf_knn2(dets[k]["desc"], dets[(k + 1) % len(dets)]["desc"])
+        oo.ratio_filter(i_, d_, 0.75)
+        return float(len(dets[k]["desc"])) * float(len(dets[(k + 1) % len(dets)]["desc"]))
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        pairs_all = sum(ex.map(one_pair, range(len(dets))))
+    t_match_all = time.perf_counter() - t0
+    Fb, Pb = 100, 20000
+    pr = synth.make_ba_problem(Fb, Pb, 6, seed=1)
     t0 = time.perf_counter()
     _, _, r = bo.adjust_points(pr["ext"], pr["K"], pr["pts0"][:, None, :], pr["obs"], pr["fi"], pr["pi"],
                                return_result=True)
@@ -360,13 +399,16 @@ def cpu_baseline(frames, nfeatures, n_frames):
     O = len(pr["fi"])
     ba_rps = O * r.nfev / t_ba
     obs_per_frame = 0.9 * nfeatures
-    frame_s = t_orb + t_match + obs_per_frame * 4 / ba_rps
-    return {"value": pairs / t_match, "unit": "descriptor pairs/s", "cores": 1, "kind": "port",
-            "sample": f"{ns} frames ORB ({t_orb * 1e3:.0f} ms/frame), 1 frame pair {len(a_)}x{len(b_)} BF match "
-                      f"({t_match * 1e3:.0f} ms), SciPy TRF+LSMR BA on 40 frames/4000 points/{O} observations "
-                      f"({t_ba:.2f} s, {r.nfev} nfev)",
-            "orb_ms_per_frame": t_orb * 1e3, "match_ms_per_pair": t_match * 1e3, "ba_residuals_per_s": ba_rps,
-            "frames_per_s_estimate": 1.0 / frame_s, "host_cpu_count": os.cpu_count()}
+    frame_s = t_orb_all + t_match_all / max(len(dets), 1) + obs_per_frame * 4 / ba_rps
+    return {"value": pairs_all / t_match_all, "unit": "descriptor pairs/s", "cores": cores, "kind": "port",
+            "sample": f"ORB: 1 frame on 1 core {t_orb1 * 1e3:.0f} ms, {len(host)} frames on {cores} cores "
+                      f"{t_orb_all * 1e3:.0f} ms per frame; BF match {len(a_)}x{len(b_)}: 1 pair on 1 core "
+                      f"{t_match1 * 1e3:.0f} ms, {len(dets)} pairs on {cores} cores {t_match_all * 1e3:.0f} ms in all; "
+                      f"SciPy TRF+LSMR BA (the reference's recipe, SciPy's own threading) on {Fb} frames / {Pb} points / "
+                      f"{O} observations: {t_ba:.2f} s, {r.nfev} nfev",
+            "value_1core": pairs / t_match1, "orb_ms_per_frame_1core": t_orb1 * 1e3,
+            "orb_ms_per_frame_all_cores": t_orb_all * 1e3, "match_ms_per_pair_1core": t_match1 * 1e3,
+            "ba_residuals_per_s": ba_rps, "frames_per_s_estimate": 1.0 / frame_s, "host_cpu_count": os.cpu_count()}
 
 
 if __name__ == "__main__":
