@@ -337,7 +337,12 @@ def main():
                 "ms": stage_ms["ba_windows"], "nfev_total": int(sum(w["nfev"] for w in out["windows"])),
                 "observations_total": int(sum(w["observations"] for w in out["windows"])),
                 "residual_evals_per_s": sum(w["observations"] * w["nfev"] for w in out["windows"]) /
-                                        max(stage_ms["ba_windows"] * 1e-3, 1e-9)},
+                                        max(stage_ms["ba_windows"] * 1e-3, 1e-9),
+                "status_counts": {str(k): int(sum(1 for w in out["windows"] if w["status"] == k))
+                                  for k in sorted({w["status"] for w in out["windows"]})},
+                "per_window": [[w["lo"], w["hi"], w["points"], w["observations"], w["nfev"], w["status"],
+                                float(f"{w['cost']:.6g}")] for w in out["windows"]],
+                "per_window_columns": ["lo", "hi", "points", "observations", "nfev", "status", "cost"]},
             "roofline": roofline,
             "bf_knn2": bf,
             "kernels": kernels[:12],
