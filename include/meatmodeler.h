@@ -273,6 +273,38 @@ int mm_chol_solve_sym(mm_ctx *ctx, double *A /*dev*/, int n, double *b /*dev [n]
 int mm_chol_solve(mm_ctx *ctx, double *A /*dev*/, int n, double *b /*dev*/, int nrhs, int half_bandwidth,
                   int32_t *info /*dev*/, void *ws, size_t ws_bytes);
 
+/* ---- keyframe gating front end (reference processor.py:61-110 keyframeTracking) ------------------------------------------
+ * The arithmetic of the three calls is defined by oracle/frame_oracle.c (OpenCV's published algorithms made integer exact;
+ * OpenCV itself is absent offline: parity unpinned) and reproduced bit for bit.
+ * mm_pyr_down: one pyramid level, 5-tap [1 4 6 4 1]/16, reflect-101: dst [(h+1)/2, (w+1)/2].
+ * mm_lk_track: cv2.calcOpticalFlowPyrLK(prev, next, pts, None, winSize, maxLevel, criteria) (processor.py:79) on pyramids
+ *   built with mm_pyr_down.  prev_levels / next_levels / w / h / pitch: HOST arrays of `levels` (= maxLevel + 1) device
+ *   pointers / sizes; pts [n,2] f32 dev.  next_pts [n,2] f32, status [n] u8, err [n] f32 (dev).  window 3..41, <= 8 levels.
+ * mm_min_eig: Shi-Tomasi minimum eigenvalue map [h,w] f64 (cornerMinEigenVal scaling for 8-bit input), block size 1..15.
+ * mm_corner_candidates: pixels above quality * max that survive the 3x3 non-maximum suppression -> value bit patterns
+ *   [cap] i64 and flat positions [cap] i32 (unordered), count [1]; the caller sorts (value desc, position asc) and runs
+ * mm_gftt_select (host): greedy minimum-distance selection of cv2.goodFeaturesToTrack (processor.py:104). */
+int mm_pyr_down(mm_ctx *ctx, const uint8_t *src /*dev*/, int w, int h, int src_pitch, uint8_t *dst /*dev*/, int dst_pitch);
+int mm_lk_track(mm_ctx *ctx, const uint8_t *const *prev_levels, const uint8_t *const *next_levels, const int *w, const int *h,
+                const int *pitch, int levels, const float *pts, int n, int win_w, int win_h, int max_count,
+                double epsilon_sq, float *next_pts, uint8_t *status, float *err);
+int mm_min_eig(mm_ctx *ctx, const uint8_t *img /*dev*/, int w, int h, int pitch, int block_size, double *eig /*dev*/);
+int mm_corner_candidates(mm_ctx *ctx, const double *eig, int w, int h, double quality, unsigned long long *max_bits /*dev [1]*/,
+                         long long *val_bits /*dev [cap]*/, int32_t *pos /*dev [cap]*/, int cap, int32_t *count /*dev [1]*/);
+int mm_gftt_select(const int32_t *pos /*host [n], sorted*/, int64_t n, int w, int h, int max_corners, double min_distance,
+                   float *out /*host [cap,2]*/, int cap);
+/* ---- increaseContrast + grey (reference processor.py:12-26, :357) and the PLY export (processor.py:480-485) ---------------
+ * mm_increase_contrast: bgr [batch,h,w,3] u8 -> out (same shape), optionally grey [batch,h,w] of the result: fixed-point
+ *   BGR <-> L*a*b* with the tables of meatmodeler_amd/frame_tables.py (gamma [256] u16, cbrt_tab [4096] u16, gamma_inv
+ *   [4096] u8, device), CLAHE(clip_limit, tiles) on L.  mm_bgr_to_grey: (1868 B + 9617 G + 4899 R + 8192) >> 14.
+ * mm_write_ply (host): binary little-endian PLY, double x / y / z per vertex. */
+size_t mm_contrast_workspace_bytes(int batch, int w, int h, int tiles_x, int tiles_y);
+int mm_increase_contrast(mm_ctx *ctx, const uint8_t *bgr, int batch, int w, int h, const uint16_t *gamma,
+                         const uint16_t *cbrt_tab, const uint8_t *gamma_inv, double clip_limit, int tiles_x, int tiles_y,
+                         uint8_t *out, uint8_t *grey /*dev|NULL*/, void *ws, size_t ws_bytes);
+int mm_bgr_to_grey(mm_ctx *ctx, const uint8_t *bgr /*dev [n,3]*/, size_t n_pixels, uint8_t *grey /*dev [n]*/);
+int mm_write_ply(const char *path, const double *xyz /*host [n,3]*/, int64_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -88,6 +88,16 @@ SIGNATURES = {
     "mm_ba_scale_update": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int]),
     "mm_ba_damp": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),
     "mm_trf_step2d": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_double, vp]),
+    "mm_pyr_down": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int]),
+    "mm_lk_track": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, vp, vp, vp]),
+    "mm_min_eig": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "mm_corner_candidates": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_double, vp, vp, vp, C.c_int, vp]),
+    "mm_gftt_select": (C.c_int, [vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_double, vp, C.c_int]),
+    "mm_contrast_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mm_increase_contrast": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_double, C.c_int, C.c_int, vp, vp, vp,
+                                       C.c_size_t]),
+    "mm_bgr_to_grey": (C.c_int, [vp, vp, C.c_size_t, vp]),
+    "mm_write_ply": (C.c_int, [C.c_char_p, vp, C.c_int64]),
     "mm_chol_solve_sym": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, C.c_size_t]),
 }
 

@@ -14,6 +14,8 @@
 #include <atomic>
 #include <cstring>
 #include <thread>
+#include <cmath>
+#include <cstdio>
 #include <vector>
 #include "../../include/meatmodeler.h"
 
@@ -239,6 +241,67 @@ int mm_ba_build_index(int F, int P, int64_t O, const int32_t *fi, const int32_t 
         cam_obs[cw[fi[o]]++] = (int32_t)o;
     }
     return MM_OK;
+}
+
+// Greedy minimum-distance selection of cv2.goodFeaturesToTrack (reference processor.py:104): the candidates arrive
+// sorted by strength (descending; ties by y, x); one is accepted iff no accepted corner lies closer than min_distance
+// (buckets of min_distance pixels, 3 x 3 neighbourhood), up to max_corners (0 = no limit).  Sequential by nature and
+// short (it stops after max_corners acceptances): host code, as in OpenCV.  -> number of corners written to out [cap,2].
+int mm_gftt_select(const int32_t *pos /*[n] y * w + x, sorted*/, int64_t n, int w, int h, int max_corners, double min_distance,
+                   float *out, int cap) {
+    if (n < 0 || w < 1 || h < 1 || cap < 0 || (n > 0 && !pos) || (cap > 0 && !out)) return MM_ERR_ARG;
+    int m = 0;
+    if (min_distance >= 1.0) {
+        const int cell = (int)lrint(min_distance);
+        const int gw = (w + cell - 1) / cell, gh = (h + cell - 1) / cell;
+        std::vector<int32_t> head((size_t)gw * gh, -1), nxt, ax, ay;
+        const double md2 = min_distance * min_distance;
+        for (int64_t i = 0; i < n; ++i) {
+            const int x = pos[i] % w, y = pos[i] / w, cx = x / cell, cy = y / cell;
+            bool good = true;
+            for (int yy = cy > 0 ? cy - 1 : 0; yy <= (cy + 1 < gh ? cy + 1 : gh - 1) && good; ++yy)
+                for (int xx = cx > 0 ? cx - 1 : 0; xx <= (cx + 1 < gw ? cx + 1 : gw - 1) && good; ++xx)
+                    for (int32_t e = head[(size_t)yy * gw + xx]; e >= 0; e = nxt[e]) {
+                        const double dx = x - ax[e], dy = y - ay[e];
+                        if (dx * dx + dy * dy < md2) {
+                            good = false;
+                            break;
+                        }
+                    }
+            if (!good) continue;
+            ax.push_back(x);
+            ay.push_back(y);
+            nxt.push_back(head[(size_t)cy * gw + cx]);
+            head[(size_t)cy * gw + cx] = m;
+            if (m < cap) {
+                out[2 * m] = (float)x;
+                out[2 * m + 1] = (float)y;
+            }
+            ++m;
+            if ((max_corners > 0 && m >= max_corners) || m >= cap) break;
+        }
+    } else {
+        for (int64_t i = 0; i < n && m < cap; ++i) {
+            out[2 * m] = (float)(pos[i] % w);
+            out[2 * m + 1] = (float)(pos[i] / w);
+            ++m;
+            if (max_corners > 0 && m >= max_corners) break;
+        }
+    }
+    return m;
+}
+
+// Binary little-endian PLY with double x, y, z vertices: what PyntCloud(pd.DataFrame(points, columns=x,y,z)).to_file(
+// path + "Cloud.ply") writes for a float64 frame (reference processor.py:480-485).  -> 0 ok.
+int mm_write_ply(const char *path, const double *xyz /*[n,3]*/, int64_t n) {
+    if (!path || n < 0 || (n > 0 && !xyz)) return MM_ERR_ARG;
+    FILE *f = fopen(path, "wb");
+    if (!f) return MM_ERR_ARG;
+    fprintf(f, "ply\nformat binary_little_endian 1.0\nelement vertex %lld\nproperty double x\nproperty double y\nproperty double z\nend_header\n",
+            (long long)n);
+    const size_t wrote = n ? fwrite(xyz, sizeof(double) * 3, (size_t)n, f) : 0;
+    const int rc = fclose(f);
+    return (wrote == (size_t)n && rc == 0) ? MM_OK : MM_ERR_ARG;
 }
 
 }  // extern "C"

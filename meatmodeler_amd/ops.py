@@ -526,3 +526,117 @@ def chol_solve_sym(A, b, ctx=None, half_bandwidth=None, both_triangles=True):
     ctx.check(lib.mm_chol_solve_sym(ctx.h, ptr(A), n, ptr(b), hb, 1 if both_triangles else 0, ptr(info), ptr(ws), wsb),
               "mm_chol_solve_sym")
     return info
+
+
+# ------------------------------------------------------------------------------------------------ keyframe gating front end
+
+def pyramid(img, max_level, ctx=None):
+    """[H,W] u8 device tensor -> list of max_level + 1 device tensors (mm_pyr_down; level 0 is `img` itself)."""
+    ctx = ctx or default_context()
+    assert img.dtype == torch.uint8 and img.dim() == 2 and img.is_contiguous()
+    levels = [img]
+    for _ in range(int(max_level)):
+        s = levels[-1]
+        h, w = s.shape
+        d = torch.empty(((h + 1) // 2, (w + 1) // 2), dtype=torch.uint8, device=s.device)
+        ctx.check(lib.mm_pyr_down(ctx.h, ptr(s), w, h, s.stride(0), ptr(d), d.stride(0)), "mm_pyr_down")
+        levels.append(d)
+    return levels
+
+
+def lk_track(prev_levels, next_levels, pts, win=(21, 21), max_count=30, epsilon=0.01, ctx=None):
+    """Pyramidal Lucas-Kanade (mm_lk_track) on two pyramids from `pyramid`.  pts [n,2] f32 device.
+    -> next [n,2] f32, status [n] u8, err [n] f32 (device)."""
+    ctx = ctx or default_context()
+    L = len(prev_levels)
+    assert len(next_levels) == L and pts.dtype == torch.float32 and pts.is_contiguous() and pts.shape[-1] == 2
+    n = pts.shape[0]
+    d = pts.device
+    out = torch.empty((n, 2), dtype=torch.float32, device=d)
+    st = torch.empty(n, dtype=torch.uint8, device=d)
+    err = torch.empty(n, dtype=torch.float32, device=d)
+    if n == 0:
+        return out, st, err
+    arr_p = (C.c_void_p * L)(*[t.data_ptr() for t in prev_levels])
+    arr_n = (C.c_void_p * L)(*[t.data_ptr() for t in next_levels])
+    ws = (C.c_int * L)(*[t.shape[1] for t in prev_levels])
+    hs = (C.c_int * L)(*[t.shape[0] for t in prev_levels])
+    ps = (C.c_int * L)(*[t.stride(0) for t in prev_levels])
+    for a, b in zip(prev_levels, next_levels):
+        assert a.shape == b.shape and a.stride(0) == b.stride(0)
+    eps = min(max(float(epsilon), 0.0), 10.0) ** 2
+    ctx.check(lib.mm_lk_track(ctx.h, arr_p, arr_n, ws, hs, ps, L, ptr(pts), n, int(win[0]), int(win[1]),
+                              min(max(int(max_count), 0), 100), eps, ptr(out), ptr(st), ptr(err)), "mm_lk_track")
+    return out, st, err
+
+
+def min_eig(img, block_size=3, ctx=None):
+    """Shi-Tomasi minimum-eigenvalue map [H,W] f64 (mm_min_eig)."""
+    ctx = ctx or default_context()
+    assert img.dtype == torch.uint8 and img.dim() == 2 and img.stride(1) == 1
+    h, w = img.shape
+    eig = torch.empty((h, w), dtype=torch.float64, device=img.device)
+    ctx.check(lib.mm_min_eig(ctx.h, ptr(img), w, h, img.stride(0), int(block_size), ptr(eig)), "mm_min_eig")
+    return eig
+
+
+def good_features(img, max_corners, quality, min_distance, block_size=3, ctx=None):
+    """cv2.goodFeaturesToTrack on a device image: eigenvalue map, threshold + non-maximum suppression and compaction on
+    the device, ordering by torch.sort (index plumbing), greedy minimum-distance selection on the host
+    (mm_gftt_select).  -> numpy [n,2] f32 (x, y)."""
+    ctx = ctx or default_context()
+    h, w = img.shape
+    eig = min_eig(img, block_size, ctx)
+    cap = (h * w) // 4 + 64                      # strict 3x3 maxima: at most one pixel in four
+    d = img.device
+    mx = torch.zeros(1, dtype=torch.int64, device=d)
+    vb = torch.empty(cap, dtype=torch.int64, device=d)
+    pos = torch.empty(cap, dtype=torch.int32, device=d)
+    cnt = torch.zeros(1, dtype=torch.int32, device=d)
+    ctx.check(lib.mm_corner_candidates(ctx.h, ptr(eig), w, h, float(quality), ptr(mx), ptr(vb), ptr(pos), cap, ptr(cnt)),
+              "mm_corner_candidates")
+    n = min(int(cnt.item()), cap)
+    if n == 0:
+        return np.zeros((0, 2), np.float32)
+    pos_s, o1 = torch.sort(pos[:n], stable=True)                       # by position ...
+    _, o2 = torch.sort(vb[:n][o1], descending=True, stable=True)       # ... then stably by strength (descending)
+    pos_h = np.ascontiguousarray(pos_s[o2].cpu().numpy(), np.int32)
+    out_cap = int(max_corners) if max_corners and max_corners > 0 else n
+    out = np.zeros((max(out_cap, 1), 2), np.float32)
+    m = lib.mm_gftt_select(pos_h.ctypes.data_as(C.c_void_p), n, w, h, int(max_corners or 0), float(min_distance),
+                           out.ctypes.data_as(C.c_void_p), out_cap)
+    if m < 0:
+        raise _lib.MMError(f"mm_gftt_select failed ({m})")
+    return out[:m]
+
+
+_LAB_TABLES = {}
+
+
+def increase_contrast(bgr, clip_limit=3.5, tiles=(8, 8), want_grey=False, ctx=None):
+    """bgr [B,H,W,3] u8 device -> contrast-enhanced BGR (and the grey image of the result): mm_increase_contrast."""
+    ctx = ctx or default_context()
+    assert bgr.dtype == torch.uint8 and bgr.dim() == 4 and bgr.shape[-1] == 3 and bgr.is_contiguous()
+    B, H, W, _ = bgr.shape
+    d = bgr.device
+    key = str(d)
+    if key not in _LAB_TABLES:
+        from .frame_tables import lab_tables
+        _LAB_TABLES[key] = tuple(torch.as_tensor(t.view(np.int16) if t.dtype == np.uint16 else t).to(d) for t in lab_tables())
+    g, cb, gi = _LAB_TABLES[key]
+    out = torch.empty_like(bgr)
+    grey = torch.empty((B, H, W), dtype=torch.uint8, device=d) if want_grey else None
+    wsb = lib.mm_contrast_workspace_bytes(B, W, H, int(tiles[0]), int(tiles[1]))
+    ws = torch.empty(max(wsb, 256), dtype=torch.uint8, device=d)
+    ctx.check(lib.mm_increase_contrast(ctx.h, ptr(bgr), B, W, H, ptr(g), ptr(cb), ptr(gi), float(clip_limit), int(tiles[0]),
+                                       int(tiles[1]), ptr(out), ptr(grey), ptr(ws), ws.numel()), "mm_increase_contrast")
+    return (out, grey) if want_grey else out
+
+
+def bgr_to_grey(bgr, ctx=None):
+    """[...,3] u8 device -> [...] u8: cv2.COLOR_BGR2GRAY's fixed-point weights (mm_bgr_to_grey)."""
+    ctx = ctx or default_context()
+    assert bgr.dtype == torch.uint8 and bgr.shape[-1] == 3 and bgr.is_contiguous()
+    grey = torch.empty(bgr.shape[:-1], dtype=torch.uint8, device=bgr.device)
+    ctx.check(lib.mm_bgr_to_grey(ctx.h, ptr(bgr), grey.numel(), ptr(grey)), "mm_bgr_to_grey")
+    return grey

@@ -156,6 +156,112 @@ def _points_xy(points):
     return np.array([p.pt for p in points], np.float32).reshape(-1, 2)
 
 
+# ----------------------------------------------------------------------------------------------- increaseContrast / grey
+
+def increaseContrast(frame):
+    """CLAHE (clip limit 3.5, 8 x 8 tiles) on the L channel of L*a*b* (processor.py:12-26).  frame [H,W,3] u8 BGR
+    (ndarray or device tensor) -> ndarray [H,W,3] u8 BGR."""
+    ctx = default_context()
+    t = frame if isinstance(frame, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(frame, np.uint8))
+    out = ops.increase_contrast(t.to(ctx.device).contiguous().unsqueeze(0), 3.5, (8, 8), ctx=ctx)[0]
+    return out if isinstance(frame, torch.Tensor) else out.cpu().numpy()
+
+
+def cvtColorBGR2GRAY(frame):
+    """cv2.cvtColor(frame, cv2.COLOR_BGR2GRAY) (processor.py:357): [H,W,3] u8 -> [H,W] u8."""
+    ctx = default_context()
+    t = frame if isinstance(frame, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(frame, np.uint8))
+    out = ops.bgr_to_grey(t.to(ctx.device).contiguous(), ctx)
+    return out if isinstance(frame, torch.Tensor) else out.cpu().numpy()
+
+
+# ----------------------------------------------------------------------------------------------- keyframeTracking
+
+_PYR_CACHE = []          # [(weakref to the host frame, max_level, device pyramid)]: the frame of one call is `prev` of the next
+
+
+def _frame_pyramid(frame_grey, max_level, ctx):
+    import weakref
+    if isinstance(frame_grey, torch.Tensor):
+        return ops.pyramid(frame_grey.to(ctx.device).contiguous(), max_level, ctx)
+    for ref, lv, pyr in _PYR_CACHE:
+        if ref() is frame_grey and lv == max_level and not frame_grey.flags.writeable:
+            return pyr
+    img = torch.as_tensor(np.ascontiguousarray(frame_grey, np.uint8)).to(ctx.device)
+    pyr = ops.pyramid(img, max_level, ctx)
+    try:
+        # (only frames that cannot change behind the cache's back are remembered: the caller opts in by freezing them)
+        if not frame_grey.flags.writeable:
+            _PYR_CACHE.append((weakref.ref(frame_grey), max_level, pyr))
+            del _PYR_CACHE[:-2]
+    except TypeError:
+        pass
+    return pyr
+
+
+def calcOpticalFlowPyrLK(prevImg, nextImg, prevPts, nextPts=None, winSize=(21, 21), maxLevel=3, criteria=(3, 30, 0.01),
+                         **_ignored):
+    """cv2.calcOpticalFlowPyrLK (processor.py:79) -> (nextPts [n,1,2] f32, status [n,1] u8, err [n,1] f32);
+    (None, None, None) without points."""
+    if prevPts is None or len(prevPts) == 0:
+        return None, None, None
+    ctx = default_context()
+    pp = _frame_pyramid(prevImg, maxLevel, ctx)
+    pn = _frame_pyramid(nextImg, maxLevel, ctx)
+    pts = torch.as_tensor(np.ascontiguousarray(np.asarray(prevPts, np.float32).reshape(-1, 2))).to(ctx.device)
+    max_count = criteria[1] if len(criteria) > 1 else 30
+    eps = criteria[2] if len(criteria) > 2 else 0.01
+    nx, st, err = ops.lk_track(pp, pn, pts, winSize, max_count, eps, ctx)
+    return (nx.cpu().numpy().reshape(-1, 1, 2), st.cpu().numpy().reshape(-1, 1), err.cpu().numpy().reshape(-1, 1))
+
+
+def goodFeaturesToTrack(image, maxCorners, qualityLevel, minDistance, mask=None, blockSize=3, useHarrisDetector=False,
+                        k=0.04, **_ignored):
+    """cv2.goodFeaturesToTrack (processor.py:104) -> [n,1,2] f32 or None without corners."""
+    if mask is not None or useHarrisDetector:
+        raise NotImplementedError("mask / Harris detector are not supported (the reference passes mask=None, processor.py:105)")
+    ctx = default_context()
+    img = image if isinstance(image, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(image, np.uint8))
+    c = ops.good_features(img.to(ctx.device).contiguous(), maxCorners, qualityLevel, minDistance, blockSize, ctx)
+    return c.reshape(-1, 1, 2) if len(c) else None
+
+
+def keyframeTracking(frame_grey, prev_frame_grey, prev_frame_points, accumulated_error, lk_params, feature_params,
+                     threshold=0.2):
+    """Is this frame a keyframe?  (processor.py:61-110.)  Tracks the previous frame's points into this frame with
+    pyramidal LK, adds the mean tracking error to `accumulated_error`, and once that exceeds threshold * width declares
+    a keyframe, resets the error and re-seeds the points with goodFeaturesToTrack.
+    -> (is_keyframe, new prev_frame_grey, new prev_frame_points, new accumulated_error)."""
+    p, st, err = calcOpticalFlowPyrLK(prev_frame_grey, frame_grey, prev_frame_points, None, **lk_params)
+    if p is not None:
+        good_new = p[st == 1]
+        prev_frame_grey = frame_grey
+        prev_frame_points = good_new.reshape(-1, 1, 2)
+        if err is not None:
+            new_err = np.nan_to_num(err)
+            new_err[new_err < 0] = 0
+            accumulated_error += np.average(new_err)
+        if accumulated_error > threshold * frame_grey.shape[1]:
+            accumulated_error = 0
+            prev_frame_points = goodFeaturesToTrack(prev_frame_grey, mask=None, **feature_params)
+            return True, prev_frame_grey, prev_frame_points, accumulated_error
+    return False, prev_frame_grey, prev_frame_points, accumulated_error
+
+
+# ----------------------------------------------------------------------------------------------- PLY export
+
+def savePointCloud(points, path):
+    """The reference's export (processor.py:480-485: PyntCloud(DataFrame(points, columns x, y, z)).to_file(path +
+    "Cloud.ply")): binary little-endian PLY with double x, y, z.  -> the file name."""
+    from ._lib import lib as _l, MMError as _E
+    pts = np.ascontiguousarray(np.asarray(points, np.float64).reshape(-1, 3))
+    filename = path + "Cloud.ply"
+    rc = _l.mm_write_ply(filename.encode(), pts.ctypes.data_as(__import__("ctypes").c_void_p), len(pts))
+    if rc != 0:
+        raise _E(f"mm_write_ply({filename!r}) failed ({rc})")
+    return filename
+
+
 # ----------------------------------------------------------------------------------------------- featureTracking
 
 def featureTracking(new_keyframe, prev_orb_points, prev_orb_descriptors, orb, flann_params, threshold=0.75):

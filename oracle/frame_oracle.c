@@ -324,10 +324,10 @@ int frc_good_features(const uint8_t *img, int w, int h, int p, int max_corners, 
 }
 
 /* ---- increaseContrast: BGR -> LAB (table-driven fixed point) -> CLAHE on L -> BGR ---------------------------------------
- * Tables (meatmodeler_amd/frame_tables.py): gamma [256] u16 (sRGB decode, 12 bit), cbrt_tab [4096] u16 (f(t), 15 bit),
- * finv_tab [4096] u16 (f^-1 on f in [0, 4095/2730): 12-bit linear), gamma_inv [4096] u8 (sRGB encode). */
+ * Tables (meatmodeler_amd/frame_tables.py): gamma [256] u16 (sRGB decode, 12 bit), cbrt_tab [4096] u16 (f(t), Q15),
+ * gamma_inv [4096] u8 (sRGB encode); f^-1 is evaluated in integer arithmetic (cube / linear branch). */
 typedef struct {
-    const uint16_t *gamma, *cbrt_tab, *finv_tab;
+    const uint16_t *gamma, *cbrt_tab;
     const uint8_t *gamma_inv;
 } lab_tables_t;
 
@@ -350,19 +350,28 @@ static inline void bgr_to_lab(const lab_tables_t *T, int B, int G, int R, int *L
     *Bb = bb < 0 ? 0 : (bb > 255 ? 255 : bb);
 }
 
+static inline int lab_finv(int f) { /* f in Q15 -> t = f^-1(f) as a 12-bit value (0..4095), integer exact */
+    int64_t t;
+    if (f > 6779)
+        t = ((int64_t)f * f * f * 4095 + ((int64_t)1 << 44)) >> 45;
+    else
+        t = ((int64_t)(f - 4520) * 269254 + ((int64_t)1 << 23)) >> 24;
+    return t < 0 ? 0 : (t > 4095 ? 4095 : (int)t);
+}
+static inline int div_round(int64_t num, int64_t den) { /* den > 0, round half away from zero */
+    return (int)(num >= 0 ? (num + den / 2) / den : -((-num + den / 2) / den));
+}
+
 static inline void lab_to_bgr(const lab_tables_t *T, int L, int A, int Bb, int *B, int *G, int *R) {
-    /* fy = (L* + 16) / 116 with L* = L 100 / 255; f values in units of 1 / 2730 (finv_tab index) */
-    int fy = (int)(((int64_t)L * 100 * 2730 + (int64_t)16 * 255 * 2730 + 58 * 255) / (116 * 255));
-    int fx = fy + (int)((2730 * (int64_t)(A - 128) + (A >= 128 ? 250 : -250)) / 500);
-    int fz = fy - (int)((2730 * (int64_t)(Bb - 128) + (Bb >= 128 ? 100 : -100)) / 200);
-    fx = fx < 0 ? 0 : (fx > 4095 ? 4095 : fx);
-    fy = fy < 0 ? 0 : (fy > 4095 ? 4095 : fy);
-    fz = fz < 0 ? 0 : (fz > 4095 ? 4095 : fz);
-    const int X = T->finv_tab[fx], Y = T->finv_tab[fy], Z = T->finv_tab[fz];
+    /* fy = (L* + 16) / 116 with L* = L 100 / 255, in Q15;  fx = fy + a* / 500,  fz = fy - b* / 200 */
+    const int fy = div_round(((int64_t)L * 100 + 16 * 255) * 32768, 116 * 255);
+    const int fx = fy + div_round((int64_t)(A - 128) * 65536, 1000);
+    const int fz = fy - div_round((int64_t)(Bb - 128) * 16384, 100);
+    const int X = lab_finv(fx), Y = lab_finv(fy), Z = lab_finv(fz);
     /* inverse matrix (XYZ / white -> linear sRGB), 12-bit fixed point */
-    int r = (12573 * X - 6201 * Y - 2276 * Z + 2048) >> 12;
-    int g = (-4147 * X + 8080 * Y + 163 * Z + 2048) >> 12;
-    int b = (263 * X - 885 * Y + 4718 * Z + 2048) >> 12;
+    int r = (12621 * X - 6300 * Y - 2225 * Z + 2048) >> 12;   /* rows sum to 4096: white stays white */
+    int g = (-3775 * X + 7686 * Y + 185 * Z + 2048) >> 12;
+    int b = (215 * X - 834 * Y + 4715 * Z + 2048) >> 12;
     r = r < 0 ? 0 : (r > 4095 ? 4095 : r);
     g = g < 0 ? 0 : (g > 4095 ? 4095 : g);
     b = b < 0 ? 0 : (b > 4095 ? 4095 : b);
@@ -432,8 +441,8 @@ void frc_clahe(const uint8_t *src, int w, int h, int p, uint8_t *dst, int pd, in
 
 /* bgr [h][w][3] u8 -> out [h][w][3] u8: increaseContrast (reference processor.py:12-26, clipLimit 3.5, 8 x 8 tiles) */
 void frc_increase_contrast(const uint8_t *bgr, int w, int h, const uint16_t *gamma, const uint16_t *cbrt_tab,
-                           const uint16_t *finv_tab, const uint8_t *gamma_inv, double clip, int tx, int ty, uint8_t *out) {
-    lab_tables_t T = {gamma, cbrt_tab, finv_tab, gamma_inv};
+                           const uint8_t *gamma_inv, double clip, int tx, int ty, uint8_t *out) {
+    lab_tables_t T = {gamma, cbrt_tab, gamma_inv};
     uint8_t *L = (uint8_t *)malloc((size_t)w * h * 4), *A = L + (size_t)w * h, *B = A + (size_t)w * h, *L2 = B + (size_t)w * h;
     for (size_t i = 0; i < (size_t)w * h; ++i) {
         int l, a, b;
@@ -457,4 +466,21 @@ void frc_increase_contrast(const uint8_t *bgr, int w, int h, const uint16_t *gam
 void frc_bgr_to_grey(const uint8_t *bgr, size_t n, uint8_t *grey) {
     for (size_t i = 0; i < n; ++i)
         grey[i] = (uint8_t)((bgr[3 * i] * 1868 + bgr[3 * i + 1] * 9617 + bgr[3 * i + 2] * 4899 + 8192) >> 14);
+}
+
+/* BGR -> LAB -> BGR without CLAHE (accuracy check of the fixed-point conversion); lab [n,3] receives L, a, b */
+void frc_lab_roundtrip(const uint8_t *bgr, size_t n, const uint16_t *gamma, const uint16_t *cbrt_tab,
+                       const uint8_t *gamma_inv, uint8_t *lab, uint8_t *out) {
+    lab_tables_t T = {gamma, cbrt_tab, gamma_inv};
+    for (size_t i = 0; i < n; ++i) {
+        int l, a, b, bb, g, r;
+        bgr_to_lab(&T, bgr[3 * i], bgr[3 * i + 1], bgr[3 * i + 2], &l, &a, &b);
+        lab[3 * i] = (uint8_t)l;
+        lab[3 * i + 1] = (uint8_t)a;
+        lab[3 * i + 2] = (uint8_t)b;
+        lab_to_bgr(&T, l, a, b, &bb, &g, &r);
+        out[3 * i] = (uint8_t)bb;
+        out[3 * i + 1] = (uint8_t)g;
+        out[3 * i + 2] = (uint8_t)r;
+    }
 }

@@ -299,3 +299,44 @@ def test_exact_trust_region_on_block_diagonal_matches_scipy():
             p, alpha, it = bundleAdjuster._solve_lsq_trust_region_eig(lam, vg, V, Delta, F * rows, a0)
             np.testing.assert_allclose(p.ravel(), p_ref, rtol=1e-9, atol=1e-12)
             assert it == it_ref and abs(alpha - alpha_ref) <= 1e-9 * max(1.0, abs(alpha_ref))
+
+
+def test_save_point_cloud_writes_binary_ply(tmp_path):
+    """processor.py:480-485: PyntCloud(DataFrame(points, x / y / z)).to_file(path + "Cloud.ply") -> binary PLY, doubles."""
+    from meatmodeler_amd import processor
+    pts = np.random.default_rng(0).normal(size=(37, 3))
+    name = processor.savePointCloud(pts, str(tmp_path) + "/scan")
+    assert name.endswith("scanCloud.ply")
+    raw = open(name, "rb").read()
+    head, body = raw.split(b"end_header\n", 1)
+    lines = head.decode().splitlines()
+    assert lines[:3] == ["ply", "format binary_little_endian 1.0", "element vertex 37"]
+    assert lines[3:6] == ["property double x", "property double y", "property double z"]
+    np.testing.assert_array_equal(np.frombuffer(body, "<f8").reshape(37, 3), pts)
+    assert processor.savePointCloud(np.zeros((0, 3)), str(tmp_path) + "/empty").endswith("emptyCloud.ply")
+
+
+def test_frame_oracle_definitions():
+    """The CPU definitions of the per-frame front end (oracle/frame_oracle.c): LK recovers a known translation, the
+    fixed-point LAB conversion is as accurate as 8-bit LAB allows, CLAHE leaves a constant image constant, corners
+    respect the minimum distance."""
+    from oracle import frame_oracle as fo
+    from meatmodeler_amd import frame_tables, synth
+    frames, _, _ = synth.render_orbit_frames(1, 320, 240, arc_deg=1.0, seed=2)
+    a = frames[0]
+    c = fo.good_features(a, 60, 0.05, 12, 5)
+    d = np.linalg.norm(c[:, None] - c[None], axis=2) + 1e9 * np.eye(len(c))
+    assert len(c) > 10 and d.min() >= 12
+    c = c[(c[:, 0] > 30) & (c[:, 0] < 290) & (c[:, 1] > 30) & (c[:, 1] < 210)]
+    nx, st, er = fo.lk_track(a, np.roll(np.roll(a, 1, 0), -2, 1), c, (21, 21), 2, 30, 0.01)
+    assert st.mean() > 0.9 and np.abs(np.median((nx - c)[st == 1], 0) - [-2, 1]).max() < 0.05
+    rng = np.random.default_rng(0)
+    bgr = rng.integers(0, 256, (4000, 1, 3), dtype=np.uint8)
+    bgr[:2, 0] = [[0, 0, 0], [255, 255, 255]]
+    lab, back = fo.lab_roundtrip(bgr, frame_tables.lab_tables())
+    assert list(lab[0, 0]) == [0, 128, 128] and list(lab[1, 0]) == [255, 128, 128]
+    err = np.abs(back.astype(int) - bgr.astype(int))
+    assert (back[:2] == bgr[:2]).all() and err.mean() < 1.0
+    flat = np.full((64, 96), 100, np.uint8)
+    out = fo.clahe(flat)
+    assert (out == out[0, 0]).all()
