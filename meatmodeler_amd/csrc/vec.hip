@@ -424,10 +424,9 @@ extern "C" int mm_ba_damp(mm_ctx *ctx, int F, int P, const double *B, const doub
 // circle as the real roots of a quartic in tan(phi / 2).  Here the scalars that define B and g stay in device memory
 // (they are results of the fused passes), one wave solves the subproblem and the trial point is formed from its
 // output, so the host no longer has to read them back between building the subspace and the trial step: ONE host
-// synchronisation per trial step instead of two.  Boundary case: the derivative of the model along the circle is
-// sampled at 128 angles; every sign change is narrowed by 64-ary search across the lanes (9 rounds reach the
-// resolution of a double) and the stationary point with the smallest model value wins -- the same minimiser as the
-// quartic's, to rounding.
+// synchronisation per trial step instead of two.  Boundary case: see the comment in the kernel (the quartic's real
+// roots by sampling + 64-ary search in two rational charts of the circle) -- the same minimiser as np.roots', to
+// rounding.
 namespace {
 struct Step2dIn {
     const double *r0, *d11, *r1, *r2, *r3, *bs, *reg;
@@ -473,47 +472,51 @@ __global__ __launch_bounds__(64) void trf_step2d_kernel(Step2dIn in, double Delt
         }
     }
     if (!interior) {
-        // derivative of the model along p = Delta (cos phi, sin phi)
-        auto dmodel = [&](double phi) {
-            double s, c;
-            sincos(phi, &s, &c);
-            return Delta * Delta * ((bb - b00) * c * s + b01 * (c * c - s * s)) + Delta * (-g0 * s + g1 * c);
-        };
-        const double two_pi = 6.283185307179586476925286766559;
-        const double h = two_pi / 128.0;
-        // lane l owns the sample intervals [2l, 2l+1] and [2l+1, 2l+2] (x h)
-        const double f_a = dmodel(h * (2 * lane)), f_b = dmodel(h * (2 * lane + 1)), f_c = dmodel(h * (2 * lane + 2));
-        const unsigned long long m0 = __ballot((f_a <= 0.0) != (f_b <= 0.0));
-        const unsigned long long m1 = __ballot((f_b <= 0.0) != (f_c <= 0.0));
+        // Boundary: stationary points of the model on the circle |p| = Delta.  Two rational charts cover the circle,
+        //   p(t) = Delta (2t, s (1 - t^2)) / (1 + t^2),  t in [-1, 1],  s = +1 (upper half), -1 (lower half);
+        // d model / dt has the sign of the quartic N_s(t) below (the same quartic SciPy hands to np.roots, in both
+        // charts instead of one chart on the whole real line).  No trigonometry: each lane samples N_s at t = -1 + l / 32,
+        // every sign change is narrowed by 64-ary search across the lanes (9 rounds: double resolution), and the
+        // stationary point with the smallest model value wins; the two chart junctions (+-Delta, 0) are candidates too.
         double best_val = 1.0e308, best_p0 = Delta, best_p1 = 0.0;
-        for (int half = 0; half < 2; ++half) {
-            unsigned long long m = half == 0 ? m0 : m1;
+        auto consider = [&](double q0, double q1) {
+            const double val = model_2d(b00, b01, bb, g0, g1, q0, q1);
+            if (val < best_val) {
+                best_val = val;
+                best_p0 = q0;
+                best_p1 = q1;
+            }
+        };
+        consider(Delta, 0.0);
+        consider(-Delta, 0.0);
+        for (int chart = 0; chart < 2; ++chart) {
+            const double sg = chart == 0 ? 1.0 : -1.0;
+            auto N = [&](double t) {
+                const double t2 = t * t, q = 1.0 + t2, u = 1.0 - t2;
+                const double a0 = b00 * (2.0 * t * Delta) + b01 * (sg * Delta * u) + g0 * q;
+                const double a1 = b01 * (2.0 * t * Delta) + bb * (sg * Delta * u) + g1 * q;
+                return a0 * (2.0 * u) - sg * a1 * (4.0 * t);
+            };
+            const double hstep = 2.0 / 64.0;
+            const double f_a = N(-1.0 + hstep * lane), f_b = N(-1.0 + hstep * (lane + 1));
+            unsigned long long m = __ballot((f_a <= 0.0) != (f_b <= 0.0));
             while (m) {
                 const int src = __builtin_ctzll(m);
                 m &= m - 1;
-                double lo = h * (2 * src + half), hi = lo + h;
-                bool lo_neg = dmodel(lo) <= 0.0;   // (wave-uniform: every lane evaluates the same point)
+                double lo = -1.0 + hstep * src, hi = lo + hstep;
+                const bool lo_neg = N(lo) <= 0.0;   // (wave-uniform: every lane evaluates the same point)
                 for (int round = 0; round < 9; ++round) {
-                    const double w = (hi - lo) / 64.0;
-                    const double x0 = lo + w * lane;
-                    const bool neg = dmodel(x0) <= 0.0;
-                    // the sign change sits behind the LAST lane whose sample still has the sign of `lo`
+                    const double wdt = (hi - lo) / 64.0;
+                    const bool neg = N(lo + wdt * lane) <= 0.0;
+                    // the sign change sits behind the LAST lane of the leading run that still has the sign of `lo`
                     const unsigned long long same = __ballot(neg == lo_neg);
                     int k = 0;
-                    while (k < 63 && ((same >> (k + 1)) & 1ull)) ++k;   // leading run of equal signs (lane 0 is `lo` itself)
-                    lo = lo + w * k;
-                    hi = lo + w;
+                    while (k < 63 && ((same >> (k + 1)) & 1ull)) ++k;
+                    lo = lo + wdt * k;
+                    hi = lo + wdt;
                 }
-                const double phi = 0.5 * (lo + hi);
-                double s, c;
-                sincos(phi, &s, &c);
-                const double q0 = Delta * c, q1 = Delta * s;
-                const double val = model_2d(b00, b01, bb, g0, g1, q0, q1);
-                if (val < best_val) {
-                    best_val = val;
-                    best_p0 = q0;
-                    best_p1 = q1;
-                }
+                const double t = 0.5 * (lo + hi), q = 1.0 + t * t;
+                consider(Delta * (2.0 * t) / q, sg * Delta * (1.0 - t * t) / q);
             }
         }
         p0 = best_p0;
