@@ -351,8 +351,8 @@ class SchurTRF:
         band_exchange = (self.allreduce is not None and hasattr(pb, "band_view")
                          and span_all <= getattr(pb, "max_band_span", 192) and half_bw < nc)
         nfev, njev = 1, 1
-        if self._native and self.allreduce is None and hasattr(pb, "trf_step2d") and hasattr(pb, "schur_solve"):
-            return self._solve_single_gpu(x, g, cost, half_bw, ftol, xtol, gtol, max_nfev, verbose)
+        if self._native and hasattr(pb, "trf_step2d") and hasattr(pb, "schur_solve"):
+            return self._solve_device(x, g, cost, half_bw, band_exchange, ftol, xtol, gtol, max_nfev, verbose)
         B, C = self._normal(x, g)
         si = self._scale_inv(B, C)
         xs = x * si
@@ -529,12 +529,60 @@ class SchurTRF:
                         iterations=iteration, host_segments_ms={k: 1e3 * v for k, v in seg.items()})
 
 
-def _solve_single_gpu(self, x, g, cost, half_bw, ftol, xtol, gtol, max_nfev, verbose):
-    """The same iteration as `SchurTRF.solve`'s generic loop (which serves the sharded path and the CPU stand-in), for ONE
-    GPU with everything device resident: the 2-D trust-region subproblem is solved by a kernel from the fused passes'
-    results (mm_trf_step2d), the trial point is formed from its output and the host reads one small board of scalars
-    per trial step -- after the trial cost is known -- instead of synchronising twice per iteration."""
+def _solve_device(self, x, g, cost, half_bw, band_exchange, ftol, xtol, gtol, max_nfev, verbose):
+    """The same iteration as `SchurTRF.solve`'s generic loop (which serves the CPU stand-in of the tests), with everything
+    device resident: the 2-D trust-region subproblem is solved by a kernel from the fused passes' results
+    (mm_trf_step2d), the trial point is formed from its output and the host reads one small board of scalars per trial
+    step -- after the trial cost is known -- instead of synchronising twice per iteration.  Sharded (points partitioned
+    over ranks): every sum over observations / points is all-reduced on the device before the next kernel reads it (the
+    "total" column of the fused passes' result rows is overwritten with the cross-rank total), so all ranks feed
+    identical scalars to identical kernels and read identical boards."""
     pb = self.pb
+    ar = self.allreduce
+
+    def fix_params(rows, k, max_row=None):
+        """result rows of a pass over the PARAMETER vector: column 2 <- cross-rank total (camera part replicated)."""
+        if ar is None:
+            return rows
+        rows[:k, 2] = self._combine(rows[:k])
+        if max_row is not None:
+            m = rows[max_row, 1:2].contiguous()
+            ar(m, op="max")
+            rows[max_row, 2:3] = torch.maximum(rows[max_row, 0:1], m)
+        return rows
+
+    def fix_residual(rows):
+        """result rows of inner products of RESIDUAL-space vectors (every rank holds its own observations)."""
+        if ar is None:
+            return rows
+        t = rows[:, 2].contiguous()
+        ar(t)
+        rows[:, 2] = t
+        return rows
+
+    def reduced_solve(Bd, Cd, gc, gp):
+        """-> (info, v = solution of the reduced camera system, Cinv)."""
+        if ar is None:
+            return pb.schur_solve(self._cams(x), self._pts(x), Bd, Cd, gc, gp, half_bw)
+        S, v, Cinv = pb.schur(self._cams(x), self._pts(x), Bd, Cd, gc, gp)
+        ws = ar.world_size
+        if band_exchange:
+            # only the lower band is exchanged: n x (hb + 1) doubles (12.7 MB at 500 cameras) instead of the dense 72 MB
+            band = pb.band_view(half_bw)
+            packed = band.contiguous()
+            ar(packed)
+            band.copy_(packed)
+        else:
+            ar(S)
+        ar(v)
+        if ws > 1:      # every rank added the full blockdiag(Bd) and gc: remove the duplicates after the sum
+            blk = S.reshape(pb.F, 6, pb.F, 6)
+            f = torch.arange(pb.F, device=pb.device)
+            blk[f, :, f, :] -= (ws - 1) * Bd
+            v -= (ws - 1) * gc.reshape(-1)
+        info = pb.chol_solve_sym(S, v, half_bw, both_triangles=not band_exchange)
+        return info, v, Cinv
+
     F, P, nc = pb.F, pb.P, self.nc
     n = nc + 3 * P
     f64 = dict(dtype=torch.float64, device=pb.device)
@@ -543,7 +591,7 @@ def _solve_single_gpu(self, x, g, cost, half_bw, ftol, xtol, gtol, max_nfev, ver
     B, C = self._normal(x, g)
     si = self._scale_inv(B, C)
     xs = x * si
-    Delta = float(torch.sqrt(pb.multi_dot([(xs, xs)], nc)[0, 2]).item())
+    Delta = float(torch.sqrt(fix_params(pb.multi_dot([(xs, xs)], nc), 1)[0, 2]).item())
     del xs
     if Delta == 0:
         Delta = 1.0
@@ -559,10 +607,10 @@ def _solve_single_gpu(self, x, g, cost, half_bw, ftol, xtol, gtol, max_nfev, ver
     seg = {"to_syncA": 0.0, "syncA_to_accept": 0.0}
     t_mark = time.perf_counter()
     while True:
-        r0 = pb.trf_fused(0, [g, si], [gh, ghs], split=nc)                  # rows: |g_h|^2 ; max |g|
+        r0 = fix_params(pb.trf_fused(0, [g, si], [gh, ghs], split=nc), 1, max_row=1)   # rows: |g_h|^2 ; max |g|
         gh2_t = r0[0, 2:3]
         u1 = pb.jvp(cams(x), pts(x), cams(ghs), pts(ghs)).reshape(-1)       # J (d g_h)
-        d11 = pb.multi_dot([(u1, u1)], 0)
+        d11 = fix_residual(pb.multi_dot([(u1, u1)], 0))
         if termination is not None or nfev == max_nfev:
             g_norm = float(r0[1, 2].item())
             if verbose == 2:
@@ -574,19 +622,21 @@ def _solve_single_gpu(self, x, g, cost, half_bw, ftol, xtol, gtol, max_nfev, ver
         vals = None
         for attempt in range(6):
             Bd, Cd = self._damped_blocks(B, C, si, reg_eff)
-            info, v, Cinv = pb.schur_solve(cams(x), pts(x), Bd, Cd, gc, gp, half_bw)
+            info, v, Cinv = reduced_solve(Bd, Cd, gc, gp)
             dp = pb.backsub(cams(x), pts(x), Cinv, gp, v.view(F, 6)).reshape(-1)
             # orthonormal basis of span{g_h, gn_h} (trf.py:481-482) in three fused passes (see the generic loop)
-            r1 = pb.trf_fused(1, [v, dp, si, gh], [gn, q1], [gh2_t], split=nc)
-            r2 = pb.trf_fused(2, [gn, q1], [w], [r1[0, 2:3]], split=nc)
-            r3 = pb.trf_fused(3, [w, q1, si, gh, x], [q2, s1, s2], [r2[0, 2:3]], split=nc)
+            r1 = fix_params(pb.trf_fused(1, [v, dp, si, gh], [gn, q1], [gh2_t], split=nc), 2)
+            r2 = fix_params(pb.trf_fused(2, [gn, q1], [w], [r1[0, 2:3]], split=nc), 1)
+            r3 = fix_params(pb.trf_fused(3, [w, q1, si, gh, x], [q2, s1, s2], [r2[0, 2:3]], split=nc), 5)
             Jq2 = pb.jvp(cams(x), pts(x), cams(s2), pts(s2)).reshape(-1)
-            bs = pb.multi_dot([(u1, Jq2), (Jq2, Jq2)], 0)
+            bs = fix_residual(pb.multi_dot([(u1, Jq2), (Jq2, Jq2)], 0))
 
             def trial(Delta_):
                 pb.trf_step2d(r0, d11, r1, r2, r3, bs, reg_eff, info, Delta_, board)
                 pb.trf_fused(5, [x, s1, s2], [x_new], [board], split=nc)
                 pb.residual(cams(x_new), pts(x_new), cost_out=cost_slot)
+                if ar is not None:
+                    ar(cost_slot)
                 return board.tolist()                                     # ---- the host sync of a trial step ----
 
             vals = trial(Delta)          # enqueued before the host knows whether the factorisation succeeded
@@ -596,7 +646,7 @@ def _solve_single_gpu(self, x, g, cost, half_bw, ftol, xtol, gtol, max_nfev, ver
             if inf < 0:
                 # the single-launch factorisation gave up waiting (see the generic loop): build and solve one after
                 # the other from here on
-                if getattr(pb, "overlap", False):
+                if ar is None and getattr(pb, "overlap", False):
                     self._serial_fallback(x, Bd, Cd, gc, gp, half_bw, solve=False)
                     continue
                 raise MMError("mm_chol_solve: the fused banded factorisation was abandoned (info = -1)")
@@ -656,7 +706,7 @@ def _solve_single_gpu(self, x, g, cost, half_bw, ftol, xtol, gtol, max_nfev, ver
                     iterations=iteration, host_segments_ms={k: 1e3 * v for k, v in seg.items()})
 
 
-SchurTRF._solve_single_gpu = _solve_single_gpu
+SchurTRF._solve_device = _solve_device
 
 
 def _finish_verbose(res, cost0, verbose):
