@@ -92,7 +92,10 @@ class ORB:
         if isinstance(image, torch.Tensor):
             img = image
         else:
-            img = torch.as_tensor(np.ascontiguousarray(image))
+            import warnings
+            with warnings.catch_warnings():          # (a frozen host frame is only read)
+                warnings.simplefilter("ignore", UserWarning)
+                img = torch.as_tensor(np.ascontiguousarray(image))
         if img.dtype != torch.uint8 or img.dim() != 2:
             raise ValueError("detectAndCompute expects a single-channel uint8 image [H, W]")
         dev = self.device or torch.device("cuda", torch.cuda.current_device())
@@ -177,6 +180,16 @@ def cvtColorBGR2GRAY(frame):
 
 # ----------------------------------------------------------------------------------------------- keyframeTracking
 
+def _upload_u8(a, device):
+    """host u8 array (possibly frozen: torch warns about wrapping read-only memory, which is only read here) -> device."""
+    import warnings
+    a = np.ascontiguousarray(a, np.uint8)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", UserWarning)
+        t = torch.from_numpy(a)
+    return t.to(device)
+
+
 _PYR_CACHE = []          # [(weakref to the host frame, max_level, device pyramid)]: the frame of one call is `prev` of the next
 
 
@@ -187,7 +200,7 @@ def _frame_pyramid(frame_grey, max_level, ctx):
     for ref, lv, pyr in _PYR_CACHE:
         if ref() is frame_grey and lv == max_level and not frame_grey.flags.writeable:
             return pyr
-    img = torch.as_tensor(np.ascontiguousarray(frame_grey, np.uint8)).to(ctx.device)
+    img = _upload_u8(frame_grey, ctx.device)
     pyr = ops.pyramid(img, max_level, ctx)
     try:
         # (only frames that cannot change behind the cache's back are remembered: the caller opts in by freezing them)
@@ -221,8 +234,8 @@ def goodFeaturesToTrack(image, maxCorners, qualityLevel, minDistance, mask=None,
     if mask is not None or useHarrisDetector:
         raise NotImplementedError("mask / Harris detector are not supported (the reference passes mask=None, processor.py:105)")
     ctx = default_context()
-    img = image if isinstance(image, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(image, np.uint8))
-    c = ops.good_features(img.to(ctx.device).contiguous(), maxCorners, qualityLevel, minDistance, blockSize, ctx)
+    img = image.to(ctx.device) if isinstance(image, torch.Tensor) else _upload_u8(image, ctx.device)
+    c = ops.good_features(img.contiguous(), maxCorners, qualityLevel, minDistance, blockSize, ctx)
     return c.reshape(-1, 1, 2) if len(c) else None
 
 
@@ -365,3 +378,61 @@ def managePoints(tracks):
         frame_indices.extend(obs.keys())
         point_indices.extend([point_index] * len(obs))
     return points, coordinates, frame_indices, point_indices
+
+
+# ----------------------------------------------------------------------------------------------- the driver loop
+
+def processFrames(frames, camera_matrix, extrinsic_for_frame, path, lk_params, feature_params, flann_params=None,
+                  threshold=0.1, nfeatures=20000, adjust=True):
+    """The body of the reference's `process` (processor.py:294-489) on frames that are already decoded, in the
+    reference's call order: contrast -> grey -> keyframe gate (:357-365) -> on a keyframe ORB + matching + track linking
+    (:378-391) -> after the last frame triangulation, flattening, bundle adjustment and the PLY export (:418-485).
+    What stays outside (video decode, chessboard detection, calibrate, poseEstimation, adjustPose)
+    is supplied by the caller: `frames` = iterable of [H,W,3] u8 BGR images, `camera_matrix` = K, and
+    `extrinsic_for_frame(i) -> 3x4` for the keyframes (every keyframe counts as "has a chessboard").
+    -> dict(points [P,3], extrinsics (list of 4x4) | None, keyframes (frame indices), tracks, file)."""
+    from . import bundleAdjuster
+    orb = ORB_create(nfeatures=nfeatures)
+    it = iter(frames)
+    start_frame = next(it)
+    prev_frame_grey = cvtColorBGR2GRAY(increaseContrast(start_frame))
+    prev_frame_grey.setflags(write=False)          # (lets the LK pyramid of a frame be reused by the next call)
+    prev_frame_points = goodFeaturesToTrack(prev_frame_grey, mask=None, **feature_params)
+    accumulative_error = 0
+    prev_orb_points, prev_orb_descriptors = orb.detectAndCompute(prev_frame_grey, None)
+    keyframes = [0]
+    tracks, popped_tracks = [], []
+    prev_keyframe_ID, keyframe_ID = 0, 1
+    for index, frame in enumerate(it, start=1):
+        frame_grey = cvtColorBGR2GRAY(increaseContrast(frame))
+        frame_grey.setflags(write=False)
+        is_keyframe, prev_frame_grey, prev_frame_points, accumulative_error = keyframeTracking(
+            frame_grey, prev_frame_grey, prev_frame_points, accumulative_error, lk_params, feature_params,
+            threshold=threshold)
+        if is_keyframe:
+            keyframes.append(index)
+            prev_matches, curr_matches, prev_orb_points, prev_orb_descriptors = featureTracking(
+                frame_grey, prev_orb_points, prev_orb_descriptors, orb, flann_params)
+            new_popped_tracks, tracks = pointTracking(tracks, prev_keyframe_ID, prev_matches, keyframe_ID, curr_matches)
+            popped_tracks += new_popped_tracks
+            prev_keyframe_ID = keyframe_ID
+            keyframe_ID += 1
+    popped_tracks += tracks
+    out = dict(points=np.zeros((0, 3)), extrinsics=None, keyframes=keyframes, tracks=popped_tracks, file=None)
+    if not popped_tracks:
+        return out
+    K = np.asarray(camera_matrix, float)
+    extrinsic_matrices = [np.asarray(extrinsic_for_frame(i), float)[:3, :] for i in keyframes]
+    projections = [K @ e for e in extrinsic_matrices]                     # processor.py:448
+    triangulatePoints(popped_tracks, projections)
+    points, points_2d, frame_indices, point_indices = managePoints(popped_tracks)
+    if adjust:
+        adjusted_points, adjusted_positions = bundleAdjuster.adjustPoints(
+            np.array(extrinsic_matrices), K, np.array(points), np.array(points_2d), np.array(frame_indices),
+            np.array(point_indices))
+        out.update(points=adjusted_points, extrinsics=adjusted_positions)
+    else:
+        out.update(points=np.array(points).reshape(-1, 3))
+    if path is not None:
+        out["file"] = savePointCloud(out["points"], path)
+    return out

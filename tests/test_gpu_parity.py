@@ -1271,3 +1271,50 @@ def test_increase_contrast_and_grey_bit_exact(w, h):
     np.testing.assert_array_equal(grey[0].cpu().numpy(), fo.bgr_to_grey(ref))
     np.testing.assert_array_equal(out[1].cpu().numpy(), fo.increase_contrast(bgr[::-1].copy(), frame_tables.lab_tables()))
     assert ref.std() > bgr.std()          # it does increase the contrast
+
+
+def test_process_frames_driver_loop_matches_oracle_flow(tmp_path):
+    """processor.processFrames = the body of the reference's `process` (processor.py:356-485) on decoded BGR frames:
+    contrast, grey, keyframe gate, ORB + matching + track linking on keyframes, triangulation, flattening, bundle
+    adjustment, PLY.  Same keyframes and the same flattened observations as the loop rebuilt from the oracle's functions."""
+    frames_g, ext, K = synth.render_orbit_frames(10, 320, 240, arc_deg=18.0, seed=6)
+    frames = [np.stack([f, np.roll(f, 3, 1), np.roll(f, 2, 0)], -1) for f in frames_g]
+    lk = dict(winSize=(15, 15), maxLevel=2, criteria=(3, 10, 0.03))
+    fp = dict(maxCorners=80, qualityLevel=0.2, minDistance=7, blockSize=7)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        out = processor.processFrames(frames, K, lambda i: ext[i], str(tmp_path) + "/run", lk, fp, threshold=0.06, nfeatures=500)
+    # ---- the same loop from the oracle's functions ----
+    tabs = frame_tables.lab_tables()
+    grey = [fo.bgr_to_grey(fo.increase_contrast(f, tabs)) for f in frames]
+    pts = fo.good_features(grey[0], 80, 0.2, 7, 7).reshape(-1, 1, 2)
+    prev, acc, keys = grey[0], 0.0, [0]
+    o_prev = oo.detect_compute(grey[0], 500, brief_pattern())
+    tracks, popped, pk, k = [], [], 0, 1
+    for i in range(1, 10):
+        nx, st, er = fo.lk_track(prev, grey[i], pts.reshape(-1, 2), (15, 15), 2, 10, 0.03)
+        pts = nx[st == 1].reshape(-1, 1, 2)
+        prev = grey[i]
+        e = np.nan_to_num(er.reshape(-1, 1))
+        e[e < 0] = 0
+        acc += np.average(e)
+        if acc > 0.06 * 320:
+            acc = 0
+            c = fo.good_features(grey[i], 80, 0.2, 7, 7)
+            pts = c.reshape(-1, 1, 2)
+            keys.append(i)
+            o_new = oo.detect_compute(grey[i], 500, brief_pattern())
+            io_, do_ = oo.bf_knn2(o_prev["desc"], o_new["desc"])
+            good = oo.ratio_filter(io_, do_, 0.75)
+            p, tracks = bo.point_tracking(tracks, pk, o_prev["xy"][good[:, 0]].astype(np.float64), k,
+                                          o_new["xy"][good[:, 1]].astype(np.float64))
+            popped += p
+            o_prev, pk, k = o_new, k, k + 1
+    popped += tracks
+    assert out["keyframes"] == keys and 2 < len(keys) < 10
+    assert len(out["tracks"]) == len(popped) > 20
+    for t, ot in zip(out["tracks"], popped):
+        assert list(t.getCoordinates().items()) == list(ot.getCoordinates().items())
+    assert out["points"].shape == (len(popped), 3) and len(out["extrinsics"]) == len(keys)
+    assert os.path.exists(out["file"]) and out["file"].endswith("runCloud.ply")
+    assert "termination condition is satisfied" in buf.getvalue() or "maximum number" in buf.getvalue()
