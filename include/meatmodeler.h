@@ -168,6 +168,7 @@ typedef struct mm_ba_problem {
     const int32_t *chunk_seg;         /* dev [n_chunks] index into seg_ids */
     const int32_t *chunk_begin, *chunk_end; /* dev [n_chunks] pair range */
     const int32_t *pair_o, *pair_o2;  /* dev [n_pairs] */
+    const int32_t *pair_p;            /* dev [n_pairs] point index of each pair (= pi[pair_o]); NULL: looked up */
 } mm_ba_problem;
 
 /* res [O,2] (may be NULL) ; cost2 [1] receives sum of squared residuals (caller halves it). */

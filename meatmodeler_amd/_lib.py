@@ -33,7 +33,7 @@ class BAProblem(C.Structure):
                 ("obs", vp), ("pt_ptr", vp), ("pt_obs", vp), ("cam_ptr", vp), ("cam_obs", vp),
                 ("cam_span", C.c_int32), ("reserved", C.c_int32), ("n_seg", C.c_int64), ("seg_ids", vp),
                 ("seg_chunk_ptr", vp), ("n_chunks", C.c_int64), ("chunk_seg", vp), ("chunk_begin", vp),
-                ("chunk_end", vp), ("pair_o", vp), ("pair_o2", vp)]
+                ("chunk_end", vp), ("pair_o", vp), ("pair_o2", vp), ("pair_p", vp)]
 
 
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header.

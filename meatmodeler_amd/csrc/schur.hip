@@ -225,9 +225,20 @@ __global__ __launch_bounds__(64 * SP_WAVES, 2) void schur_pairs_kernel(mm_ba_pro
 #pragma unroll
     for (int q = 0; q < 42; ++q) acc[q] = 0.0;
     const int e_end = __builtin_amdgcn_readfirstlane(pb.chunk_end[c]);
-    for (int e = __builtin_amdgcn_readfirstlane(pb.chunk_begin[c]) + lane; e < e_end; e += 64) {
-        const int o = pb.pair_o[e], o2 = pb.pair_o2[e];
-        const int p = pb.pi[o];
+    const int e_begin = __builtin_amdgcn_readfirstlane(pb.chunk_begin[c]);
+    // A chunk holds at most 256 pairs = four per lane: all their indices are requested up front (one memory round trip
+    // instead of one -- two without pair_p -- per trip of the loop), so that a trip only waits for its own data gathers
+    constexpr int MAXT = 4;
+    int oi[MAXT], o2i[MAXT], pidx[MAXT];
+#pragma unroll
+    for (int k = 0; k < MAXT; ++k) {
+        const int e = e_begin + lane + 64 * k;
+        const bool in = e < e_end;
+        oi[k] = in ? pb.pair_o[e] : -1;
+        o2i[k] = in ? pb.pair_o2[e] : -1;
+        pidx[k] = in ? (pb.pair_p ? pb.pair_p[e] : -2) : -1;
+    }
+    auto pair_body = [&](int o, int o2, int p) {
         const double *Xp = pts + (size_t)p * 3;
         Proj pr;
         ba_eval_vals<true, true>(cv_i, Xp, Ks, pb.obs[2 * (size_t)o], pb.obs[2 * (size_t)o + 1], pr);
@@ -258,6 +269,26 @@ __global__ __launch_bounds__(64 * SP_WAVES, 2) void schur_pairs_kernel(mm_ba_pro
 #pragma unroll
             for (int a = 0; a < 6; ++a) acc[a * 6 + b] += Y[a][0] * x0 + Y[a][1] * x1 + Y[a][2] * x2;
         }
+    };
+    const int trips = (e_end - e_begin + 63) / 64;   // wave-uniform
+    for (int k = 0; k < MAXT; ++k) {                 // (rolled: the body is ~450 f64 instructions)
+        if (k >= trips) break;
+        int o = oi[0], o2 = o2i[0], p = pidx[0];
+#pragma unroll
+        for (int q = 1; q < MAXT; ++q)               // select slot k without dynamic register indexing
+            if (q == k) {
+                o = oi[q];
+                o2 = o2i[q];
+                p = pidx[q];
+            }
+        if (o >= 0) {
+            if (p == -2) p = pb.pi[o];
+            pair_body(o, o2, p);
+        }
+    }
+    for (int e = e_begin + lane + 64 * MAXT; e < e_end; e += 64) {   // chunks longer than 256 pairs (other callers)
+        const int o = pb.pair_o[e], o2 = pb.pair_o2[e];
+        pair_body(o, o2, pb.pair_p ? pb.pair_p[e] : pb.pi[o]);
     }
     // totals: lane q < 21 holds value q (tot0) and value 21 + q (tot1); values 0..35 = the 6 x 6 block (row-major),
     // 36..41 = the right-hand side rows of the self segment

@@ -241,7 +241,7 @@ class BADevice:
         self.overlap = os.environ.get("MM_SCHUR_OVERLAP", "0") != "0"
         self.pb = BAProblem(F, P, O, ptr(self.K), ptr(self.fi), ptr(self.pi), ptr(self.obs),
                             ptr(self.pt_ptr), ptr(self.pt_obs), ptr(self.cam_ptr), ptr(self.cam_obs),
-                            0, 0, 0, None, None, 0, None, None, None, None, None)
+                            0, 0, 0, None, None, 0, None, None, None, None, None, None)
         self.n_pairs = 0
         if O:
             # widest camera span of any point: cameras further apart never share a point, so the reduced camera system
@@ -286,6 +286,8 @@ class BADevice:
                 self.pb.seg_ids, self.pb.seg_chunk_ptr = ptr(self.seg_ids), ptr(self.seg_chunk_ptr)
                 self.pb.chunk_seg, self.pb.chunk_begin, self.pb.chunk_end = ptr(self.chunk_seg), ptr(self.chunk_begin), ptr(self.chunk_end)
                 self.pb.pair_o, self.pb.pair_o2 = ptr(self.pair_o), ptr(self.pair_o2)
+                self.pair_p = self.pi[self.pair_o.long()].contiguous()   # saves the pair kernel a dependent gather
+                self.pb.pair_p = ptr(self.pair_p)
                 # camera slabs for the overlapped build + solve (mm_ba_schur_solve): first segment / chunk of each slab
                 n_slabs = 8
                 cps = -(-F // n_slabs)
