@@ -3,7 +3,7 @@
 
 extern "C" {
 
-int mm_abi_version(void) { return 1; }
+int mm_abi_version(void) { return 2; }
 
 int mm_ctx_create(int device, void *hip_stream, mm_ctx **out) {
     if (!out) return MM_ERR_ARG;

@@ -195,6 +195,29 @@ def g5_adjust_points():
         json.dump(meta, fh, indent=1)
 
 
+def g5_adjust_points_large():
+    """G5 case d: a problem wide enough for the two-ended banded factorisation (120 cameras -> 12 blocks of 64, band of
+    one block), reference settings and converged; only every 10th point of the minimisers is stored (small fixture)."""
+    F, P, L, seed = 120, 6000, 8, 21
+    pr = synth.make_ba_problem(F, P, L, seed=seed)
+    with np.errstate(all="ignore"):
+        cams0 = ref_ba.frameParameters(pr["ext"])
+    x0 = np.hstack([cams0, pr["pts0"].reshape(-1)])
+    A = ref_ba.pointAdjustmentSparsity(F, P, pr["fi"], pr["pi"])
+    args = (pr["K"], F, P, pr["fi"], pr["pi"], pr["obs"])
+    with contextlib.redirect_stdout(io.StringIO()):
+        r1 = least_squares(ref_ba.pointFun, x0, jac_sparsity=A, verbose=2, x_scale="jac", ftol=1e-4, method="trf", args=args)
+        tight = dict(jac_sparsity=A, verbose=0, x_scale="jac", ftol=1e-13, xtol=1e-13, gtol=1e-13, method="trf",
+                     args=args, max_nfev=3000, tr_solver="lsmr", tr_options=dict(atol=1e-14, btol=1e-14))
+        r2 = least_squares(ref_ba.pointFun, x0, jac="3-point", **tight)
+    assert r2.status > 0, r2.status
+    sub = np.arange(0, P, 10)
+    save("g5_adjust_points_d.npz", F=F, P=P, L=L, seed=seed, sub=sub, cost0=0.5 * float(np.sum(ref_ba.pointFun(x0, *args) ** 2)),
+         cost_ref=r1.cost, nfev_ref=r1.nfev, status_ref=r1.status, points_ref_sub=r1.x[6 * F:].reshape(P, 3)[sub],
+         cost_tight=r2.cost, nfev_tight=r2.nfev, status_tight=r2.status, optimality_tight=r2.optimality,
+         points_tight_sub=r2.x[6 * F:].reshape(P, 3)[sub], cams_tight=r2.x[:6 * F])
+
+
 def g6_adjust_pose():
     F = 5
     rng = np.random.default_rng(66)
@@ -293,7 +316,7 @@ def g8_track_api():
 
 if __name__ == "__main__":
     todo = dict(g1=g1_rotate_project, g2=g2_frame_parameters, g3=g3_point_pose_fun, g4=g4_sparsity,
-                g5=g5_adjust_points, g6=g6_adjust_pose, g7=g7_point_tracking, g8=g8_track_api)
+                g5=g5_adjust_points, g5d=g5_adjust_points_large, g6=g6_adjust_pose, g7=g7_point_tracking, g8=g8_track_api)
     for name in (sys.argv[1:] or list(todo)):          # `make_golden.py g5` regenerates one family
         todo[name]()
     with open(os.path.join(HERE, "VERSIONS.json"), "w") as fh:

@@ -26,12 +26,12 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_sizes_without_gpu():
     from meatmodeler_amd import _lib
-    assert _lib.lib.mm_abi_version() == 1
+    assert _lib.lib.mm_abi_version() == 2
     assert _lib.lib.mm_bf_workspace_bytes(1, 4000, 4000) > 0
     assert _lib.lib.mm_chol_workspace_bytes(3000) >= 47 * 64 * 64 * 8
     p = _lib.OrbParams(4000, 8, 31, 20, 1.2, 0)
     assert _lib.lib.mm_orb_workspace_bytes(2, 1080, 1920, ctypes.byref(p)) > 2 * 1920 * 1080
-    assert ctypes.sizeof(_lib.BAProblem) == 16 + 8 * 8 + 16 + 2 * 8 + 8 + 5 * 8   # matches sizeof(mm_ba_problem)
+    assert ctypes.sizeof(_lib.BAProblem) == 16 + 8 * 8 + 16 + 2 * 8 + 8 + 6 * 8   # matches sizeof(mm_ba_problem)
 
 
 def test_no_cpu_fallback_without_gpu():

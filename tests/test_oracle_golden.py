@@ -107,6 +107,13 @@ def test_g5_tight_minimiser_is_pinned(golden_dir, tag):
     assert ct <= float(d["cost_ref"]) and abs(float(d["cost_tight_2pt"]) - ct) <= 1e-10 * ct
 
 
+def test_g5_case_d_fixture_is_converged(golden_dir):
+    d = g(golden_dir, "g5_adjust_points_d.npz")
+    assert int(d["status_tight"]) > 0 and int(d["status_ref"]) == 2
+    assert float(d["cost_tight"]) <= float(d["cost_ref"]) < float(d["cost0"])
+    assert d["points_tight_sub"].shape == (len(d["sub"]), 3)
+
+
 @pytest.mark.parametrize("tag", ["a", "b"])
 def test_g5_tight_driver_reaches_reference_minimiser(golden_dir, tag):
     """The product's trust-region driver (bundleAdjuster.SchurTRF) run to ftol = xtol = gtol = 1e-12 on a NumPy
