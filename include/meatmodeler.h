@@ -186,6 +186,12 @@ int mm_ba_normal_eq(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, co
 /* out [O,2] = Jc * wc[fi] + Jp * wp[pi]  (either w may be NULL = zero). */
 int mm_ba_jvp(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, const double *pts, const double *wc,
               const double *wp, double *out);
+/* mm_ba_jvp with its inner products fused in: rows [2,3] dev receives {0, s, s} for s = <out, other> (other == NULL:
+ * <out, out>) and for s = <out, out> (the layout of mm_multi_dot's rows for residual-space vectors).  Deterministic. */
+size_t mm_ba_jvp_dots_workspace_bytes(const mm_ba_problem *pb);
+int mm_ba_jvp_dots(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, const double *pts, const double *wc,
+                   const double *wp, double *out, const double *other /*dev [O,2] | NULL*/, double *rows /*dev [2,3]*/,
+                   void *ws, size_t ws_bytes);
 /* Reduced camera system.  Cd [P,6] = damped point blocks (C + reg*diag), Bd [F,6,6] damped camera blocks.
  * S [6F,6F] (row-major) = blockdiag(Bd) - sum_p E_p Cd_p^-1 E_p^T ;  v [6F] = gc - E Cd^-1 gp.
  * Cinv [P,6] receives Cd^-1 (upper triangle).  S and v are overwritten.

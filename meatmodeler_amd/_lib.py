@@ -85,6 +85,8 @@ SIGNATURES = {
     "mm_ba_backsub": (C.c_int, [vp, C.POINTER(BAProblem), vp, vp, vp, vp, vp, vp]),
     "mm_chol_workspace_bytes": (C.c_size_t, [C.c_int]),
     "mm_chol_solve": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, C.c_size_t]),
+    "mm_ba_jvp_dots_workspace_bytes": (C.c_size_t, [C.POINTER(BAProblem)]),
+    "mm_ba_jvp_dots": (C.c_int, [vp, C.POINTER(BAProblem), vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t]),
     "mm_ba_scale_update": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int]),
     "mm_ba_damp": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),
     "mm_trf_step2d": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_double, vp]),

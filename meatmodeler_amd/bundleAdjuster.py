@@ -351,7 +351,7 @@ class SchurTRF:
         band_exchange = (self.allreduce is not None and hasattr(pb, "band_view")
                          and span_all <= getattr(pb, "max_band_span", 192) and half_bw < nc)
         nfev, njev = 1, 1
-        if self._native and hasattr(pb, "trf_step2d") and hasattr(pb, "schur_solve"):
+        if self._native and hasattr(pb, "trf_step2d") and hasattr(pb, "schur_solve") and hasattr(pb, "jvp_dots"):
             return self._solve_device(x, g, cost, half_bw, band_exchange, ftol, xtol, gtol, max_nfev, verbose)
         B, C = self._normal(x, g)
         si = self._scale_inv(B, C)
@@ -609,8 +609,8 @@ def _solve_device(self, x, g, cost, half_bw, band_exchange, ftol, xtol, gtol, ma
     while True:
         r0 = fix_params(pb.trf_fused(0, [g, si], [gh, ghs], split=nc), 1, max_row=1)   # rows: |g_h|^2 ; max |g|
         gh2_t = r0[0, 2:3]
-        u1 = pb.jvp(cams(x), pts(x), cams(ghs), pts(ghs)).reshape(-1)       # J (d g_h)
-        d11 = fix_residual(pb.multi_dot([(u1, u1)], 0))
+        u1, d11 = pb.jvp_dots(cams(x), pts(x), cams(ghs), pts(ghs))         # J (d g_h) and |J d g_h|^2 in one sweep
+        d11 = fix_residual(d11)
         if termination is not None or nfev == max_nfev:
             g_norm = float(r0[1, 2].item())
             if verbose == 2:
@@ -628,8 +628,8 @@ def _solve_device(self, x, g, cost, half_bw, band_exchange, ftol, xtol, gtol, ma
             r1 = fix_params(pb.trf_fused(1, [v, dp, si, gh], [gn, q1], [gh2_t], split=nc), 2)
             r2 = fix_params(pb.trf_fused(2, [gn, q1], [w], [r1[0, 2:3]], split=nc), 1)
             r3 = fix_params(pb.trf_fused(3, [w, q1, si, gh, x], [q2, s1, s2], [r2[0, 2:3]], split=nc), 5)
-            Jq2 = pb.jvp(cams(x), pts(x), cams(s2), pts(s2)).reshape(-1)
-            bs = fix_residual(pb.multi_dot([(u1, Jq2), (Jq2, Jq2)], 0))
+            _, bs = pb.jvp_dots(cams(x), pts(x), cams(s2), pts(s2), other=u1)   # <J s2, u1>, |J s2|^2
+            bs = fix_residual(bs)
 
             def trial(Delta_):
                 pb.trf_step2d(r0, d11, r1, r2, r3, bs, reg_eff, info, Delta_, board)

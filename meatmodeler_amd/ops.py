@@ -343,6 +343,18 @@ class BADevice:
                        "mm_ba_jvp")
         return out
 
+    def jvp_dots(self, cams, pts, wc, wp, other=None):
+        """jvp with its inner products fused in (mm_ba_jvp_dots): -> (out [O,2], rows [2,3]) with rows[0] = <out, other>
+        (other None: <out, out>) and rows[1] = <out, out>, each as {0, total, total}."""
+        out = torch.empty((self.O, 2), dtype=torch.float64, device=self.device)
+        rows = torch.empty((2, 3), dtype=torch.float64, device=self.device)
+        if getattr(self, "_jvp_ws", None) is None:
+            self._jvp_ws = torch.zeros(lib.mm_ba_jvp_dots_workspace_bytes(C.byref(self.pb)), dtype=torch.uint8,
+                                       device=self.device)
+        self.ctx.check(lib.mm_ba_jvp_dots(self.ctx.h, C.byref(self.pb), ptr(cams), ptr(pts), ptr(wc), ptr(wp), ptr(out),
+                                          ptr(other), ptr(rows), ptr(self._jvp_ws), self._jvp_ws.numel()), "mm_ba_jvp_dots")
+        return out, rows
+
     def schur(self, cams, pts, Bd, Cd, gc, gp):
         """Reduced camera system.  With a pair list (banded problems) only the LOWER block band of S is produced
         (deterministically) and the rest of S is zero; otherwise all of S is filled."""

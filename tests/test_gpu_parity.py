@@ -590,6 +590,25 @@ def test_vector_kernels_on_empty_vectors():
     assert r.cpu().tolist() == [[0.0, 0.0, 0.0], [0.0, 0.0, 0.0]]
 
 
+def test_jvp_dots_equals_jvp_plus_inner_products():
+    pr = synth.make_ba_problem(30, 3000, 5, seed=12)
+    F, P = 30, 3000
+    pb = ops.BADevice(pr["K"], pr["fi"], pr["pi"], pr["obs"], F, P, DEV)
+    rng = np.random.default_rng(3)
+    cams, pts = dev(bo.frame_parameters(pr["ext"]).reshape(F, 6)), dev(pr["pts0"])
+    wc, wp = dev(rng.normal(size=(F, 6))), dev(rng.normal(size=(P, 3)))
+    ref = pb.jvp(cams, pts, wc, wp)
+    other = dev(rng.normal(size=(pb.O, 2)))
+    for rep in range(2):                     # (the workspace counter resets itself)
+        out, rows = pb.jvp_dots(cams, pts, wc, wp)
+        assert torch.equal(out, ref)
+        r = rows.cpu().numpy()
+        np.testing.assert_allclose(r[:, 2], [float((ref * ref).sum())] * 2, rtol=1e-13)
+        assert (r[:, 0] == 0).all() and (r[:, 1] == r[:, 2]).all()
+        out, rows = pb.jvp_dots(cams, pts, wc, wp, other=other)
+        np.testing.assert_allclose(rows.cpu().numpy()[:, 2], [float((ref * other).sum()), float((ref * ref).sum())], rtol=1e-12)
+
+
 def test_trf_damping_vs_scipy_formula():
     """mm_trf_damping == the scalar recipe of SciPy trf.py:473-477 (regulariser from the Cauchy-like model along g_h)."""
     rng = np.random.default_rng(5)
