@@ -204,7 +204,8 @@ __global__ __launch_bounds__(64 * SP_WAVES, 2) void schur_pairs_kernel(mm_ba_pro
                                                                     const double *__restrict__ gp,
                                                                     double *partial, const double *__restrict__ Bd,
                                                                     const double *__restrict__ gc, double *S, double *v,
-                                                                    int32_t *seg_done, SlabSync slabs) {
+                                                                    int32_t *seg_done, SlabSync slabs, unsigned wg_begin,
+                                                                    unsigned wg_total) {
     __shared__ double Ks[9];
     __shared__ double red[SP_WAVES][21 * RED_LD];
     if (threadIdx.x < 9) Ks[threadIdx.x] = pb.K[threadIdx.x];
@@ -212,7 +213,9 @@ __global__ __launch_bounds__(64 * SP_WAVES, 2) void schur_pairs_kernel(mm_ba_pro
     const int lane = threadIdx.x & 63;
     // chunks are ordered by camera; the workgroups take them alternately from the front and from the back, because the
     // two-ended factorisation that may be consuming S concurrently starts at both ends and needs the middle last
-    const unsigned wg = (blockIdx.x & 1) ? gridDim.x - 1 - (blockIdx.x >> 1) : (blockIdx.x >> 1);
+    // (a build may be cut into several launches: this one covers the positions wg_begin .. of that order)
+    const unsigned gpos = blockIdx.x + wg_begin;
+    const unsigned wg = (gpos & 1) ? wg_total - 1 - (gpos >> 1) : (gpos >> 1);
     const int64_t c = (int64_t)wg * SP_WAVES + (threadIdx.x >> 6);
     if (c >= pb.n_chunks) return;  // wave-uniform; no workgroup barriers below
     const int sidx = __builtin_amdgcn_readfirstlane(pb.chunk_seg[c]);
@@ -479,7 +482,8 @@ extern "C" int mm_ba_schur(mm_ctx *ctx, const mm_ba_problem *pb, const double *c
         SlabSync none = {};
         MM_LAUNCH(ctx, "cam_table_kernel", cam_table_kernel, dim3((pb->F + 63) / 64), dim3(64), 0, pb->F, cams, w.camtab);
         MM_LAUNCH(ctx, "schur_pairs_kernel", schur_pairs_kernel, dim3((unsigned)wgs), dim3(64 * SP_WAVES), 0, *pb,
-                  (const double *)w.camtab, pts, (const double *)Cinv, gp, w.partial, Bd, gc, S, v, w.seg_done, none);
+                  (const double *)w.camtab, pts, (const double *)Cinv, gp, w.partial, Bd, gc, S, v, w.seg_done, none, 0u,
+                  (unsigned)wgs);
         return MM_OK;
     }
     const int nwin = (pb->F + SR_WIN - 1) / SR_WIN;
@@ -537,9 +541,19 @@ extern "C" int mm_ba_schur_solve(mm_ctx *ctx, const mm_ba_problem *pb, const dou
     MM_LAUNCH(ctx, "schur_diag_fill_kernel", schur_diag_fill_kernel, dim3(pb->F), dim3(64), 0, *pb, Bd, gc, S, v);
     for (int sl = 0; sl < n_slabs; ++sl)   // a slab without any segment is complete as it is
         if (slabs.seg_count[sl] == 0) MM_LAUNCH(ctx, "slab_flag_kernel", slab_flag_kernel, dim3(1), dim3(1), 0, w.slab_ready, sl);
+    // The build is ONE ordered list of chunks taken alternately from the front and the back (the two-ended factorisation
+    // needs the outer cameras first, the middle last), cut into two launches: the first half runs alone at full speed;
+    // the factorisation -- whose workgroups use the whole register file of their CUs, so no wave of the build fits
+    // beside them -- starts behind it on a second stream and shares the chip with the second half only, consuming
+    // block rows as their slabs are flagged complete.
+    const unsigned wg_total = (unsigned)((pb->n_chunks + SP_WAVES - 1) / SP_WAVES);
+    const unsigned wg_first = wg_total / 2;
+    if (wg_first > 0)
+        MM_LAUNCH(ctx, "schur_pairs_kernel", schur_pairs_kernel, dim3(wg_first), dim3(64 * SP_WAVES), 0, *pb,
+                  (const double *)w.camtab, pts, (const double *)Cinv, gp, w.partial, Bd, gc, S, v, w.seg_done, slabs, 0u, wg_total);
     MM_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
     MM_HIP(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
-    {   // the consumer goes first, so that its workgroups are resident before the producer floods the CUs
+    {
         mm_stream_swap sw(ctx, ctx->aux);
         int rc = mm_chol_solve_gated(ctx, S, n, v, 1, half_bandwidth, info, ws_chol, ws_chol_bytes, w.slab_ready, cams_per_slab, pb->F, 2);
         if (rc) {  // whatever did get enqueued on the second stream is joined before the error travels up
@@ -549,11 +563,8 @@ extern "C" int mm_ba_schur_solve(mm_ctx *ctx, const mm_ba_problem *pb, const dou
         }
         MM_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
     }
-    // ONE launch builds all of S; chunks are ordered by camera, so the slabs complete roughly in ascending order and
-    // the waves that finish a slab's last segment raise its flag (no kernel boundaries inside the build)
-    MM_LAUNCH(ctx, "schur_pairs_kernel", schur_pairs_kernel, dim3((unsigned)((pb->n_chunks + SP_WAVES - 1) / SP_WAVES)),
-              dim3(64 * SP_WAVES), 0, *pb, (const double *)w.camtab, pts, (const double *)Cinv, gp, w.partial, Bd, gc, S, v,
-              w.seg_done, slabs);
+    MM_LAUNCH(ctx, "schur_pairs_kernel", schur_pairs_kernel, dim3(wg_total - wg_first), dim3(64 * SP_WAVES), 0, *pb,
+              (const double *)w.camtab, pts, (const double *)Cinv, gp, w.partial, Bd, gc, S, v, w.seg_done, slabs, wg_first, wg_total);
     MM_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     return MM_OK;
 }
