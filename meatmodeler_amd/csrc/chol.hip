@@ -1234,6 +1234,15 @@ __global__ __launch_bounds__(256) void chol_band_bwd_kernel(double *A, TwGeom g,
     if (dead) MM_FUSED_ABANDON;
 }
 
+// one launch instead of three fills per solve: info = 0, flags = 0, the backward kernel's contribution buffer = sentinel
+__global__ __launch_bounds__(256) void chol_init_kernel(int32_t *__restrict__ info, int32_t *__restrict__ flags, size_t nflags,
+                                                        unsigned long long *__restrict__ sentinel_buf, size_t nsent) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+    if (i == 0) info[0] = 0;
+    for (size_t k = i; k < nflags; k += stride) flags[k] = 0;
+    for (size_t k = i; k < nsent; k += stride) sentinel_buf[k] = BWD_SENTINEL;
+}
+
 // copy the band of the lower triangle into the upper triangle for the columns side 1 eliminates: (j, i) <- (i, j) for
 // i >= row0, 0 < i - j <= hb (callers of the two-ended path that only filled the lower triangle)
 __global__ __launch_bounds__(256) void chol_mirror_kernel(double *A, int n, int row0, int hb) {
@@ -1326,7 +1335,7 @@ size_t mm_chol_workspace_bytes(int n) {
     size_t nblk = (size_t)(n + NB - 1) / NB;
     return mm_align_up(nblk * NB * NB * sizeof(double), 256) + mm_align_up((size_t)(n + NB) * sizeof(double), 256) +
            mm_align_up((2 * (2 * nblk * (FUSED_MAX_BWB + 1) + 2 * nblk) + 64 + FUSED_MAX_BWB * FUSED_MAX_BWB) * sizeof(int32_t), 256) +
-           mm_align_up(2 * nblk * (FUSED_MAX_BWB + 1) * NB * sizeof(double), 256);
+           2 * mm_align_up(2 * nblk * (FUSED_MAX_BWB + 1) * NB * sizeof(double), 256);   // forward + backward contributions
 }
 
 int mm_chol_solve(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int half_bandwidth, int32_t *info, void *ws,
@@ -1376,7 +1385,6 @@ int mm_chol_solve_gated(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int 
         return mm_fail(ctx, MM_ERR_ARG, "mm_chol_solve: bad argument");
     if (!ws || ws_bytes < mm_chol_workspace_bytes(n)) return mm_fail(ctx, MM_ERR_WORKSPACE, "mm_chol_solve: workspace too small");
     if (((uintptr_t)A & 15) || (n & 1)) return mm_fail(ctx, MM_ERR_ARG, "mm_chol_solve: A must be 16-byte aligned and n even");
-    MM_HIP(ctx, hipMemsetAsync(info, 0, sizeof(int32_t), ctx->stream));
     const int nblk = (n + NB - 1) / NB;
     double *Linv = (double *)ws;
     double *ytmp = (double *)((char *)ws + mm_align_up((size_t)nblk * NB * NB * sizeof(double), 256));
@@ -1397,6 +1405,8 @@ int mm_chol_solve_gated(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int 
     int32_t *flags = (int32_t *)((char *)ytmp + mm_align_up((size_t)(n + NB) * sizeof(double), 256));
     double *contrib = (double *)((char *)flags + mm_align_up((2 * (2 * (size_t)nblk * (FUSED_MAX_BWB + 1) + 2 * nblk) + 64 + FUSED_MAX_BWB * FUSED_MAX_BWB) * sizeof(int32_t), 256));
     const int sides = g.b > 0 ? 2 : 1;
+    double *contrib_bwd = (double *)((char *)contrib + mm_align_up(2 * (size_t)nblk * (FUSED_MAX_BWB + 1) * NB * sizeof(double), 256));
+    if (!fused) MM_HIP(ctx, hipMemsetAsync(info, 0, sizeof(int32_t), ctx->stream));
     if (fused) {
         if (!ctx->attr_chol_fused) {
             MM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(chol_band_fused_kernel<2>),
@@ -1410,7 +1420,8 @@ int mm_chol_solve_gated(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int 
         }
         const size_t nflags = 1 + 2 * (2 * (size_t)nblk * (bwb + 1) + 2 * nblk) + (size_t)g.m * g.m;
         const double *b_fwd = nrhs >= 1 ? b : nullptr;  // the first right-hand side rides along
-        MM_HIP(ctx, hipMemsetAsync(flags, 0, nflags * sizeof(int32_t), ctx->stream));
+        MM_LAUNCH(ctx, "chol_init_kernel", chol_init_kernel, dim3(32), dim3(256), 0, info, flags, nflags,
+                  (unsigned long long *)contrib_bwd, (size_t)sides * nblk * (bwb + 1) * NB);
         const int G = (bwb + 1) + bwb * (bwb - 1) / 2;
         // two-ended: a third group of workgroups, one per block of M x M (fewer than G: m = bwb), pre-accumulates
         const int grid = g.b > 0 ? 2 * G + g.m * (g.m + 1) / 2 : G;
@@ -1447,12 +1458,16 @@ int mm_chol_solve_gated(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int 
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_LDS_BYTES));
                 ctx->attr_chol_bwd = true;
             }
-            // x (the output) and the contribution buffer start as the NaN sentinel the kernel polls on
-            MM_HIP(ctx, hipMemsetAsync(flags, 0, sizeof(int32_t), ctx->stream));
+            // x (the output) and the contribution buffer start as the NaN sentinel the kernel polls on (the buffer of the
+            // first right-hand side was prepared by chol_init_kernel; an abort flag left by the factorisation makes the
+            // kernel leave at once -- info is -1 then anyway)
+            if (c > 0) {
+                MM_HIP(ctx, hipMemsetAsync(flags, 0, sizeof(int32_t), ctx->stream));
+                MM_HIP(ctx, hipMemsetAsync(contrib_bwd, 0xFF, (size_t)sides * nblk * (bwb + 1) * NB * sizeof(double), ctx->stream));
+            }
             MM_HIP(ctx, hipMemsetAsync(bc, 0xFF, (size_t)n * sizeof(double), ctx->stream));
-            MM_HIP(ctx, hipMemsetAsync(contrib, 0xFF, (size_t)sides * nblk * (bwb + 1) * NB * sizeof(double), ctx->stream));
             MM_LAUNCH(ctx, "chol_band_bwd_kernel", chol_band_bwd_kernel, dim3(sides * (bwb >= 2 ? bwb : 1)), dim3(256),
-                      BWD_LDS_BYTES, A, g, (const double *)Linv, (const double *)ytmp, bc, contrib, flags, info);
+                      BWD_LDS_BYTES, A, g, (const double *)Linv, (const double *)ytmp, bc, contrib_bwd, flags, info);
             continue;
         }
         for (int k = nblk - 1; k >= 0; --k) {  // L^T x = y

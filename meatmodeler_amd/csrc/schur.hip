@@ -128,8 +128,11 @@ struct SlabSync {
 // Per-camera table for the pair kernel: parameters + rotation coefficients (11 doubles per camera), computed once
 // per build instead of a sincos / sqrt / four divisions in every chunk's prologue.
 constexpr int CAMTAB = 11;
-__global__ __launch_bounds__(64) void cam_table_kernel(int F, const double *__restrict__ cams, double *__restrict__ tab) {
+__global__ __launch_bounds__(64) void cam_table_kernel(int F, const double *__restrict__ cams, double *__restrict__ tab,
+                                                       int32_t *__restrict__ seg_done, int64_t n_seg) {
     const int f = blockIdx.x * 64 + threadIdx.x;
+    // (also clears the finished-chunk counters of the build that follows: one fill launch less)
+    for (int64_t k = f; k < n_seg; k += (int64_t)gridDim.x * 64) seg_done[k] = 0;
     if (f >= F) return;
     const double *c = cams + (size_t)f * 6;
     const CamCoef k = cam_coef_of(c);
@@ -478,9 +481,9 @@ extern "C" int mm_ba_schur(mm_ctx *ctx, const mm_ba_problem *pb, const double *c
         MM_LAUNCH(ctx, "schur_diag_fill_kernel", schur_diag_fill_kernel, dim3(pb->F), dim3(64), 0, *pb, Bd, gc, S, v);
         const int64_t wgs = (pb->n_chunks + SP_WAVES - 1) / SP_WAVES;
         const SchurWs w = carve_schur_ws(pb, ws);
-        MM_HIP(ctx, hipMemsetAsync(w.seg_done, 0, (size_t)pb->n_seg * sizeof(int32_t), ctx->stream));
         SlabSync none = {};
-        MM_LAUNCH(ctx, "cam_table_kernel", cam_table_kernel, dim3((pb->F + 63) / 64), dim3(64), 0, pb->F, cams, w.camtab);
+        MM_LAUNCH(ctx, "cam_table_kernel", cam_table_kernel, dim3((pb->F + 63) / 64), dim3(64), 0, pb->F, cams, w.camtab, w.seg_done,
+                  (int64_t)pb->n_seg);
         MM_LAUNCH(ctx, "schur_pairs_kernel", schur_pairs_kernel, dim3((unsigned)wgs), dim3(64 * SP_WAVES), 0, *pb,
                   (const double *)w.camtab, pts, (const double *)Cinv, gp, w.partial, Bd, gc, S, v, w.seg_done, none, 0u,
                   (unsigned)wgs);
@@ -534,9 +537,9 @@ extern "C" int mm_ba_schur_solve(mm_ctx *ctx, const mm_ba_problem *pb, const dou
     slabs.done = w.slab_done;
     slabs.cams_per_slab = cams_per_slab;
     for (int sl = 0; sl < n_slabs; ++sl) slabs.seg_count[sl] = (int32_t)(slab_seg_ptr[sl + 1] - slab_seg_ptr[sl]);
-    MM_LAUNCH(ctx, "cam_table_kernel", cam_table_kernel, dim3((pb->F + 63) / 64), dim3(64), 0, pb->F, cams, w.camtab);
+    MM_LAUNCH(ctx, "cam_table_kernel", cam_table_kernel, dim3((pb->F + 63) / 64), dim3(64), 0, pb->F, cams, w.camtab, w.seg_done,
+              (int64_t)pb->n_seg);
     MM_HIP(ctx, hipMemsetAsync(S, 0, (size_t)n * n * sizeof(double), ctx->stream));
-    MM_HIP(ctx, hipMemsetAsync(w.seg_done, 0, (size_t)pb->n_seg * sizeof(int32_t), ctx->stream));
     MM_HIP(ctx, hipMemsetAsync(w.slab_ready, 0, 2 * MAX_SLABS * sizeof(int32_t), ctx->stream));
     MM_LAUNCH(ctx, "schur_diag_fill_kernel", schur_diag_fill_kernel, dim3(pb->F), dim3(64), 0, *pb, Bd, gc, S, v);
     for (int sl = 0; sl < n_slabs; ++sl)   // a slab without any segment is complete as it is

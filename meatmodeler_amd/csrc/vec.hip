@@ -509,9 +509,8 @@ __global__ __launch_bounds__(64) void trf_step2d_kernel(Step2dIn in, double Delt
                     const double wdt = (hi - lo) / 64.0;
                     const bool neg = N(lo + wdt * lane) <= 0.0;
                     // the sign change sits behind the LAST lane of the leading run that still has the sign of `lo`
-                    const unsigned long long same = __ballot(neg == lo_neg);
-                    int k = 0;
-                    while (k < 63 && ((same >> (k + 1)) & 1ull)) ++k;
+                    const unsigned long long same = __ballot(neg == lo_neg);   // bit 0 (the sample at `lo`) is always set
+                    const int k = (~same ? (int)__builtin_ctzll(~same) : 64) - 1;  // length of the leading run of ones - 1
                     lo = lo + wdt * k;
                     hi = lo + wdt;
                 }
