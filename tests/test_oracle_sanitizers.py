@@ -48,3 +48,64 @@ def test_c_oracles_clean_under_asan_ubsan(tmp_path):
     r = subprocess.run([sys.executable, "-c", CHILD.format(root=ROOT, orb=libs["orb_oracle"], frame=libs["frame_oracle"])],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "sanitized run ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+HOST_CHILD = r"""
+import ctypes as C, sys, os, numpy as np
+L = C.CDLL({so!r})
+vp = C.c_void_p
+p = lambda a: a.ctypes.data_as(vp)
+# goodFeaturesToTrack's greedy selection
+rng = np.random.default_rng(0)
+w, h = 97, 61
+pos = rng.permutation(w * h)[:900].astype(np.int32)
+out = np.zeros((64, 2), np.float32)
+L.mm_gftt_select.argtypes = [vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_double, vp, C.c_int]
+for md in (0.0, 1.0, 5.5, 200.0):
+    m = L.mm_gftt_select(p(pos), len(pos), w, h, 50, md, p(out), 64)
+    assert 0 < m <= 50
+    if md >= 1:
+        q = out[:m]
+        d = np.linalg.norm(q[:, None] - q[None], axis=2) + 1e9 * np.eye(m)
+        assert d.min() >= md - 1e-6
+assert L.mm_gftt_select(p(pos), 0, w, h, 5, 3.0, p(out), 64) == 0
+# PLY writer
+L.mm_write_ply.argtypes = [C.c_char_p, vp, C.c_int64]
+xyz = rng.normal(size=(11, 3))
+assert L.mm_write_ply({ply!r}.encode(), p(xyz), 11) == 0 and os.path.getsize({ply!r}) > 11 * 24
+# BA index build (CSR by point / by camera) incl. the range check
+L.mm_ba_build_index.argtypes = [C.c_int, C.c_int, C.c_int64] + [vp] * 6
+fi = rng.integers(0, 7, 200).astype(np.int32); pi = np.sort(rng.integers(0, 30, 200)).astype(np.int32)
+pt_ptr = np.zeros(31, np.int32); pt_obs = np.zeros(200, np.int32); cam_ptr = np.zeros(8, np.int32); cam_obs = np.zeros(200, np.int32)
+assert L.mm_ba_build_index(7, 30, 200, p(fi), p(pi), p(pt_ptr), p(pt_obs), p(cam_ptr), p(cam_obs)) == 0
+assert pt_ptr[-1] == 200 and cam_ptr[-1] == 200 and sorted(cam_obs.tolist()) == list(range(200))
+fi[3] = 9
+assert L.mm_ba_build_index(7, 30, 200, p(fi), p(pi), p(pt_ptr), p(pt_obs), p(cam_ptr), p(cam_obs)) != 0
+# track linking over a clip (hash join) incl. a malformed match index
+L.mm_link_tracks_clip.restype = C.c_int64
+L.mm_link_tracks_clip.argtypes = [C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int64, C.c_int64, vp, vp, vp, vp]
+F, cap = 5, 40
+kc = np.full(F, cap, np.int32); xy = rng.uniform(0, 100, (F, cap, 2)).astype(np.float32)
+mc = np.full(F - 1, 25, np.int32); mm = np.stack([np.stack([rng.permutation(cap)[:25], rng.integers(0, cap, 25)], 1) for _ in range(F - 1)]).astype(np.int32)
+tot = int(mc.sum())
+tp = np.zeros(tot + 2, np.int64); of = np.zeros(2 * tot + 2, np.int32); ok = np.zeros(2 * tot + 2, np.int32); no = C.c_int64(0)
+nt = L.mm_link_tracks_clip(F, cap, p(kc), p(xy), 25, p(mc), p(mm), tot + 1, 2 * tot + 1, p(tp), p(of), p(ok), C.byref(no))
+assert nt > 0 and no.value >= 2 * nt and tp[nt] == no.value
+print("sanitized host run ok", nt, no.value)
+"""
+
+
+def test_host_side_of_the_library_clean_under_asan_ubsan(tmp_path):
+    """meatmodeler_amd/csrc/host_index.cpp (track linking, BA index build, goodFeaturesToTrack's greedy selection, PLY
+    writer) is plain C++: compiled alone with g++ -fsanitize=address,undefined and exercised through ctypes."""
+    libasan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not libasan or not os.path.isabs(libasan) or not os.path.exists(libasan):
+        pytest.skip("libasan not available")
+    so = str(tmp_path / "libhost_san.so")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fno-omit-frame-pointer", "-fsanitize=address,undefined",
+                           "-fno-sanitize-recover=undefined", "-shared", "-fPIC", "-o", so,
+                           os.path.join(ROOT, "meatmodeler_amd", "csrc", "host_index.cpp"), "-lpthread"])
+    env = dict(os.environ, LD_PRELOAD=libasan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1")
+    r = subprocess.run([sys.executable, "-c", HOST_CHILD.format(so=so, ply=str(tmp_path / "c.ply"))], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "sanitized host run ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
