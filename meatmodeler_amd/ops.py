@@ -601,7 +601,7 @@ def good_features(img, max_corners, quality, min_distance, block_size=3, ctx=Non
     ctx = ctx or default_context()
     h, w = img.shape
     eig = min_eig(img, block_size, ctx)
-    cap = (h * w) // 4 + 64                      # strict 3x3 maxima: at most one pixel in four
+    cap = h * w                                  # (a plateau of equal values keeps every one of its pixels)
     d = img.device
     mx = torch.zeros(1, dtype=torch.int64, device=d)
     vb = torch.empty(cap, dtype=torch.int64, device=d)

@@ -250,7 +250,7 @@ int frc_good_features(const uint8_t *img, int w, int h, int p, int max_corners, 
     for (size_t i = 0; i < (size_t)w * h; ++i)
         if (eig[i] > mx) mx = eig[i];
     const double thr = mx * quality;
-    cand_t *cd = (cand_t *)malloc(sizeof(cand_t) * (size_t)w * h / 2 + 64);
+    cand_t *cd = (cand_t *)malloc(sizeof(cand_t) * ((size_t)w * h + 1)); /* (a plateau of equal values keeps every pixel) */
     size_t nc = 0;
     for (int y = 1; y < h - 1; ++y)
         for (int x = 1; x < w - 1; ++x) {

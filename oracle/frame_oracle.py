@@ -74,7 +74,7 @@ def min_eig(img, block_size=3):
 def good_features(img, max_corners, quality, min_distance, block_size=3):
     img = np.ascontiguousarray(img, np.uint8)
     h, w = img.shape
-    cap = max_corners if max_corners > 0 else (h * w) // 4 + 16
+    cap = max_corners if max_corners > 0 else h * w
     out = np.zeros((cap, 2), np.float32)
     n = _lib().frc_good_features(_p(img), C.c_int(w), C.c_int(h), C.c_int(w), C.c_int(max_corners), C.c_double(quality),
                                  C.c_double(min_distance), C.c_int(block_size), _p(out), C.c_int(cap))

@@ -1263,6 +1263,13 @@ def test_min_eig_and_good_features_bit_exact(bs, w, h):
         np.testing.assert_array_equal(got, ref, err_msg=str((max_c, q, md)))
     assert len(fo.good_features(img, 200, 0.01, 10.0, bs)) > (20 if w > 100 else 3)
     assert processor.goodFeaturesToTrack(np.full((40, 40), 7, np.uint8), 10, 0.1, 5) is None      # flat image: no corners
+    # a periodic pattern: hundreds of corners with EQUAL strength and plateaus of equal values -> the tie order (y, x)
+    # and the candidate capacity are exercised
+    yy, xx = np.mgrid[0:h, 0:w]
+    board = (((yy // 8) + (xx // 8)) % 2 * 200 + 20).astype(np.uint8)
+    np.testing.assert_array_equal(ops.min_eig(dev(board), bs).cpu().numpy(), fo.min_eig(board, bs))
+    for max_c, q, md in ((0, 0.5, 0.0), (300, 0.2, 6.0)):
+        np.testing.assert_array_equal(ops.good_features(dev(board), max_c, q, md, bs), fo.good_features(board, max_c, q, md, bs))
 
 
 def test_keyframe_tracking_flow_matches_oracle_flow():
