@@ -600,6 +600,8 @@ def good_features(img, max_corners, quality, min_distance, block_size=3, ctx=Non
     (mm_gftt_select).  -> numpy [n,2] f32 (x, y)."""
     ctx = ctx or default_context()
     h, w = img.shape
+    if h < 3 or w < 3:                            # no interior pixel: no corner (the 3x3 suppression needs a neighbourhood)
+        return np.zeros((0, 2), np.float32)
     eig = min_eig(img, block_size, ctx)
     cap = h * w                                  # (a plateau of equal values keeps every one of its pixels)
     d = img.device
