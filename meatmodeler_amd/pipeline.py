@@ -131,7 +131,8 @@ class ClipPipeline:
             return inside
         return inside & (last_frame <= hi - 2)
 
-    def adjust_windows(self, out, K, extrinsics, window=50, stride=25, ftol=1e-4, verbose=0, timers=None, dist=None):
+    def adjust_windows(self, out, K, extrinsics, window=50, stride=25, ftol=1e-4, verbose=0, timers=None, dist=None,
+                       order="sequential"):
         """Incremental bundle adjustment over a sliding window of keyframes: the reference keeps this step as a
         commented hook (processor.py:395-408: after a keyframe whose tracks were popped, `managePoints(popped_tracks)`
         + `adjustPoints` over everything so far); bounding it to the last `window` keyframes is what makes the
@@ -145,11 +146,24 @@ class ClipPipeline:
         all-reduces the camera-side blocks exactly as the global adjustment does ("C5 sliding
         window: same, with F replaced by W"); the adjusted points of a window are re-assembled on every rank.
 
+        order = "wavefront": the windows are coloured so that windows of one colour share no camera (two colours for
+        stride >= window / 2: the even windows, then the odd ones, which start from both neighbours' results) and each
+        colour is one pass in which every window is solved WHOLE by one rank (round robin), the results of a pass being
+        exchanged with one all-reduce of the touched cameras / points.  Windows of a pass are independent, so this
+        scales with the number of GPUs instead of paying a collective per trust-region iteration of a 300-unknown
+        system, and the result does not depend on the world size at all (bit for bit: every window is solved by the
+        same un-sharded code on the same inputs).  It is a different -- equally valid -- schedule than "sequential".
+
         `out` is the result of `run(..., ba=False)`.  -> dict(cams [F,6] device, points [T,3] device, windows=[...])."""
         d = self.device
         world = dist.get_world_size() if dist is not None else 1
         rank = dist.get_rank() if dist is not None else 0
         allreduce = parallel.AllReduce() if world > 1 else None
+        if order not in ("sequential", "wavefront"):
+            raise ValueError("order must be 'sequential' or 'wavefront'")
+        if order == "wavefront":
+            return self._adjust_windows_wavefront(out, K, extrinsics, window, stride, ftol, verbose, timers, allreduce,
+                                                  world, rank)
         F = int(np.asarray(extrinsics).shape[0])
         tp, of_, ok = out["track_ptr_dev"], out["obs_frame_dev"], out["obs_kp_dev"]
         xy = out["xy_dev"]
@@ -211,6 +225,86 @@ class ClipPipeline:
         self.ctx.sync()
         if timers is not None:
             timers["ba_windows"] = timers.get("ba_windows", 0.0) + (time.perf_counter() - t0) * 1e3
+        return dict(cams=cams, points=pts, windows=stats)
+
+    def _window_problem(self, out, first_f, last_f, lens_all, tp64, lo, hi, F):
+        """Selection + managePoints-order flattening of one window on the device -> (sel, fi, pi, coords, P, O)."""
+        d = self.device
+        of_, ok, xy = out["obs_frame_dev"], out["obs_kp_dev"], out["xy_dev"]
+        sel = torch.nonzero(self.window_selection(first_f, last_f, lo, hi, F)).reshape(-1)
+        P = int(sel.numel())
+        if P == 0:
+            return sel, None, None, None, 0, 0
+        lens = lens_all[sel]
+        O = int(lens.sum().item())
+        starts = tp64[sel]
+        offs = torch.cumsum(lens, 0) - lens
+        oi = torch.repeat_interleave(starts - offs, lens, output_size=O) + torch.arange(O, device=d)
+        fi = (of_[oi] - lo).to(torch.int32)
+        pi = torch.repeat_interleave(torch.arange(P, dtype=torch.int32, device=d), lens, output_size=O)
+        coords = xy[of_[oi].long(), ok[oi].long()].to(torch.float64)
+        return sel, fi, pi, coords, P, O
+
+    def _adjust_windows_wavefront(self, out, K, extrinsics, window, stride, ftol, verbose, timers, allreduce, world, rank):
+        d = self.device
+        F = int(np.asarray(extrinsics).shape[0])
+        tp, of_ = out["track_ptr_dev"], out["obs_frame_dev"]
+        T = tp.shape[0] - 1
+        with np.errstate(all="ignore"):
+            cams = torch.as_tensor(frameParameters(np.asarray(extrinsics, float)[:, :3, :]).reshape(F, 6)).to(d)
+        pts = out["points0"].clone()
+        if T == 0:
+            return dict(cams=cams, points=pts, windows=[])
+        tp64 = tp.long()
+        first_f, last_f = of_[tp64[:-1]], of_[tp64[1:] - 1]
+        lens_all = tp64[1:] - tp64[:-1]
+        window = max(2, min(int(window), F))
+        his = list(range(window, F, max(1, int(stride)))) + [F]
+        wins = [(max(0, hi - window), hi) for hi in his]
+        # greedy colouring in window order: a colour's windows share no camera
+        colour_end, colours = [], []
+        for lo, hi in wins:
+            c = next((k for k, e in enumerate(colour_end) if e <= lo), len(colour_end))
+            if c == len(colour_end):
+                colour_end.append(hi)
+            else:
+                colour_end[c] = hi
+            colours.append(c)
+        t0 = time.perf_counter()
+        table = torch.zeros((len(wins), 5), dtype=torch.float64, device=d)      # points, observations, nfev, status, cost
+        for c in range(len(colour_end)):
+            mine = [k for k, cc in enumerate(colours) if cc == c]
+            cams_upd, pts_upd = torch.zeros_like(cams), torch.zeros_like(pts)
+            cam_mask = torch.zeros(F, dtype=torch.float64, device=d)
+            pt_mask = torch.zeros(T, dtype=torch.float64, device=d)
+            for j, k in enumerate(mine):
+                if j % world != rank:
+                    continue
+                lo, hi = wins[k]
+                sel, fi, pi, coords, P, O = self._window_problem(out, first_f, last_f, lens_all, tp64, lo, hi, F)
+                if P == 0:
+                    continue
+                pb = ops.BADevice(K, fi, pi, coords, hi - lo, P, d, self.ctx)
+                res = SchurTRF(pb).solve(cams[lo:hi].contiguous(), pts[sel].contiguous(), ftol=ftol,
+                                         verbose=verbose if rank == 0 else 0)
+                cams_upd[lo:hi] = res.cams
+                cam_mask[lo:hi] = 1.0
+                pts_upd[sel] = res.pts
+                pt_mask[sel] = 1.0
+                table[k] = torch.tensor([P, O, res.nfev, res.status, res.cost], dtype=torch.float64, device=d)
+            if allreduce is not None:          # the windows of a pass touch disjoint cameras / points: the sums are copies
+                for t_ in (cams_upd, cam_mask, pts_upd, pt_mask):
+                    allreduce(t_)
+            cams = torch.where(cam_mask[:, None] > 0, cams_upd, cams)
+            pts = torch.where(pt_mask[:, None] > 0, pts_upd, pts)
+        if allreduce is not None:
+            allreduce(table)
+        self.ctx.sync()
+        if timers is not None:
+            timers["ba_windows"] = timers.get("ba_windows", 0.0) + (time.perf_counter() - t0) * 1e3
+        tab = table.cpu().numpy()
+        stats = [dict(lo=wins[k][0], hi=wins[k][1], points=int(r[0]), observations=int(r[1]), nfev=int(r[2]), status=int(r[3]),
+                      cost=float(r[4]), colour=colours[k]) for k, r in enumerate(tab) if r[0] > 0]
         return dict(cams=cams, points=pts, windows=stats)
 
     @staticmethod

@@ -79,6 +79,10 @@ def main():
     out.update(win_cams=w["cams"].cpu().numpy(), win_pts=w["points"].cpu().numpy(),
                win_nfev=np.array([s["nfev"] for s in w["windows"]]), win_cost=np.array([s["cost"] for s in w["windows"]]),
                win_points=np.array([s["points"] for s in w["windows"]]))
+    wf = pipe.adjust_windows(o, K, ext, window=5, stride=2, ftol=1e-4, dist=dist, order="wavefront")
+    out.update(wf_cams=wf["cams"].cpu().numpy(), wf_pts=wf["points"].cpu().numpy(),
+               wf_table=np.array([[s["lo"], s["hi"], s["points"], s["observations"], s["nfev"], s["status"], s["cost"], s["colour"]]
+                                  for s in wf["windows"]]))
     np.savez(os.path.join(outdir, f"w{world}_rank{rank}.npz"), **out)
     if dist is not None:
         dist.barrier()

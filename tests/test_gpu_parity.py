@@ -1202,6 +1202,11 @@ def test_two_ranks_on_one_gpu_real_kernels_match_one_rank(tmp_path):
     np.testing.assert_array_equal(r0["win_cams"], r1["win_cams"])
     np.testing.assert_array_equal(r0["win_pts"], r1["win_pts"])
     np.testing.assert_array_equal(r0["win_nfev"], r1["win_nfev"])
+    # wavefront schedule: whole windows spread over the ranks -> the result does not depend on the world size, bit for bit
+    for k in ("wf_cams", "wf_pts", "wf_table"):
+        np.testing.assert_array_equal(r0[k], r1[k])
+        np.testing.assert_array_equal(r0[k], one[k])
+    assert len(one["wf_table"]) == len(one["win_points"]) and set(one["wf_table"][:, 7]) >= {0.0, 1.0}
     assert np.all(np.abs(r0["win_cost"] - one["win_cost"]) <= 0.3 * one["win_cost"])
 
 
