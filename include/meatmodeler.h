@@ -262,6 +262,31 @@ int mm_ba_damp(mm_ctx *ctx, int F, int P, const double *B, const double *C, cons
  * scalars the host-side bookkeeping needs (wn2, gn2, |x|^2, |g|_inf, |g_h|^2, d11, reg): one read-back per trial step. */
 int mm_trf_step2d(mm_ctx *ctx, const double *r0, const double *d11, const double *r1, const double *r2, const double *r3,
                   const double *bs, const double *reg, const int32_t *info, double Delta, double *board /*dev [14]*/);
+/* The whole trust-region solve of adjustPoints in ONE call (single GPU; replaces the loop scipy.optimize.least_squares
+ * runs for bundleAdjuster.py:180-192: method='trf', x_scale='jac', linear loss, exact Schur-complement step instead of
+ * LSMR).  Sequences exactly the calls above the way meatmodeler_amd/bundleAdjuster.py does -- bit-identical iterates --
+ * with the host side of an iteration in C++: one 16-double read-back per trial step, no allocation.
+ * cams [F,6] / pts [P,3] dev: initial values in, solution out.  log (HOST, may be NULL with log_cap 0) receives one row
+ * per line of SciPy's verbose=2 table; report->log_rows counts the rows produced (may exceed log_cap).
+ * status: SciPy's (0 max_nfev, 1 gtol, 2 ftol, 3 xtol, 4 both).  Returns MM_ERR_NUMERIC if the residuals are not finite
+ * at the start or the reduced system stays indefinite after six 100x increases of the damping. */
+typedef struct mm_trf_params {
+    double ftol, xtol, gtol;
+    double min_damping;   /* floor of the damping relative to the unit diagonal of the scaled system (<= 0: 1e-9) */
+    int64_t max_nfev;     /* <= 0: 100 * (6F + 3P) */
+} mm_trf_params;
+typedef struct mm_trf_row {
+    int32_t iteration, nfev;
+    double cost, reduction, step_norm, optimality;   /* reduction / step_norm are NaN on the first row */
+} mm_trf_row;
+typedef struct mm_trf_report {
+    double cost0, cost, optimality, min_damping /* as raised during the solve */;
+    int32_t nfev, njev, status, iterations, log_rows, reserved;
+} mm_trf_report;
+size_t mm_ba_trf_workspace_bytes(const mm_ba_problem *pb);
+int mm_ba_trf(mm_ctx *ctx, const mm_ba_problem *pb, double *cams /*dev, in/out*/, double *pts /*dev, in/out*/,
+              const mm_trf_params *prm, mm_trf_report *report /*host*/, mm_trf_row *log /*host|NULL*/, int log_cap,
+              void *ws /*dev, 256-byte aligned*/, size_t ws_bytes);
 /* SPD solve A x = b by blocked Cholesky (f64 MFMA trailing updates).  A [n,n] row-major, lower triangle is
  * overwritten by L; b [nrhs,n] is overwritten by x.  half_bandwidth: A[i][j] == 0 whenever i - j > half_bandwidth
  * (pass n for a dense matrix); the factorisation and the substitutions skip blocks outside the band.

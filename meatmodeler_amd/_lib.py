@@ -36,6 +36,22 @@ class BAProblem(C.Structure):
                 ("chunk_end", vp), ("pair_o", vp), ("pair_o2", vp), ("pair_p", vp)]
 
 
+class TrfParams(C.Structure):
+    _fields_ = [("ftol", C.c_double), ("xtol", C.c_double), ("gtol", C.c_double), ("min_damping", C.c_double),
+                ("max_nfev", C.c_int64)]
+
+
+class TrfRow(C.Structure):
+    _fields_ = [("iteration", C.c_int32), ("nfev", C.c_int32), ("cost", C.c_double), ("reduction", C.c_double),
+                ("step_norm", C.c_double), ("optimality", C.c_double)]
+
+
+class TrfReport(C.Structure):
+    _fields_ = [("cost0", C.c_double), ("cost", C.c_double), ("optimality", C.c_double), ("min_damping", C.c_double),
+                ("nfev", C.c_int32), ("njev", C.c_int32), ("status", C.c_int32), ("iterations", C.c_int32),
+                ("log_rows", C.c_int32), ("reserved", C.c_int32)]
+
+
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header.
 SIGNATURES = {
     "mm_abi_version": (C.c_int, []),
@@ -101,6 +117,9 @@ SIGNATURES = {
     "mm_bgr_to_grey": (C.c_int, [vp, vp, C.c_size_t, vp]),
     "mm_write_ply": (C.c_int, [C.c_char_p, vp, C.c_int64]),
     "mm_chol_solve_sym": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, C.c_size_t]),
+    "mm_ba_trf_workspace_bytes": (C.c_size_t, [C.POINTER(BAProblem)]),
+    "mm_ba_trf": (C.c_int, [vp, C.POINTER(BAProblem), vp, vp, C.POINTER(TrfParams), C.POINTER(TrfReport),
+                            C.POINTER(TrfRow), C.c_int, vp, C.c_size_t]),
 }
 
 

@@ -16,6 +16,7 @@ Jacobian; see DESIGN.md §BA for what "parity" means on this gauge-free problem.
 Host Python only sequences launches and does the 2x2 / scalar algebra of the trust region; torch is used for
 device buffers and a handful of axpy / dot reductions on the parameter vector.
 """
+import os
 import time
 import warnings
 
@@ -223,11 +224,14 @@ class SchurTRF:
     so every axpy / dot of the iteration is a single launch, and the host reads device scalars three times per
     iteration (before the damping is known, after the step basis is built, after each trial step)."""
 
-    def __init__(self, pb, allreduce=None, timers=None, min_damping=1e-9):
+    def __init__(self, pb, allreduce=None, timers=None, min_damping=1e-9, driver=None):
         self.pb = pb
         self.allreduce = allreduce
         self.timers = timers
         self.min_damping = min_damping
+        # "library": the loop itself runs inside the C-ABI library (mm_ba_trf; one GPU only); "python": sequenced from
+        # here (what the sharded path and the CPU stand-in of the tests use).  Same kernels, bit-identical iterates.
+        self.driver = driver or os.environ.get("MM_TRF_DRIVER", "library")
         self._overlap_checked = False
 
     # -- reductions that need the cross-rank sum when sharded --
@@ -333,6 +337,9 @@ class SchurTRF:
             self._Bd, self._Cd = torch.empty((F, 6, 6), **f64), torch.empty((P, 6), **f64)
             self._si = torch.empty(n, **f64)
 
+        if (self.driver == "library" and self.allreduce is None and hasattr(pb, "trf_solve")
+                and not getattr(pb, "overlap", False)):
+            return self._solve_library(x, ftol, xtol, gtol, max_nfev, verbose)
         c2 = self._cost_dev(x)
         cost = 0.5 * float(c2.item())
         if not np.isfinite(cost):
@@ -527,6 +534,29 @@ class SchurTRF:
         return BAResult(cams=self._cams(x).clone(), pts=self._pts(x).clone(), cost=cost, optimality=g_norm, nfev=nfev,
                         njev=njev, status=termination, message=_MESSAGES[termination], success=termination > 0,
                         iterations=iteration, host_segments_ms={k: 1e3 * v for k, v in seg.items()})
+
+
+def _solve_library(self, x, ftol, xtol, gtol, max_nfev, verbose):
+    """One GPU: the whole loop of `_solve_device` inside the library (mm_ba_trf, csrc/trf.hip)."""
+    nc = self.nc
+    cams, pts = x[:nc], x[nc:]
+    t0 = time.perf_counter()
+    rep, rows = self.pb.trf_solve(cams, pts, ftol, xtol, gtol, max_nfev, self.min_damping,
+                                  log_cap=4096 if verbose == 2 else 0)
+    self.min_damping = rep.min_damping
+    if verbose == 2:
+        _print_header()
+        for it, nf, c, red, stp, opt in rows:
+            _print_iteration(it, nf, c, None if np.isnan(red) else red, None if np.isnan(stp) else stp, opt)
+        if rep.log_rows > len(rows):
+            print(f"... ({rep.log_rows - len(rows)} more iterations)")
+    return BAResult(cams=self._cams(x).clone(), pts=self._pts(x).clone(), cost=rep.cost, optimality=rep.optimality,
+                    nfev=rep.nfev, njev=rep.njev, status=rep.status, message=_MESSAGES[rep.status],
+                    success=rep.status > 0, iterations=rep.iterations,
+                    host_segments_ms={"library": 1e3 * (time.perf_counter() - t0)})
+
+
+SchurTRF._solve_library = _solve_library
 
 
 def _solve_device(self, x, g, cost, half_bw, band_exchange, ftol, xtol, gtol, max_nfev, verbose):

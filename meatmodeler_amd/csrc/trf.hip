@@ -1,0 +1,297 @@
+// The whole trust-region solve of adjustPoints behind ONE call (single GPU): mm_ba_trf.
+//
+// Replaces the loop scipy.optimize.least_squares runs for bundleAdjuster.adjustPoints (reference
+// bundleAdjuster.py:180-192: method='trf', jac_sparsity, x_scale='jac', linear loss -> scipy/optimize/_lsq/trf.py
+// trf_no_bounds).  The iteration is the one meatmodeler_amd/bundleAdjuster.py::_solve_device sequences from Python --
+// same kernels, same order, same scalars, bit-identical iterates -- driven from C++: the host side of an iteration
+// shrinks from ~0.45 ms of interpreter time to a few microseconds, which is what bounds the small systems of the
+// sliding-window adjustment (300 unknowns per window: 0.39 ms per evaluation from Python, launch-bound here), and the
+// library itself now owns the loop SURVEY.md section 8(b) calls mm_ba_lm.  One host synchronisation per trial step (a
+// 16-double board copied to the host after the trial cost is known).  Everything lives in the caller's workspace; no
+// allocation, no second stream unless the overlapped build is requested.
+#include "mm_common.h"
+#include <cmath>
+
+namespace {
+
+__global__ __launch_bounds__(256) void vec_mul_kernel(const double *__restrict__ a, const double *__restrict__ b,
+                                                      double *__restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = a[i] * b[i];
+}
+
+struct Carve {
+    char *p;
+    size_t used = 0;
+    explicit Carve(void *base) : p((char *)base) {}
+    template <class T>
+    T *take(size_t count) {
+        T *r = p ? (T *)(p + used) : nullptr;
+        used += mm_align_up(count * sizeof(T), 256);
+        return r;
+    }
+};
+
+struct TrfWs {
+    double *x, *x_new, *g, *si, *gh, *ghs, *gn, *q1, *w, *q2, *s1, *s2;
+    double *B, *Bd, *C, *Cd, *Cinv, *u1, *Jq2, *dp, *v, *S;
+    double *r0, *r1, *r2, *r3, *d11, *bs, *damp, *board, *cost2, *rowsx;
+    int32_t *info;
+    void *ws_res, *ws_md, *ws_jvp, *ws_schur, *ws_chol;
+    size_t ws_res_b, ws_md_b, ws_jvp_b, ws_schur_b, ws_chol_b;
+    size_t total;
+};
+
+TrfWs carve_trf(const mm_ba_problem *pb, void *base) {
+    TrfWs t;
+    Carve c(base);
+    const size_t F = pb->F, P = pb->P, O = (size_t)pb->O, n = 6 * F + 3 * P, nc = 6 * F;
+    double **vecs[12] = {&t.x, &t.x_new, &t.g, &t.si, &t.gh, &t.ghs, &t.gn, &t.q1, &t.w, &t.q2, &t.s1, &t.s2};
+    for (auto v : vecs) *v = c.take<double>(n + 2);
+    t.B = c.take<double>(F * 36);
+    t.Bd = c.take<double>(F * 36);
+    t.C = c.take<double>(P * 6 + 2);
+    t.Cd = c.take<double>(P * 6 + 2);
+    t.Cinv = c.take<double>(P * 6 + 2);
+    t.u1 = c.take<double>(O * 2 + 2);
+    t.Jq2 = c.take<double>(O * 2 + 2);
+    t.dp = c.take<double>(P * 3 + 2);
+    t.v = c.take<double>(nc + 2);
+    t.S = c.take<double>(2 * nc * nc + 2);   // (+ the zero padding the band view of the sharded path expects)
+    t.r0 = c.take<double>(6);
+    t.r1 = c.take<double>(9);
+    t.r2 = c.take<double>(6);
+    t.r3 = c.take<double>(18);
+    t.d11 = c.take<double>(6);
+    t.bs = c.take<double>(6);
+    t.damp = c.take<double>(2);
+    t.board = c.take<double>(16);
+    t.cost2 = c.take<double>(1);
+    t.rowsx = c.take<double>(3);
+    t.info = c.take<int32_t>(1);
+    t.ws_res_b = 2048 * 8;
+    t.ws_res = c.take<char>(t.ws_res_b);
+    t.ws_md_b = mm_multi_dot_workspace_bytes();
+    t.ws_md = c.take<char>(t.ws_md_b);
+    t.ws_jvp_b = mm_ba_jvp_dots_workspace_bytes(pb);
+    t.ws_jvp = c.take<char>(t.ws_jvp_b);
+    t.ws_schur_b = mm_ba_schur_workspace_bytes(pb);
+    if (t.ws_schur_b < 256) t.ws_schur_b = 256;
+    t.ws_schur = c.take<char>(t.ws_schur_b);
+    t.ws_chol_b = mm_chol_workspace_bytes((int)nc);
+    t.ws_chol = c.take<char>(t.ws_chol_b);
+    t.total = c.used;
+    return t;
+}
+
+// SciPy's update_tr_radius / check_termination (scipy/optimize/_lsq/common.py:222-245, 705-717)
+void update_tr_radius(double &Delta, double actual, double predicted, double step_norm, bool bound_hit, double &ratio) {
+    if (predicted > 0)
+        ratio = actual / predicted;
+    else if (predicted == 0 && actual == 0)
+        ratio = 1;
+    else
+        ratio = 0;
+    if (ratio < 0.25)
+        Delta = 0.25 * step_norm;
+    else if (ratio > 0.75 && bound_hit)
+        Delta *= 2.0;
+}
+int check_termination(double dF, double F, double dx_norm, double x_norm, double ratio, double ftol, double xtol) {
+    const bool ftol_ok = dF < ftol * F && ratio > 0.25;
+    const bool xtol_ok = dx_norm < xtol * (xtol + x_norm);
+    if (ftol_ok && xtol_ok) return 4;
+    if (ftol_ok) return 2;
+    if (xtol_ok) return 3;
+    return -100;  // (None)
+}
+
+}  // namespace
+
+extern "C" size_t mm_ba_trf_workspace_bytes(const mm_ba_problem *pb) {
+    if (!pb || pb->F < 0 || pb->P < 0 || pb->O < 0) return 0;
+    return carve_trf(pb, nullptr).total;
+}
+
+#define TRF_CALL(expr)        \
+    do {                      \
+        int rc_ = (expr);     \
+        if (rc_) return rc_;  \
+    } while (0)
+
+extern "C" int mm_ba_trf(mm_ctx *ctx, const mm_ba_problem *pb, double *cams, double *pts, const mm_trf_params *prm,
+                         mm_trf_report *rep, mm_trf_row *log, int log_cap, void *ws, size_t ws_bytes) {
+    if (!ctx) return MM_ERR_ARG;
+    if (!pb || !cams || !pts || !prm || !rep || pb->F <= 0 || pb->P < 0 || pb->O < 0 || !pb->K || log_cap < 0 || (log_cap > 0 && !log))
+        return mm_fail(ctx, MM_ERR_ARG, "mm_ba_trf: bad argument");
+    if (!ws || ws_bytes < mm_ba_trf_workspace_bytes(pb) || ((uintptr_t)ws & 255))
+        return mm_fail(ctx, MM_ERR_WORKSPACE, "mm_ba_trf: workspace too small or misaligned");
+    const TrfWs t = carve_trf(pb, ws);
+    const int F = pb->F, P = pb->P;
+    const int64_t nc = 6 * (int64_t)F, n = nc + 3 * (int64_t)P;
+    hipStream_t st = ctx->stream;
+    auto cams_of = [&](double *v) { return v; };
+    auto pts_of = [&](double *v) { return v + nc; };
+    // the reduction workspaces count arrivals: zero once
+    MM_HIP(ctx, hipMemsetAsync(t.ws_md, 0, t.ws_md_b, st));
+    MM_HIP(ctx, hipMemsetAsync(t.ws_jvp, 0, t.ws_jvp_b, st));
+    MM_HIP(ctx, hipMemsetAsync(t.S, 0, (size_t)(2 * nc * nc) * sizeof(double), st));
+    double *x = t.x, *x_new = t.x_new;
+    MM_HIP(ctx, hipMemcpyAsync(x, cams, (size_t)nc * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (P) MM_HIP(ctx, hipMemcpyAsync(x + nc, pts, (size_t)3 * P * sizeof(double), hipMemcpyDeviceToDevice, st));
+    double host[16];
+    auto read_board = [&](const double *dev, int count) -> int {
+        MM_HIP(ctx, hipMemcpyAsync(host, dev, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, st));
+        MM_HIP(ctx, hipStreamSynchronize(st));
+        return MM_OK;
+    };
+    // initial cost
+    TRF_CALL(mm_ba_residual(ctx, pb, cams_of(x), pts_of(x), nullptr, t.cost2, t.ws_res, t.ws_res_b));
+    TRF_CALL(read_board(t.cost2, 1));
+    double cost = 0.5 * host[0];
+    rep->cost0 = cost;
+    if (!std::isfinite(cost)) {
+        rep->status = -2;
+        return mm_fail(ctx, MM_ERR_NUMERIC, "mm_ba_trf: residuals are not finite in the initial point");
+    }
+    const int half_bw = 6 * pb->cam_span + 5;
+    int nfev = 1, njev = 1;
+    TRF_CALL(mm_ba_normal_eq(ctx, pb, cams_of(x), pts_of(x), t.B, cams_of(t.g), t.C, pts_of(t.g)));
+    TRF_CALL(mm_ba_scale_update(ctx, F, P, t.B, t.C, t.si, 1));
+    {   // Delta0 = |x * scale_inv|  (trf.py:428)
+        hipLaunchKernelGGL(vec_mul_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double *)x, (const double *)t.si, t.w, n);
+        const double *pa[1] = {t.w}, *pbv[1] = {t.w};
+        TRF_CALL(mm_multi_dot(ctx, 1, pa, pbv, n, nc, t.rowsx, t.ws_md, t.ws_md_b));
+        TRF_CALL(read_board(t.rowsx, 3));
+    }
+    double Delta = std::sqrt(host[2]);
+    if (Delta == 0) Delta = 1.0;
+    const long max_nfev = prm->max_nfev > 0 ? prm->max_nfev : (long)n * 100;
+    double min_damping = prm->min_damping > 0 ? prm->min_damping : 1e-9;
+    double alpha = 0.0;
+    (void)alpha;
+    int termination = -100, iteration = 0, n_log = 0;
+    double step_norm = NAN, actual = NAN, g_norm = NAN;
+    auto log_row = [&](int it, int nf, double c, double red, double stepn, double opt) {
+        if (n_log < log_cap) log[n_log] = mm_trf_row{it, nf, c, red, stepn, opt};
+        ++n_log;
+    };
+    for (;;) {
+        {
+            const double *in[2] = {t.g, t.si};
+            double *outv[2] = {t.gh, t.ghs};
+            TRF_CALL(mm_trf_fused(ctx, 0, in, outv, nullptr, 0, 0, n, nc, t.r0, t.ws_md, t.ws_md_b));
+        }
+        TRF_CALL(mm_ba_jvp_dots(ctx, pb, cams_of(x), pts_of(x), cams_of(t.ghs), pts_of(t.ghs), t.u1, nullptr, t.d11, t.ws_jvp, t.ws_jvp_b));
+        if (termination != -100 || nfev == max_nfev) {
+            TRF_CALL(read_board(t.r0, 6));
+            g_norm = host[5];
+            log_row(iteration, nfev, cost, actual, step_norm, g_norm);
+            break;
+        }
+        TRF_CALL(mm_trf_damping(ctx, t.r0 + 2, t.d11 + 2, Delta, min_damping, t.damp));
+        double *reg_eff = t.damp + 1;
+        bool solved = false;
+        auto trial = [&](double Delta_) -> int {
+            TRF_CALL(mm_trf_step2d(ctx, t.r0, t.d11, t.r1, t.r2, t.r3, t.bs, reg_eff, t.info, Delta_, t.board));
+            const double *in[3] = {x, t.s1, t.s2};
+            double *outv[1] = {x_new};
+            const double *sc[1] = {t.board};
+            TRF_CALL(mm_trf_fused(ctx, 5, in, outv, sc, 0, 0, n, nc, nullptr, t.ws_md, t.ws_md_b));
+            TRF_CALL(mm_ba_residual(ctx, pb, cams_of(x_new), pts_of(x_new), nullptr, t.board + 14, t.ws_res, t.ws_res_b));
+            return read_board(t.board, 16);   // ---- the host sync of a trial step ----
+        };
+        for (int attempt = 0; attempt < 6 && !solved; ++attempt) {
+            TRF_CALL(mm_ba_damp(ctx, F, P, t.B, t.C, t.si, reg_eff, t.Bd, t.Cd));
+            TRF_CALL(mm_ba_schur_solve(ctx, pb, cams_of(x), pts_of(x), t.Bd, t.Cd, cams_of(t.g), pts_of(t.g), t.S, t.v, t.Cinv, half_bw,
+                                       t.info, t.ws_schur, t.ws_schur_b, t.ws_chol, t.ws_chol_b, 0, 0, nullptr, nullptr));
+            TRF_CALL(mm_ba_backsub(ctx, pb, cams_of(x), pts_of(x), t.Cinv, pts_of(t.g), t.v, t.dp));
+            {
+                const double *in[4] = {t.v, t.dp, t.si, t.gh};
+                double *outv[2] = {t.gn, t.q1};
+                const double *sc[1] = {t.r0 + 2};
+                TRF_CALL(mm_trf_fused(ctx, 1, in, outv, sc, 0, 0, n, nc, t.r1, t.ws_md, t.ws_md_b));
+            }
+            {
+                const double *in[2] = {t.gn, t.q1};
+                double *outv[1] = {t.w};
+                const double *sc[1] = {t.r1 + 2};
+                TRF_CALL(mm_trf_fused(ctx, 2, in, outv, sc, 0, 0, n, nc, t.r2, t.ws_md, t.ws_md_b));
+            }
+            {
+                const double *in[5] = {t.w, t.q1, t.si, t.gh, x};
+                double *outv[3] = {t.q2, t.s1, t.s2};
+                const double *sc[1] = {t.r2 + 2};
+                TRF_CALL(mm_trf_fused(ctx, 3, in, outv, sc, 0, 0, n, nc, t.r3, t.ws_md, t.ws_md_b));
+            }
+            TRF_CALL(mm_ba_jvp_dots(ctx, pb, cams_of(x), pts_of(x), cams_of(t.s2), pts_of(t.s2), t.Jq2, t.u1, t.bs, t.ws_jvp, t.ws_jvp_b));
+            TRF_CALL(trial(Delta));   // enqueued before the host knows whether the factorisation succeeded
+            const int inf = (int)host[6];
+            if (inf == 0) {
+                solved = true;
+                break;
+            }
+            if (inf < 0) return mm_fail(ctx, MM_ERR_HIP, "mm_ba_trf: the fused banded factorisation was abandoned (info = -1)");
+            if (host[13] <= min_damping * (1.0 + 1e-12)) min_damping *= 100.0;   // failed AT the floor: the floor was too low
+            // reg_eff *= 100 on the device: damp[1] is a plain double
+            double r100 = host[13] * 100.0;
+            MM_HIP(ctx, hipMemcpyAsync(t.damp + 1, &r100, sizeof(double), hipMemcpyHostToDevice, st));
+            MM_HIP(ctx, hipStreamSynchronize(st));
+        }
+        if (!solved) return mm_fail(ctx, MM_ERR_NUMERIC, "mm_ba_trf: reduced camera system is not positive definite (pivot %d)", (int)host[6]);
+        g_norm = host[10];
+        const double xx = host[9];
+        if (g_norm < prm->gtol) termination = 1;   // (checked before the step is used, as trf.py:443 does)
+        log_row(iteration, nfev, cost, actual, step_norm, g_norm);
+        if (termination != -100) break;
+        const double x_norm = std::sqrt(xx);
+        actual = -1.0;
+        bool have = true;
+        double cost_new = cost;
+        while (actual <= 0 && nfev < max_nfev) {
+            if (!have) TRF_CALL(trial(Delta));
+            have = false;
+            const double predicted = host[2], step_h_norm = host[3], step_norm_dev = host[4];
+            cost_new = 0.5 * host[14];
+            ++nfev;
+            if (!std::isfinite(cost_new)) {
+                Delta = 0.25 * step_h_norm;
+                continue;
+            }
+            actual = cost - cost_new;
+            double Delta_new = Delta, ratio;
+            update_tr_radius(Delta_new, actual, predicted, step_h_norm, step_h_norm > 0.95 * Delta, ratio);
+            step_norm = step_norm_dev;
+            termination = check_termination(actual, cost, step_norm, x_norm, ratio, prm->ftol, prm->xtol);
+            if (termination != -100) break;
+            alpha *= Delta / Delta_new;
+            Delta = Delta_new;
+        }
+        if (actual > 0) {
+            double *tmp = x;
+            x = x_new;
+            x_new = tmp;
+            cost = cost_new;
+            TRF_CALL(mm_ba_normal_eq(ctx, pb, cams_of(x), pts_of(x), t.B, cams_of(t.g), t.C, pts_of(t.g)));
+            ++njev;
+            TRF_CALL(mm_ba_scale_update(ctx, F, P, t.B, t.C, t.si, 0));
+        } else {
+            step_norm = 0;
+            actual = 0;
+        }
+        ++iteration;
+    }
+    if (termination == -100) termination = 0;
+    MM_HIP(ctx, hipMemcpyAsync(cams, x, (size_t)nc * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (P) MM_HIP(ctx, hipMemcpyAsync(pts, x + nc, (size_t)3 * P * sizeof(double), hipMemcpyDeviceToDevice, st));
+    MM_HIP(ctx, hipStreamSynchronize(st));
+    rep->cost = cost;
+    rep->optimality = g_norm;
+    rep->nfev = nfev;
+    rep->njev = njev;
+    rep->status = termination;
+    rep->iterations = iteration;
+    rep->log_rows = n_log;
+    rep->min_damping = min_damping;
+    return MM_OK;
+}

@@ -468,6 +468,27 @@ class BADevice:
         """Solution only (S destroyed): lets a narrow band be eliminated from both ends (see ops.chol_solve_sym)."""
         return chol_solve_sym(S, v, self.ctx, half_bandwidth, both_triangles)
 
+    def trf_solve(self, cams, pts, ftol, xtol, gtol, max_nfev=None, min_damping=1e-9, log_cap=0):
+        """The whole trust-region solve in one library call (mm_ba_trf; one GPU).  cams [F,6] / pts [P,3] are updated in
+        place.  -> (report, rows) with rows = the (iteration, nfev, cost, reduction, step_norm, optimality) lines of
+        SciPy's verbose=2 table (the first `log_cap` of them)."""
+        for t in (cams, pts):
+            assert t.dtype == torch.float64 and t.is_contiguous() and t.device == self.device
+        if getattr(self, "_trf_ws", None) is None:
+            self._trf_ws = torch.empty(lib.mm_ba_trf_workspace_bytes(C.byref(self.pb)), dtype=torch.uint8,
+                                       device=self.device)
+        prm = _lib.TrfParams(ftol, xtol, gtol, min_damping, int(max_nfev) if max_nfev else 0)
+        rep = _lib.TrfReport()
+        log = (_lib.TrfRow * max(log_cap, 1))()
+        rc = lib.mm_ba_trf(self.ctx.h, C.byref(self.pb), ptr(cams), ptr(pts), C.byref(prm), C.byref(rep), log,
+                           int(log_cap), ptr(self._trf_ws), self._trf_ws.numel())
+        if rc and rep.status == -2:
+            raise ValueError("Residuals are not finite in the initial point.")      # (as scipy's least_squares does)
+        self.ctx.check(rc, "mm_ba_trf")
+        rows = [(r.iteration, r.nfev, r.cost, r.reduction, r.step_norm, r.optimality)
+                for r in log[:min(rep.log_rows, log_cap)]]
+        return rep, rows
+
     def backsub(self, cams, pts, Cinv, gp, dc):
         dp = torch.empty((self.P, 3), dtype=torch.float64, device=self.device)
         self.ctx.check(lib.mm_ba_backsub(self.ctx.h, C.byref(self.pb), ptr(cams), ptr(pts), ptr(Cinv), ptr(gp), ptr(dc),

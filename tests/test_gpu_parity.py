@@ -796,6 +796,38 @@ def test_adjust_points_on_real_matches_vs_scipy_recipe(golden_dir):
     assert res2.nfev == res.nfev and res2.cost == res.cost          # bitwise reproducible
 
 
+@pytest.mark.parametrize("case", ["a", "c", "d", "real", "tiny"])
+def test_library_trf_driver_equals_python_driver_bitwise(golden_dir, case, monkeypatch):
+    """mm_ba_trf (the loop inside the library, csrc/trf.hip) and the Python-sequenced loop issue the same kernels with
+    the same scalars: identical nfev / status / cost / x to the last bit, and the same verbose=2 table."""
+    if case == "real":
+        d = np.load(os.path.join(golden_dir, "o1_real_match_ba.npz"))
+        pr = {k: d[k] for k in ("ext", "K", "pts0", "obs", "fi", "pi")}
+        kw = {}
+    elif case == "tiny":
+        pr = synth.make_ba_problem(3, 12, 3, seed=4)        # smaller than one Cholesky block
+        kw = dict(ftol=1e-10, xtol=1e-10, gtol=1e-10, max_nfev=7)      # ... stopped by max_nfev
+    else:
+        d = np.load(os.path.join(golden_dir, f"g5_adjust_points_{case}.npz"))
+        pr = synth.make_ba_problem(*(int(d[k]) for k in ("F", "P", "L")), seed=int(d["seed"]))
+        kw = dict(ftol=1e-12, xtol=1e-12, gtol=1e-12, max_nfev=60) if case == "c" else {}
+    out = {}
+    for drv in ("python", "library"):
+        monkeypatch.setenv("MM_TRF_DRIVER", drv)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            res = bundleAdjuster.solvePoints(pr["ext"], pr["K"], pr["pts0"], pr["obs"], pr["fi"], pr["pi"], verbose=2, **kw)
+        out[drv] = (res, buf.getvalue())
+        assert ("library" in res.host_segments_ms) == (drv == "library")
+    a, b = out["python"][0], out["library"][0]
+    assert (a.nfev, a.njev, a.status, a.iterations) == (b.nfev, b.njev, b.status, b.iterations)
+    assert a.cost == b.cost and a.optimality == b.optimality
+    assert np.array_equal(a.x, b.x)
+    assert out["python"][1] == out["library"][1]
+    if case == "tiny":
+        assert a.status == 0 and a.nfev == 7
+
+
 def test_adjust_points_raises_on_non_finite():
     pr = synth.make_ba_problem(4, 10, 3, seed=1)
     pts = pr["pts0"].copy()
