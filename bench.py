@@ -52,8 +52,10 @@ def parse():
                     help="sliding-window BA instead of the global one (SURVEY 8(f)-2): keyframes per window (1 GPU only)")
     ap.add_argument("--ba-stride", type=int, default=0, help="keyframes between windows (default: window / 2)")
     ap.add_argument("--ba-order", default=None, choices=("sequential", "wavefront"),
-                    help="window schedule (default: sequential on one GPU, wavefront -- independent windows spread over the "
-                         "ranks -- on several)")
+                    help="window schedule (default: wavefront -- the independent windows of a pass spread over the ranks and "
+                         "over --ba-streams streams per GPU; sequential = every window starts from its predecessor's result)")
+    ap.add_argument("--ba-streams", type=int, default=8,
+                    help="wavefront schedule: windows in flight per GPU (one HIP stream + host thread each)")
     ap.add_argument("--verbose", type=int, default=0)
     ap.add_argument("--no-profile", action="store_true", help="no per-launch HIP events in the timed steps")
     return ap.parse_args()
@@ -164,7 +166,8 @@ def main():
             o = pipe.run(frames, K, ext, ba=False, dist=d, timers=timers)
             o["windows"] = pipe.adjust_windows(o, K, ext, window=a.ba_window, stride=a.ba_stride or max(1, a.ba_window // 2),
                                                ftol=1e-4, timers=timers, dist=d,
-                                               order=a.ba_order or ("wavefront" if use_dist else "sequential"))["windows"]
+                                               order=a.ba_order or "wavefront",
+                                               streams=a.ba_streams)["windows"]
             return o
         return pipe.run(frames, K, ext, ba=not a.no_ba, ftol=1e-4, verbose=a.verbose, dist=d, timers=timers)
 
@@ -338,7 +341,7 @@ def main():
                         "schur_pairs": out.get("n_pairs"), "render_s": t_render},
             "sliding_window_ba": None if "windows" not in out else {
                 "window": a.ba_window, "stride": a.ba_stride or max(1, a.ba_window // 2), "windows": len(out["windows"]),
-                "order": a.ba_order or ("wavefront" if use_dist else "sequential"),
+                "order": a.ba_order or "wavefront", "streams": a.ba_streams,
                 "ms": stage_ms["ba_windows"], "nfev_total": int(sum(w["nfev"] for w in out["windows"])),
                 "observations_total": int(sum(w["observations"] for w in out["windows"])),
                 "residual_evals_per_s": sum(w["observations"] * w["nfev"] for w in out["windows"]) /

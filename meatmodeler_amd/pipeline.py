@@ -7,12 +7,14 @@ Keyframe gating, calibration and PnP are outside the scope: the 
 per frame (the reference gets them from calibrate / poseEstimation / adjustPose, processor.py:422-448).
 """
 import ctypes as C
+import queue
 import time
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 import torch
 
-from . import ops, parallel
+from . import _lib, ops, parallel
 from ._lib import lib, default_context, c_i32p, c_i64p, c_f32p, MMError
 from .bundleAdjuster import SchurTRF, frameParameters
 from .orb_pattern import brief_pattern
@@ -132,7 +134,7 @@ class ClipPipeline:
         return inside & (last_frame <= hi - 2)
 
     def adjust_windows(self, out, K, extrinsics, window=50, stride=25, ftol=1e-4, verbose=0, timers=None, dist=None,
-                       order="sequential"):
+                       order="sequential", streams=1):
         """Incremental bundle adjustment over a sliding window of keyframes: the reference keeps this step as a
         commented hook (processor.py:395-408: after a keyframe whose tracks were popped, `managePoints(popped_tracks)`
         + `adjustPoints` over everything so far); bounding it to the last `window` keyframes is what makes the
@@ -153,6 +155,8 @@ class ClipPipeline:
         scales with the number of GPUs instead of paying a collective per trust-region iteration of a 300-unknown
         system, and the result does not depend on the world size at all (bit for bit: every window is solved by the
         same un-sharded code on the same inputs).  It is a different -- equally valid -- schedule than "sequential".
+        streams > 1 (wavefront only): that many windows of a pass are in flight on this GPU at once, one HIP stream and
+        one host thread each; the result does not depend on it either.
 
         `out` is the result of `run(..., ba=False)`.  -> dict(cams [F,6] device, points [T,3] device, windows=[...])."""
         d = self.device
@@ -163,7 +167,7 @@ class ClipPipeline:
             raise ValueError("order must be 'sequential' or 'wavefront'")
         if order == "wavefront":
             return self._adjust_windows_wavefront(out, K, extrinsics, window, stride, ftol, verbose, timers, allreduce,
-                                                  world, rank)
+                                                  world, rank, streams)
         F = int(np.asarray(extrinsics).shape[0])
         tp, of_, ok = out["track_ptr_dev"], out["obs_frame_dev"], out["obs_kp_dev"]
         xy = out["xy_dev"]
@@ -245,7 +249,8 @@ class ClipPipeline:
         coords = xy[of_[oi].long(), ok[oi].long()].to(torch.float64)
         return sel, fi, pi, coords, P, O
 
-    def _adjust_windows_wavefront(self, out, K, extrinsics, window, stride, ftol, verbose, timers, allreduce, world, rank):
+    def _adjust_windows_wavefront(self, out, K, extrinsics, window, stride, ftol, verbose, timers, allreduce, world, rank,
+                                  streams=1):
         d = self.device
         F = int(np.asarray(extrinsics).shape[0])
         tp, of_ = out["track_ptr_dev"], out["obs_frame_dev"]
@@ -272,26 +277,54 @@ class ClipPipeline:
             colours.append(c)
         t0 = time.perf_counter()
         table = torch.zeros((len(wins), 5), dtype=torch.float64, device=d)      # points, observations, nfev, status, cost
+        # Windows of a pass are independent AND small (a 300-unknown reduced system keeps 16 workgroups busy): this rank
+        # solves up to `streams` of them at once, each on its own HIP stream with its own library context, driven by its
+        # own host thread (mm_ba_trf blocks in C with the GIL released).  Every window still runs the same code on the
+        # same inputs, so the result does not depend on `streams`.
+        n_streams = max(1, int(streams))
+        slots = queue.SimpleQueue()
+        if n_streams > 1:
+            for _ in range(n_streams):
+                st = torch.cuda.Stream(device=d)
+                slots.put((st, _lib.Context(d, st)))
+
+        def solve_window(k, ctx, cams, pts, cams_upd, cam_mask, pts_upd, pt_mask):
+            lo, hi = wins[k]
+            sel, fi, pi, coords, P, O = self._window_problem(out, first_f, last_f, lens_all, tp64, lo, hi, F)
+            if P == 0:
+                return
+            pb = ops.BADevice(K, fi, pi, coords, hi - lo, P, d, ctx)
+            res = SchurTRF(pb).solve(cams[lo:hi].contiguous(), pts[sel].contiguous(), ftol=ftol,
+                                     verbose=verbose if rank == 0 and n_streams == 1 else 0)
+            cams_upd[lo:hi] = res.cams
+            cam_mask[lo:hi] = 1.0
+            pts_upd[sel] = res.pts
+            pt_mask[sel] = 1.0
+            table[k] = torch.tensor([P, O, res.nfev, res.status, res.cost], dtype=torch.float64, device=d)
+
+        def solve_window_on_slot(k, *state):
+            slot = slots.get()
+            try:
+                with torch.cuda.stream(slot[0]):
+                    solve_window(k, slot[1], *state)
+                    slot[0].synchronize()       # results are in place before the pass's thread pool is joined
+            finally:
+                slots.put(slot)
+
         for c in range(len(colour_end)):
-            mine = [k for k, cc in enumerate(colours) if cc == c]
+            mine = [k for j, k in enumerate(k for k, cc in enumerate(colours) if cc == c) if j % world == rank]
             cams_upd, pts_upd = torch.zeros_like(cams), torch.zeros_like(pts)
             cam_mask = torch.zeros(F, dtype=torch.float64, device=d)
             pt_mask = torch.zeros(T, dtype=torch.float64, device=d)
-            for j, k in enumerate(mine):
-                if j % world != rank:
-                    continue
-                lo, hi = wins[k]
-                sel, fi, pi, coords, P, O = self._window_problem(out, first_f, last_f, lens_all, tp64, lo, hi, F)
-                if P == 0:
-                    continue
-                pb = ops.BADevice(K, fi, pi, coords, hi - lo, P, d, self.ctx)
-                res = SchurTRF(pb).solve(cams[lo:hi].contiguous(), pts[sel].contiguous(), ftol=ftol,
-                                         verbose=verbose if rank == 0 else 0)
-                cams_upd[lo:hi] = res.cams
-                cam_mask[lo:hi] = 1.0
-                pts_upd[sel] = res.pts
-                pt_mask[sel] = 1.0
-                table[k] = torch.tensor([P, O, res.nfev, res.status, res.cost], dtype=torch.float64, device=d)
+            state = (cams, pts, cams_upd, cam_mask, pts_upd, pt_mask)
+            if n_streams > 1 and len(mine) > 1:
+                torch.cuda.current_stream(d).synchronize()        # the pass's inputs are complete
+                with ThreadPoolExecutor(max_workers=n_streams) as pool:
+                    for f_ in [pool.submit(solve_window_on_slot, k, *state) for k in mine]:
+                        f_.result()
+            else:
+                for k in mine:
+                    solve_window(k, self.ctx, *state)
             if allreduce is not None:          # the windows of a pass touch disjoint cameras / points: the sums are copies
                 for t_ in (cams_upd, cam_mask, pts_upd, pt_mask):
                     allreduce(t_)

@@ -1118,6 +1118,21 @@ def test_sliding_window_ba_equals_window_by_window_adjustment():
     assert np.array_equal(res["points"].cpu().numpy(), pts) and np.array_equal(res["cams"].cpu().numpy(), cams)
 
 
+def test_wavefront_windows_in_flight_on_several_streams_equal_one_at_a_time():
+    """order="wavefront": the windows of a pass share no camera and no point; solving four of them at once (one HIP
+    stream, one library context and one host thread each) gives the result of solving them one after the other, bit for
+    bit, and the same per-window nfev / cost."""
+    F, W, S = 16, 4, 2
+    frames, ext, K = synth.render_orbit_frames(F, 640, 480, arc_deg=16.0)
+    pipe = ClipPipeline(480, 640, 600, batch=F)
+    out = pipe.run(dev(frames), K, ext, ba=False)
+    one = pipe.adjust_windows(out, K, ext, window=W, stride=S, order="wavefront")
+    four = pipe.adjust_windows(out, K, ext, window=W, stride=S, order="wavefront", streams=4)
+    assert len(one["windows"]) >= 6 and max(w["colour"] for w in one["windows"]) == 1
+    assert one["windows"] == four["windows"]
+    assert torch.equal(one["cams"], four["cams"]) and torch.equal(one["points"], four["points"])
+
+
 def test_clip_pipeline_c2_shape_match_and_triangulate():
     """BASELINE config "1080p, 2000 key points, BF match + 2-view triangulation" on a short clip: the batched pipeline's
     matches of two frame pairs equal the oracle's (detect -> describe -> kNN-2 -> ratio, bit exact at 1080p), every
