@@ -758,6 +758,13 @@ __device__ __forceinline__ size_t tw_side_flags(int nblk, int W) { return 2 * (s
 // soon as that exists and hands the 64-vector to the owner of the diagonal block r, which adds the contributions in
 // a fixed order (deterministic), applies L_rr^-1 and publishes y_r.  The y chain trails the factorisation by a hop or
 // two, so the forward solve costs no extra time.  (Two-ended: the rows of M receive contributions from both sides.)
+#ifdef MM_CHOL_TRACE
+__device__ unsigned long long g_chol_trace[128][12];
+#define MM_TRACE(r, e) do { if (side == 0 && threadIdx.x == 0 && (r) < 128) g_chol_trace[r][e] = wall_clock64(); } while (0)
+#else
+#define MM_TRACE(r, e) do { } while (0)
+#endif
+
 template <int MODE>
 __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, TwGeom g, double *Linv,
                                                               int32_t *__restrict__ flags, int32_t *__restrict__ info,
@@ -911,6 +918,7 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, TwGeom 
         if (!diag_here && !has_sub) continue;
         const TileRef dt = tile_ref(A, g, side, r, r);
         const TileRef st = tile_ref(A, g, side, r, has_sub ? r - 1 : r);  // block (r, r - 1)
+        MM_TRACE(r, 0);
         zero_acc(acc);
         zero_acc(acc1);
         // rows of M (two-ended, side 0): the diagonal block -- and the block left of it when that is in M too -- come
@@ -936,11 +944,16 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, TwGeom 
             MM_ACC_FOREACH(a0[a][b][i] = (dt.rv(row) && dt.cv(col) && col <= row) ? ld_shared<MODE>(dt.at(row, col)) : 0.0;)
         if (has_sub) MM_ACC_FOREACH(a1[a][b][i] = (st.rv(row) && st.cv(col)) ? ld_shared<MODE>(st.at(row, col)) : 0.0;)
         if (has_sub) {
+            MM_TRACE(r, 1);
             if (!wg_wait<MODE>(aflag(fb, r - 1), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
+            MM_TRACE(r, 2);
             finish_off_block_a<MODE>(As, Bs, T, a1, acc1, tile_ref(A, g, side, r - 1, r - 1), linv(side, r - 1), st);
+            MM_TRACE(r, 3);
             if (!wg_wait<MODE>(flag(fb, r - 1, 0), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
+            MM_TRACE(r, 4);
             finish_off_block_b<MODE>(As, Bs, T, linv(side, r - 1), st);
             wg_publish<MODE>(flag(fb, r, 1));  // (its barrier also orders the LDS copy of the block)
+            MM_TRACE(r, 5);
             if (diag_here) tile_gemm_nt(As, As, acc);
         }
         if (!diag_here) {  // side 1, block (b, b - 1): its row belongs to M, side 0 finishes it
@@ -986,7 +999,9 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, TwGeom 
             __builtin_amdgcn_wave_barrier();
             if (lane == 0) __hip_atomic_store(aflag(fb, r), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
+        MM_TRACE(r, 6);
         factor_block_lds(M, X, R, 0, bad, stage_a);
+        MM_TRACE(r, 7);
         if (bad && threadIdx.x == 64) {  // `bad` = 1-based position inside the block; report the natural column
             const long col = vec_index(g, side, r, bad - 1);
             report_bad(info, (int)(col >= 0 && col < n ? col + 1 : n));
@@ -998,6 +1013,7 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, TwGeom 
             st_shared<MODE>(Lr + rr * NB + cc, X[rr][cc]);
         }
         wg_publish<MODE>(flag(fb, r, 0));
+        MM_TRACE(r, 8);
         for (int q = 0; q < 4; ++q) {  // diagonal 16 x 16 blocks of L_rr: only the later kernels read them
             const int e = threadIdx.x + 256 * q, blk = e >> 8, rr = 16 * blk + ((e >> 4) & 15), cc = 16 * blk + (e & 15);
             if (dt.rv(rr) && dt.cv(cc) && cc <= rr) *dt.at(rr, cc) = M[rr][cc];
@@ -1043,9 +1059,16 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, TwGeom 
             }
             wg_publish<MODE>(yflag(fb, r));
         }
+        MM_TRACE(r, 9);
         __syncthreads();  // M / X are overwritten by the next row's tiles
     }
 }
+
+#ifdef MM_CHOL_TRACE
+extern "C" int mm_debug_chol_trace(unsigned long long *host /*[128*12]*/) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_chol_trace), sizeof(g_chol_trace));
+}
+#endif
 
 // ---- backward substitution L^T x = y for a narrow band: ONE launch ------------------------------------------------------
 // Per side, workgroup 0 owns the diagonal and the first sub-diagonal: x_k = L_kk^-T (y_k - sum_d L_{k+d,k}^T x_{k+d}),

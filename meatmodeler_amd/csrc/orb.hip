@@ -161,13 +161,19 @@ constexpr int FT_W = 64, FT_H = 64;        // keypoint tile
 constexpr int FP_W = 80, FP_H = FT_H + 8;  // pixel tile in LDS (80 = 72 needed + alignment slack)
 constexpr int FS_W = FT_W + 2, FS_H = FT_H + 2;
 
-__device__ __forceinline__ int fast_score(const uint8_t (*P)[FP_W], int r, int c, int t) {
-    const int p = P[r][c];
-    int v[16];
+// the 16 ring pixels of FAST around P[r][c], clockwise from (row + 3, col)
+__device__ __forceinline__ void fast_ring(const uint8_t (*P)[FP_W], int r, int c, int (&v)[16]) {
     v[0] = P[r + 3][c];      v[1] = P[r + 3][c + 1];  v[2] = P[r + 2][c + 2];  v[3] = P[r + 1][c + 3];
     v[4] = P[r][c + 3];      v[5] = P[r - 1][c + 3];  v[6] = P[r - 2][c + 2];  v[7] = P[r - 3][c + 1];
     v[8] = P[r - 3][c];      v[9] = P[r - 3][c - 1];  v[10] = P[r - 2][c - 2]; v[11] = P[r - 1][c - 3];
     v[12] = P[r][c - 3];     v[13] = P[r + 1][c - 3]; v[14] = P[r + 2][c - 2]; v[15] = P[r + 3][c - 1];
+}
+
+// 0: no corner, 1: nine contiguous ring pixels brighter than p + t, 2: darker than p - t (never both: 9 + 9 > 16)
+__device__ __forceinline__ int fast_corner_kind(const uint8_t (*P)[FP_W], int r, int c, int t) {
+    const int p = P[r][c];
+    int v[16];
+    fast_ring(P, r, c, v);
     uint32_t mb = 0, md = 0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -182,31 +188,43 @@ __device__ __forceinline__ int fast_score(const uint8_t (*P)[FP_W], int r, int c
         x &= m >> 8;
         return (x & 0xFFFFu) != 0;
     };
-    const bool cb = has9(mb), cd = has9(md);
-    if (!cb && !cd) return 0;
+    return has9(mb) ? 1 : (has9(md) ? 2 : 0);
+}
+
+// largest threshold for which the pixel is still a corner of the given kind: max over the 16 arcs of nine of the
+// smallest signed difference in the arc, minus one
+__device__ __forceinline__ int fast_score(const uint8_t (*P)[FP_W], int r, int c, int kind) {
+    const int p = P[r][c];
+    int v[16], d[16], m1[16], m2[16], m4[16];
+    fast_ring(P, r, c, v);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) d[i] = kind == 1 ? v[i] - p : p - v[i];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m1[i] = min(d[i], d[(i + 1) & 15]);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m2[i] = min(m1[i], m1[(i + 2) & 15]);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m4[i] = min(m2[i], m2[(i + 4) & 15]);
     int best = 0;
 #pragma unroll
-    for (int pol = 0; pol < 2; ++pol) {
-        if (pol == 0 ? !cb : !cd) continue;
-        int d[16], m1[16], m2[16], m4[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) d[i] = pol == 0 ? v[i] - p : p - v[i];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) m1[i] = min(d[i], d[(i + 1) & 15]);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) m2[i] = min(m1[i], m1[(i + 2) & 15]);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) m4[i] = min(m2[i], m2[(i + 4) & 15]);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) best = max(best, min(m4[i], d[(i + 8) & 15]));
-    }
-    return best - 1;  // largest threshold for which the pixel is still a corner (>= t)
+    for (int i = 0; i < 16; ++i) best = max(best, min(m4[i], d[(i + 8) & 15]));
+    return best - 1;
+}
+
+// append the lanes with `pass` to an LDS list (one LDS atomic per wave)
+__device__ __forceinline__ void wave_append(bool pass, uint16_t value, uint16_t *list, int *count) {
+    const unsigned long long m = __ballot(pass);
+    if (m == 0) return;
+    int base = 0;
+    if ((threadIdx.x & 63) == 0) base = atomicAdd(count, __popcll(m));
+    base = __shfl(base, 0, 64);
+    if (pass) list[base + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1))] = value;
 }
 
 __global__ __launch_bounds__(256) void orb_fast_kernel(OrbGeom g, const uint8_t *__restrict__ imgs,
-                                                       uint8_t *__restrict__ ws, int fast_t) {
+                                                       uint8_t *__restrict__ ws, int fast_t, int dbg) {
     __shared__ __attribute__((aligned(16))) uint8_t P[FP_H][FP_W];
-    __shared__ uint8_t Sc[FS_H][FS_W + 2];
+    __shared__ __attribute__((aligned(16))) uint8_t Sc[FS_H][FS_W + 2];
     const int b = blockIdx.y;
     int l = 0;
     while (l + 1 < g.nlevels && (int)blockIdx.x >= g.tile_start[l + 1]) ++l;
@@ -216,7 +234,7 @@ __global__ __launch_bounds__(256) void orb_fast_kernel(OrbGeom g, const uint8_t 
     const int w = g.w[l], h = g.h[l];
     int pitch;
     const uint8_t *img = level_ptr(g, imgs, ws, l, b, pitch);
-    // pixel tile: rows oy-4 .. oy+19, columns ox-7 .. ox+72 (ox-7 is a multiple of 4)
+    // pixel tile: rows oy-4 .. oy+67, columns ox-7 .. ox+72 (ox-7 is a multiple of 4)
     const int bx = ox - 7, by = oy - 4;
     for (int e = threadIdx.x; e < FP_H * (FP_W / 4); e += 256) {
         const int r = e / (FP_W / 4), c4 = (e % (FP_W / 4)) * 4;
@@ -225,57 +243,96 @@ __global__ __launch_bounds__(256) void orb_fast_kernel(OrbGeom g, const uint8_t 
         if (y < h && x + 3 < pitch) v = *reinterpret_cast<const uint32_t *>(img + (size_t)y * pitch + x);
         *reinterpret_cast<uint32_t *>(&P[r][c4]) = v;
     }
-    __syncthreads();
-    // Two passes over the score positions.  Pass 1 is the exact compass pre-test (any 9 contiguous ring pixels contain
-    // at least two of the four compass pixels, so a corner needs two of them brighter than p + t or two darker than
-    // p - t) and compacts the survivors into an LDS list with one LDS atomic per wave; pass 2 runs the full 16-pixel
-    // score on the list with full waves.  (Testing and scoring in one pass, a wave pays for the score as soon as one
-    // of its 64 pixels survives.)
+    static_assert(sizeof(Sc) % 4 == 0, "score tile is cleared by words");
+    for (int e = threadIdx.x; e < (int)sizeof(Sc) / 4; e += 256) reinterpret_cast<uint32_t *>(&Sc[0][0])[e] = 0;
+    // A cascade over the score positions, each stage compacting its survivors into an LDS list so that the next one runs
+    // on full waves (in one pass, a wave pays for the most expensive stage as soon as one of its 64 pixels gets there):
+    //   1. every position: the exact compass pre-test (any 9 contiguous ring pixels contain two of the four compass
+    //      pixels, so a corner needs two of them brighter than p + t or two darker than p - t)          ~7 % survive
+    //   2. survivors: the 16 comparisons and the nine-in-a-row test                                     ~1 % are corners
+    //   3. corners: the score (16 arcs of nine), written into the score tile
+    //   4. corners again: strict 3 x 3 non-maximum suppression against the score tile -> key points
+    if (dbg & 1) return;
     __shared__ uint16_t todo[FS_H * FS_W];
-    __shared__ int n_todo;
-    if (threadIdx.x == 0) n_todo = 0;
+    uint16_t *corners = todo;
+    __shared__ int n_todo, n_corners;
+    if (threadIdx.x == 0) n_todo = n_corners = 0;
     __syncthreads();
-    for (int e0 = 0; e0 < FS_H * FS_W; e0 += 256) {
-        const int e = e0 + threadIdx.x;
-        bool pass = false;
-        if (e < FS_H * FS_W) {
-            const int sr = e / FS_W, sc = e % FS_W;
+    {
+        // Stage 1, one row of score positions per wave and step (lane = column; the two columns 64, 65 are left to one
+        // extra step): addresses advance by a constant, the survivors of all steps are kept as a bit mask per lane and
+        // appended to the list at the end with ONE LDS atomic per wave.
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        auto compass = [&](int sr, int sc) -> bool {
             // score position: image (ox-1+sc, oy-1+sr) -> P[r = sr+3][c = sc+6]
-            const int x = ox - 1 + sc, y = oy - 1 + sr;
-            Sc[sr][sc] = 0;
-            if (x < w - 3 && y < h - 3) {
-                const int r = sr + 3, c = sc + 6;
-                const int p = P[r][c], hi = p + fast_t, lo = p - fast_t;
-                const int a0 = P[r + 3][c], a4 = P[r][c + 3], a8 = P[r - 3][c], a12 = P[r][c - 3];
-                const int nb = (a0 > hi) + (a4 > hi) + (a8 > hi) + (a12 > hi);
-                const int nd = (a0 < lo) + (a4 < lo) + (a8 < lo) + (a12 < lo);
-                pass = nb >= 2 || nd >= 2;
-            }
+            const int r = sr + 3, c = sc + 6;
+            const int p = P[r][c], hi = p + fast_t, lo = p - fast_t;
+            const int a0 = P[r + 3][c], a4 = P[r][c + 3], a8 = P[r - 3][c], a12 = P[r][c - 3];
+            const int nb = (a0 > hi) + (a4 > hi) + (a8 > hi) + (a12 > hi);
+            const int nd = (a0 < lo) + (a4 < lo) + (a8 < lo) + (a12 < lo);
+            return nb >= 2 || nd >= 2;
+        };
+        uint32_t mask = 0;
+        const bool col_ok = ox - 1 + lane < w - 3;
+#pragma unroll
+        for (int it = 0; it < (FS_H + 3) / 4; ++it) {
+            const int sr = wv + 4 * it;
+            if (sr < FS_H && oy - 1 + sr < h - 3)                     // wave-uniform
+                mask |= (uint32_t)(col_ok && compass(sr, lane)) << it;
         }
-        const unsigned long long m = __ballot(pass);
+        constexpr int LEFT_BIT = (FS_H + 3) / 4;
+        const int q = wv * 64 + lane, qr = q >> 1, qc = 64 + (q & 1);   // the two right-most columns
+        if (q < 2 * FS_H && ox - 1 + qc < w - 3 && oy - 1 + qr < h - 3) mask |= (uint32_t)compass(qr, qc) << LEFT_BIT;
+        // append row by row (neighbouring list entries = neighbouring pixels: stage 2 reads P without bank conflicts)
+        int total = 0;
+#pragma unroll
+        for (int it = 0; it <= LEFT_BIT; ++it) total += __popcll(__ballot((mask >> it) & 1));
         int base = 0;
-        if ((threadIdx.x & 63) == 0 && m) base = atomicAdd(&n_todo, __popcll(m));
+        if (lane == 0 && total) base = atomicAdd(&n_todo, total);
         base = __shfl(base, 0, 64);
-        if (pass) todo[base + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1))] = (uint16_t)e;
+#pragma unroll
+        for (int it = 0; it <= LEFT_BIT; ++it) {
+            const bool on = (mask >> it) & 1;
+            const unsigned long long m = __ballot(on);
+            const int e = it == LEFT_BIT ? qr * FS_W + qc : (wv + 4 * it) * FS_W + lane;
+            if (on) todo[base + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)e;
+            base += __popcll(m);
+        }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < n_todo; i += 256) {
-        const int e = todo[i];
+    if (dbg & 2) return;
+    const int nt = n_todo;
+    for (int i0 = 0; i0 < nt; i0 += 256) {      // (the corner list overwrites the part of the survivor list already read)
+        const int i = i0 + threadIdx.x;
+        const int e = i < nt ? todo[i] : 0;
+        __syncthreads();
+        const int kind = i < nt ? fast_corner_kind(P, e / FS_W + 3, e % FS_W + 6, fast_t) : 0;
+        wave_append(kind != 0, (uint16_t)(e | (kind << 14)), corners, &n_corners);   // e < 4356 < 2^13
+    }
+    __syncthreads();
+    if (dbg & 4) return;
+    const int nc = n_corners;
+    for (int i = threadIdx.x; i < nc; i += 256) {
+        const int e = corners[i] & 0x3FFF, kind = corners[i] >> 14;
         const int sr = e / FS_W, sc = e % FS_W;
-        Sc[sr][sc] = (uint8_t)fast_score(P, sr + 3, sc + 6, fast_t);
+        Sc[sr][sc] = (uint8_t)fast_score(P, sr + 3, sc + 6, kind);
     }
-    __syncthreads();
     // Survivors of the strict 3x3 NMS are collected in LDS first (at most 1 in 4 pixels can survive), so the tile costs
     // ONE returning global atomic on the per-(frame, level) counter plus one add per occupied histogram bin, instead of
     // one of each per key point on the same few words.
-    __shared__ uint32_t keys[FT_H * FT_W / 4 + 8];
-    __shared__ int lhist[256];
+    // (keys and histogram reuse the pixel tile, which nobody reads after the scores: 19 KB of LDS, 8 workgroups per CU)
+    static_assert(sizeof(P) >= (FT_H * FT_W / 4 + 8) * 4 + 256 * 4, "key list + histogram must fit into the pixel tile");
+    uint32_t *keys = reinterpret_cast<uint32_t *>(&P[0][0]);
+    int *lhist = reinterpret_cast<int *>(keys + FT_H * FT_W / 4 + 8);
     __shared__ int lcount, lbase;
+    __syncthreads();
     lhist[threadIdx.x] = 0;
     if (threadIdx.x == 0) lcount = 0;
     __syncthreads();
-    for (int e = threadIdx.x; e < FT_H * FT_W; e += 256) {
-        const int r = e / FT_W, c = e % FT_W;
+    for (int i = threadIdx.x; i < nc; i += 256) {
+        const int e = corners[i] & 0x3FFF;
+        const int r = e / FS_W - 1, c = e % FS_W - 1;       // key point tile coordinates (the halo ring only feeds the NMS)
+        if (r < 0 || r >= FT_H || c < 0 || c >= FT_W) continue;
         const int x = ox + c, y = oy + r;
         if (x >= w - EDGE || y >= h - EDGE) continue;
         const int s = Sc[r + 1][c + 1];
@@ -289,13 +346,13 @@ __global__ __launch_bounds__(256) void orb_fast_kernel(OrbGeom g, const uint8_t 
     }
     __syncthreads();
     const int nloc = lcount;
-    if (nloc == 0) return;
+    if (nloc == 0 || (dbg & 8)) return;
     const int seg = b * g.nlevels + l;
     int32_t *cnt = reinterpret_cast<int32_t *>(ws + g.cnt_off) + seg;
     int32_t *hist = reinterpret_cast<int32_t *>(ws + g.hist_off) + (size_t)seg * 256;
     uint32_t *cand = reinterpret_cast<uint32_t *>(ws + g.cand_off[l]) + (size_t)b * g.cand_cap[l];
     if (threadIdx.x == 0) lbase = atomicAdd(cnt, nloc);
-    if (lhist[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lhist[threadIdx.x]);
+    if (lhist[threadIdx.x] && !(dbg & 16)) atomicAdd(&hist[threadIdx.x], lhist[threadIdx.x]);
     __syncthreads();
     const int base = lbase;
     for (int e = threadIdx.x; e < nloc; e += 256)
@@ -693,7 +750,7 @@ int mm_orb_detect_compute(mm_ctx *ctx, const uint8_t *imgs, int batch, int heigh
         }
     }
     if (g.tile_start[g.nlevels] > 0) {
-        MM_LAUNCH(ctx, "orb_fast_kernel", orb_fast_kernel, dim3(g.tile_start[g.nlevels], batch), dim3(256), 0, g, imgs, w8, prm->fast_threshold);
+        MM_LAUNCH(ctx, "orb_fast_kernel", orb_fast_kernel, dim3(g.tile_start[g.nlevels], batch), dim3(256), 0, g, imgs, w8, prm->fast_threshold, getenv("MM_ORB_DBG") ? atoi(getenv("MM_ORB_DBG")) : 0);
     }
     const int segs = batch * g.nlevels;
     MM_LAUNCH(ctx, "orb_select_kernel", orb_select_kernel, dim3(segs), dim3(256), 0, g, w8);

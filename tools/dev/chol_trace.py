@@ -1,0 +1,40 @@
+"""Phase timestamps of the row-head workgroups of the single-launch banded factorisation (build csrc with
+-DMM_CHOL_TRACE): where the ~21 us per block column of the chain go."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np, torch
+from meatmodeler_amd import ops
+from meatmodeler_amd._lib import lib, default_context, LIB_PATH
+ctx = default_context(); dev = ctx.device
+n, hb = int(os.environ.get("N", 3000)), int(os.environ.get("HB", 527))
+rng = np.random.default_rng(0)
+A = np.zeros((n, n))
+for i in range(n):
+    lo = max(0, i - hb)
+    A[i, lo:i] = rng.normal(size=i - lo) * 0.01
+A = A + A.T + np.eye(n) * 4
+b = rng.normal(size=n)
+for rep in range(3):
+    S = torch.as_tensor(A, device=dev).clone(); v = torch.as_tensor(b, device=dev).clone()
+    info = ops.chol_solve_sym(S, v, ctx, hb, True)
+    torch.cuda.synchronize()
+x = v.cpu().numpy()
+print("info", int(info), "residual", np.abs(A @ x - b).max())
+raw = C.CDLL(LIB_PATH)
+buf = (C.c_ulonglong * (128 * 12))()
+assert raw.mm_debug_chol_trace(buf) == 0
+t = np.array(buf[:], dtype=np.int64).reshape(128, 12)[:, :10] * 10e-3   # 100 MHz -> us
+rows = [r for r in range(128) if t[r, 9] > 0]
+t0 = t[rows, 0].min()
+names = ["start", "acc_done", "aflag", "fin_a", "flag0", "fin_b+pub", "syrk+M", "factor", "publish", "row_end"]
+print("row  " + " ".join(f"{x:>9s}" for x in names) + "   step(publish - prev publish)")
+prev = None
+for r in rows:
+    rel = t[r] - t0
+    step = "" if prev is None else f"{t[r, 8] - prev:8.2f}"
+    print(f"{r:3d}  " + " ".join(f"{x:9.2f}" for x in rel) + "   " + step)
+    prev = t[r, 8]
+d = np.diff(t[rows][:, 8])
+print("median step", np.median(d))
+seg = t[rows][:, 1:] - t[rows][:, :-1]
+print("median per-phase (us):", dict(zip(names[1:], np.round(np.median(seg[1:], 0), 2))))
