@@ -169,7 +169,9 @@ __device__ __forceinline__ void fast_ring(const uint8_t (*P)[FP_W], int r, int c
     v[12] = P[r][c - 3];     v[13] = P[r + 1][c - 3]; v[14] = P[r + 2][c - 2]; v[15] = P[r + 3][c - 1];
 }
 
-// 0: no corner, 1: nine contiguous ring pixels brighter than p + t, 2: darker than p - t (never both: 9 + 9 > 16)
+// 0: no corner, 1: nine contiguous ring pixels brighter than p + t, 2: darker than p - t (never both: 9 + 9 > 16).
+// (Per-lane bit masks: the same logic on wave-wide ballot masks in scalar registers was 1.7x slower here -- 158
+// dependent scalar operations per step -- while it pays for the four-pixel pre-test of stage 1.)
 __device__ __forceinline__ int fast_corner_kind(const uint8_t (*P)[FP_W], int r, int c, int t) {
     const int p = P[r][c];
     int v[16];
@@ -253,58 +255,62 @@ __global__ __launch_bounds__(256) void orb_fast_kernel(OrbGeom g, const uint8_t 
     //   3. corners: the score (16 arcs of nine), written into the score tile
     //   4. corners again: strict 3 x 3 non-maximum suppression against the score tile -> key points
     if (dbg & 1) return;
-    __shared__ uint16_t todo[FS_H * FS_W];
+    constexpr int TODO_SEG = ((FS_H + 3) / 4 + 1) * 64;      // rows of a wave + its share of the two right-most columns
+    __shared__ uint16_t todo[4 * TODO_SEG];
     uint16_t *corners = todo;
-    __shared__ int n_todo, n_corners;
-    if (threadIdx.x == 0) n_todo = n_corners = 0;
+    __shared__ int seg_n[4], n_corners;
+    if (threadIdx.x == 0) n_corners = 0;
     __syncthreads();
     {
         // Stage 1, one row of score positions per wave and step (lane = column; the two columns 64, 65 are left to one
         // extra step): addresses advance by a constant, the survivors of all steps are kept as a bit mask per lane and
         // appended to the list at the end with ONE LDS atomic per wave.
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        auto compass = [&](int sr, int sc) -> bool {
+        // The test itself runs on wave-wide masks (one bit per lane, in scalar registers): per position 8 vector
+        // compares; the and / or logic is scalar work, which issues beside the vector instructions of the other waves.
+        // Any 9 contiguous ring pixels contain pixel 0 or 8 AND pixel 4 or 12, so a corner needs
+        // (b0 | b8) & (b4 | b12) among the brighter-than-p+t bits or the same among the darker-than-p-t bits.
+        auto compass = [&](int sr, int sc, bool ok) -> unsigned long long {
             // score position: image (ox-1+sc, oy-1+sr) -> P[r = sr+3][c = sc+6]
             const int r = sr + 3, c = sc + 6;
-            const int p = P[r][c], hi = p + fast_t, lo = p - fast_t;
+            const int p = P[r][c], hi = ok ? p + fast_t : 256, lo = ok ? p - fast_t : -1;
             const int a0 = P[r + 3][c], a4 = P[r][c + 3], a8 = P[r - 3][c], a12 = P[r][c - 3];
-            const int nb = (a0 > hi) + (a4 > hi) + (a8 > hi) + (a12 > hi);
-            const int nd = (a0 < lo) + (a4 < lo) + (a8 < lo) + (a12 < lo);
-            return nb >= 2 || nd >= 2;
+            const unsigned long long b = (__ballot(a0 > hi) | __ballot(a8 > hi)) & (__ballot(a4 > hi) | __ballot(a12 > hi));
+            const unsigned long long d = (__ballot(a0 < lo) | __ballot(a8 < lo)) & (__ballot(a4 < lo) | __ballot(a12 < lo));
+            return b | d;
         };
-        uint32_t mask = 0;
+        // every wave appends to its own segment of the list (neighbouring entries = neighbouring pixels: stage 2 reads P
+        // without bank conflicts); the running count is a scalar
         const bool col_ok = ox - 1 + lane < w - 3;
-#pragma unroll
-        for (int it = 0; it < (FS_H + 3) / 4; ++it) {
-            const int sr = wv + 4 * it;
-            if (sr < FS_H && oy - 1 + sr < h - 3)                     // wave-uniform
-                mask |= (uint32_t)(col_ok && compass(sr, lane)) << it;
+        const unsigned long long below = (1ull << lane) - 1;
+        uint16_t *seg = todo + wv * TODO_SEG;
+        int cnt = 0;
+        const int sr_end = min(FS_H, h - 3 - (oy - 1));
+        for (int sr = wv; sr < sr_end; sr += 4) {
+            const unsigned long long m = compass(sr, lane, col_ok);
+            if ((m >> lane) & 1) seg[cnt + __popcll(m & below)] = (uint16_t)(sr * FS_W + lane);
+            cnt += __popcll(m);
         }
-        constexpr int LEFT_BIT = (FS_H + 3) / 4;
         const int q = wv * 64 + lane, qr = q >> 1, qc = 64 + (q & 1);   // the two right-most columns
-        if (q < 2 * FS_H && ox - 1 + qc < w - 3 && oy - 1 + qr < h - 3) mask |= (uint32_t)compass(qr, qc) << LEFT_BIT;
-        // append row by row (neighbouring list entries = neighbouring pixels: stage 2 reads P without bank conflicts)
-        int total = 0;
-#pragma unroll
-        for (int it = 0; it <= LEFT_BIT; ++it) total += __popcll(__ballot((mask >> it) & 1));
-        int base = 0;
-        if (lane == 0 && total) base = atomicAdd(&n_todo, total);
-        base = __shfl(base, 0, 64);
-#pragma unroll
-        for (int it = 0; it <= LEFT_BIT; ++it) {
-            const bool on = (mask >> it) & 1;
-            const unsigned long long m = __ballot(on);
-            const int e = it == LEFT_BIT ? qr * FS_W + qc : (wv + 4 * it) * FS_W + lane;
-            if (on) todo[base + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)e;
-            base += __popcll(m);
+        if (wv * 64 < 2 * FS_H) {
+            const unsigned long long m = compass(min(qr, FS_H - 1), qc, q < 2 * FS_H && ox - 1 + qc < w - 3 && oy - 1 + qr < h - 3);
+            if ((m >> lane) & 1) seg[cnt + __popcll(m & below)] = (uint16_t)(qr * FS_W + qc);
+            cnt += __popcll(m);
         }
+        if (lane == 0) seg_n[wv] = cnt;
     }
     __syncthreads();
     if (dbg & 2) return;
-    const int nt = n_todo;
-    for (int i0 = 0; i0 < nt; i0 += 256) {      // (the corner list overwrites the part of the survivor list already read)
+    const int pre1 = seg_n[0], pre2 = pre1 + seg_n[1], pre3 = pre2 + seg_n[2], nt = pre3 + seg_n[3];
+    for (int i0 = 0; i0 < nt; i0 += 256) {
         const int i = i0 + threadIdx.x;
-        const int e = i < nt ? todo[i] : 0;
+        int e = 0;
+        if (i < nt) {
+            const int sg = (i >= pre1) + (i >= pre2) + (i >= pre3);
+            e = todo[sg * TODO_SEG + i - (sg == 0 ? 0 : sg == 1 ? pre1 : sg == 2 ? pre2 : pre3)];
+        }
+        // the corner list overwrites the list of survivors from its start: it holds fewer entries than have been read,
+        // and an entry's position in its segment is never before its rank in the order of reading
         __syncthreads();
         const int kind = i < nt ? fast_corner_kind(P, e / FS_W + 3, e % FS_W + 6, fast_t) : 0;
         wave_append(kind != 0, (uint16_t)(e | (kind << 14)), corners, &n_corners);   // e < 4356 < 2^13
