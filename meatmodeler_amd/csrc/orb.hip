@@ -511,11 +511,12 @@ __global__ __launch_bounds__(256) void orb_rank_kernel(OrbGeom g, uint8_t *__res
 
 // ---- orientation + descriptor ----------------------------------------------------------------------------------------------
 __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
-__constant__ int c_gw[7] = {18, 33, 49, 56, 49, 33, 18};  // 7-tap sigma=2 Gaussian, 8-bit fixed point, sum 256
+// blur: 7-tap sigma=2 Gaussian {18, 33, 49, 56, 49, 33, 18} / 256 in 8-bit fixed point (weights inlined in the kernel)
 
 constexpr int DP = 39;  // raw patch side (31 + 2*(1 rotation slack) + 2*3 blur) -> offsets -19..19
 constexpr int DB = 33;  // blurred patch side, offsets -16..16
 constexpr int DESC_WAVES = 4;
+constexpr int DESC_KP_PER_WAVE = 8;  // key points a wave describes one after the other (the next patch prefetched)
 
 __global__ __launch_bounds__(64 * DESC_WAVES) void orb_describe_kernel(OrbGeom g, const uint8_t *__restrict__ imgs,
                                                                        const uint8_t *__restrict__ ws,
@@ -524,36 +525,82 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void orb_describe_kernel(OrbGeom g
                                                                        const int32_t *__restrict__ n_out,
                                                                        int32_t *__restrict__ kp_mom,
                                                                        uint8_t *__restrict__ desc) {
-    __shared__ uint8_t raw[DESC_WAVES][DP][DP + 1];
-    __shared__ uint16_t hb[DESC_WAVES][DP][DB + 1];
-    __shared__ uint8_t bl[DESC_WAVES][DB][DB + 3];
+    // Per wave: the raw 39 x 39 patch as aligned words (byte j of a row = image column xa + j, xa = (x - 19) & ~3, so
+    // patch column c sits at byte c + sh), the horizontally blurred patch TRANSPOSED as u16 (so that the vertical pass
+    // reads its seven taps as four words), and the blurred 33 x 33 patch, which reuses the raw patch's storage.
+    constexpr int RW = 12, HT = 40, BLP = 36;
+    __shared__ uint32_t raw_w[DESC_WAVES][DP * RW];
+    __shared__ uint16_t hbt[DESC_WAVES][36 * HT];
+    static_assert(DP * RW * 4 >= DB * BLP, "blurred patch reuses the raw patch");
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int kp = blockIdx.x * DESC_WAVES + wv;
-    if (kp >= n_out[b]) return;  // wave-uniform; no workgroup barriers below
+    const int n_kp = n_out[b];
+    const int n_waves = gridDim.x * DESC_WAVES;
+    int kp = blockIdx.x * DESC_WAVES + wv;
+    if (kp >= n_kp) return;  // wave-uniform; no workgroup barriers below
+    uint32_t *rw = raw_w[wv];
+    const uint8_t *raw = reinterpret_cast<const uint8_t *>(rw);     // raw[r * 48 + c + sh]
+    uint8_t *bl = reinterpret_cast<uint8_t *>(rw);                   // bl[r * BLP + c], written after the last read of raw
+    uint16_t *ht = hbt[wv];
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    // what does not depend on the key point: this lane's four sampling pairs and its row of the moment disc
+    uint32_t patw[4];      // (kept packed: unpacked and converted to f64 inside the loop, or 32 registers are pinned)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) patw[q] = reinterpret_cast<const uint32_t *>(pattern)[lane * 4 + q];
+    const int mv = lane - 15, um = lane < 31 ? c_umax[mv < 0 ? -mv : mv] : -1;
+    // A wave describes every n_waves-th key point of its frame.  The patch of the NEXT key point is requested (into
+    // registers) before the current one is processed: the two dependent global accesses (key point record, then 39 row
+    // segments scattered over a pyramid level) were 36 % of a wave's life and more on clips that do not fit the caches.
+    constexpr int NPRE = (DP * 11 + 63) / 64;
+    uint32_t pre[NPRE];
+    int x = 0, y = 0;
+    auto request = [&](int k) {
+        const size_t oo = (size_t)b * g.cap_out + k;
+        const int l = kp_meta[oo * 4];
+        x = kp_meta[oo * 4 + 1];
+        y = kp_meta[oo * 4 + 2];
+        int pitch;
+        const uint8_t *img = level_ptr(g, imgs, ws, l, b, pitch);
+        const int xa = (x - 19) & ~3;
+        // 11 words per row cover bytes 0 .. 43 >= 38 + 3; key points keep 31 pixels from the border: inside the row
+#pragma unroll
+        for (int j = 0; j < NPRE; ++j) {
+            const int e = min(lane + 64 * j, DP * 11 - 1), r = e / 11, wc = e % 11;
+            pre[j] = *reinterpret_cast<const uint32_t *>(img + (size_t)(y - 19 + r) * pitch + xa + 4 * wc);
+        }
+    };
+    request(kp);
+    const int lane_invariant = lane;
+    for (;;) {
+    // (opaque copy: otherwise every index expression below is hoisted out of the key point loop -- 118 registers, half
+    // the occupancy)
+    int lane = lane_invariant;
+    asm volatile("" : "+v"(lane));
     const size_t o = (size_t)b * g.cap_out + kp;
-    const int l = kp_meta[o * 4], x = kp_meta[o * 4 + 1], y = kp_meta[o * 4 + 2];
-    int pitch;
-    const uint8_t *img = level_ptr(g, imgs, ws, l, b, pitch);
-    for (int e = lane; e < DP * DP; e += 64) {
-        const int r = e / DP, c = e % DP;
-        raw[wv][r][c] = img[(size_t)(y - 19 + r) * pitch + (x - 19 + c)];
+    const int sh = (x - 19) & 3;
+#pragma unroll
+    for (int j = 0; j < NPRE; ++j) {
+        const int e = lane + 64 * j;
+        if (e < DP * 11) rw[(e / 11) * RW + e % 11] = pre[j];
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    wave_sync();
+    const int kp_next = kp + n_waves;
+    if (kp_next < n_kp) request(kp_next);      // (x, y now belong to the next key point)
     // intensity-centroid moments over the radius-15 disc (rows v = -15..15 over lanes 0..30)
     int m10 = 0, m01 = 0;
     if (lane < 31) {
-        const int v = lane - 15;
-        const int um = c_umax[v < 0 ? -v : v];
         int rs = 0;
+        const uint8_t *row = raw + (19 + mv) * (4 * RW) + 19 + sh;
         for (int u = -um; u <= um; ++u) {
-            const int val = raw[wv][19 + v][19 + u];
+            const int val = row[u];
             m10 += u * val;
             rs += val;
         }
-        m01 = v * rs;
+        m01 = mv * rs;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -564,27 +611,47 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void orb_describe_kernel(OrbGeom g
         kp_mom[o * 2] = m10;
         kp_mom[o * 2 + 1] = m01;
     }
-    // horizontal blur: rows 0..38 (offset -19..19), cols -16..16
-    for (int e = lane; e < DP * DB; e += 64) {
-        const int r = e / DB, c = e % DB;  // output col offset = c - 16 -> raw col index c + 3
-        int s = 0;
+    // horizontal blur, four outputs (bytes 4k .. 4k+3 of the row, i.e. patch columns 4k - sh ..) per lane and step from
+    // three words: taps 0..3 and 4..6 are one v_dot4_u32_u8 each on byte windows cut out with v_alignbyte.
+    // {18,33,49,56 | 49,33,18,0}: exact integer sums <= 255 * 256.
+    constexpr uint32_t GW_LO = 18u | (33u << 8) | (49u << 16) | (56u << 24), GW_HI = 49u | (33u << 8) | (18u << 16);
+    for (int e = lane; e < DP * 9; e += 64) {
+        const int r = e / 9, k = e % 9;
+        const uint32_t w0 = rw[r * RW + k], w1 = rw[r * RW + k + 1], w2 = rw[r * RW + k + 2];
+        uint32_t s[4];
+        s[0] = __builtin_amdgcn_udot4(w1, GW_HI, __builtin_amdgcn_udot4(w0, GW_LO, 0u, false), false);
 #pragma unroll
-        for (int k = 0; k < 7; ++k) s += c_gw[k] * raw[wv][r][c + k];
-        hb[wv][r][c] = (uint16_t)s;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (int e = lane; e < DB * DB; e += 64) {
-        const int r = e / DB, c = e % DB;
-        int s = 0;
+        for (int q = 1; q < 4; ++q) {
+            const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, (uint32_t)q), hi = __builtin_amdgcn_alignbyte(w2, w1, (uint32_t)q);
+            s[q] = __builtin_amdgcn_udot4(hi, GW_HI, __builtin_amdgcn_udot4(lo, GW_LO, 0u, false), false);
+        }
 #pragma unroll
-        for (int k = 0; k < 7; ++k) s += c_gw[k] * hb[wv][r + k][c];
-        bl[wv][r][c] = (uint8_t)((s + 32768) >> 16);
+        for (int q = 0; q < 4; ++q) ht[(4 * k + q) * HT + r] = (uint16_t)s[q];
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    wave_sync();
+    // vertical blur: two output rows (2 rp, 2 rp + 1) of one column per lane and step from the same four words of the
+    // transposed rows (u16 pairs, v_dot2_u32_u16): the odd row only shifts the weights.  Rows 33 / taps past row 38 are
+    // computed from padding and never read.
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    const u16x2 E0 = {18, 33}, E1 = {49, 56}, E2 = {49, 33}, E3 = {18, 0};
+    const u16x2 O0 = {0, 18}, O1 = {33, 49}, O2 = {56, 49}, O3 = {33, 18};
+    for (int e = lane; e < DB * 17; e += 64) {
+        const int c = e / 17, rp = e % 17;
+        const uint32_t *col = reinterpret_cast<const uint32_t *>(ht + (c + sh) * HT) + rp;
+        const u16x2 a0 = __builtin_bit_cast(u16x2, col[0]), a1 = __builtin_bit_cast(u16x2, col[1]),
+                    a2 = __builtin_bit_cast(u16x2, col[2]), a3 = __builtin_bit_cast(u16x2, col[3]);
+        uint32_t se = __builtin_amdgcn_udot2(a0, E0, 32768u, false);
+        se = __builtin_amdgcn_udot2(a1, E1, se, false);
+        se = __builtin_amdgcn_udot2(a2, E2, se, false);
+        se = __builtin_amdgcn_udot2(a3, E3, se, false);
+        uint32_t so = __builtin_amdgcn_udot2(a0, O0, 32768u, false);
+        so = __builtin_amdgcn_udot2(a1, O1, so, false);
+        so = __builtin_amdgcn_udot2(a2, O2, so, false);
+        so = __builtin_amdgcn_udot2(a3, O3, so, false);
+        bl[(2 * rp) * BLP + c] = (uint8_t)(se >> 16);
+        if (2 * rp + 1 < DB) bl[(2 * rp + 1) * BLP + c] = (uint8_t)(so >> 16);
+    }
+    wave_sync();
     // steering: cos = m10 / |m|, sin = m01 / |m| in IEEE f64 (no trig), offsets rounded half-to-even.
     // No FMA contraction here: the CPU oracle must reproduce every rounding (file is built with -ffp-contract=off).
     double cs = 1.0, sn = 0.0;
@@ -600,8 +667,9 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void orb_describe_kernel(OrbGeom g
     uint32_t nib = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int bit = lane * 4 + k;
-        const int8_t *pp = pattern + bit * 4;
+        uint32_t pw = patw[k];
+        asm volatile("" : "+v"(pw));      // not loop invariant as far as the optimiser is concerned
+        const int8_t pp[4] = {(int8_t)pw, (int8_t)(pw >> 8), (int8_t)(pw >> 16), (int8_t)(pw >> 24)};
         int val[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -609,13 +677,17 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void orb_describe_kernel(OrbGeom g
             const double fx = __dsub_rn(__dmul_rn(px, cs), __dmul_rn(py, sn));
             const double fy = __dadd_rn(__dmul_rn(px, sn), __dmul_rn(py, cs));
             const int ix = (int)rint(fx), iy = (int)rint(fy);
-            val[e] = bl[wv][16 + iy][16 + ix];
+            val[e] = bl[(16 + iy) * BLP + 16 + ix];
         }
         nib |= (uint32_t)(val[0] < val[1]) << k;
     }
     // two lanes per byte: low nibble from the even lane
     const uint32_t other = __shfl_xor(nib, 1, 64);
     if ((lane & 1) == 0) desc[o * 32 + (lane >> 1)] = (uint8_t)(nib | (other << 4));
+    if (kp_next >= n_kp) break;
+    kp = kp_next;
+    wave_sync();      // every lane is done with the blurred patch before the next raw patch overwrites it
+    }
 }
 
 // ---- host side geometry ---------------------------------------------------------------------------------------------------
@@ -763,7 +835,7 @@ int mm_orb_detect_compute(mm_ctx *ctx, const uint8_t *imgs, int batch, int heigh
     MM_LAUNCH(ctx, "orb_harris_kernel", orb_harris_kernel, dim3(32, segs), dim3(256), 0, g, imgs, w8);
     MM_LAUNCH(ctx, "orb_rank_kernel", orb_rank_kernel, dim3((g.kcap + 255) / 256, segs), dim3(256), 0, g, w8, kp_xy, kp_meta, kp_resp, n_out);
     if (g.cap_out > 0) {
-        MM_LAUNCH(ctx, "orb_describe_kernel", orb_describe_kernel, dim3((g.cap_out + DESC_WAVES - 1) / DESC_WAVES, batch), dim3(64 * DESC_WAVES), 0, g, imgs, (const uint8_t *)w8, pattern, (const int32_t *)kp_meta, (const int32_t *)n_out, kp_mom, desc);
+        MM_LAUNCH(ctx, "orb_describe_kernel", orb_describe_kernel, dim3((g.cap_out + DESC_WAVES * DESC_KP_PER_WAVE - 1) / (DESC_WAVES * DESC_KP_PER_WAVE), batch), dim3(64 * DESC_WAVES), 0, g, imgs, (const uint8_t *)w8, pattern, (const int32_t *)kp_meta, (const int32_t *)n_out, kp_mom, desc);
     }
     return MM_OK;
 }
