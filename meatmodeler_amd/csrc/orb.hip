@@ -224,7 +224,7 @@ __device__ __forceinline__ void wave_append(bool pass, uint16_t value, uint16_t 
 }
 
 __global__ __launch_bounds__(256) void orb_fast_kernel(OrbGeom g, const uint8_t *__restrict__ imgs,
-                                                       uint8_t *__restrict__ ws, int fast_t, int dbg) {
+                                                       uint8_t *__restrict__ ws, int fast_t) {
     __shared__ __attribute__((aligned(16))) uint8_t P[FP_H][FP_W];
     __shared__ __attribute__((aligned(16))) uint8_t Sc[FS_H][FS_W + 2];
     const int b = blockIdx.y;
@@ -254,7 +254,6 @@ __global__ __launch_bounds__(256) void orb_fast_kernel(OrbGeom g, const uint8_t 
     //   2. survivors: the 16 comparisons and the nine-in-a-row test                                     ~1 % are corners
     //   3. corners: the score (16 arcs of nine), written into the score tile
     //   4. corners again: strict 3 x 3 non-maximum suppression against the score tile -> key points
-    if (dbg & 1) return;
     constexpr int TODO_SEG = ((FS_H + 3) / 4 + 1) * 64;      // rows of a wave + its share of the two right-most columns
     __shared__ uint16_t todo[4 * TODO_SEG];
     uint16_t *corners = todo;
@@ -300,7 +299,6 @@ __global__ __launch_bounds__(256) void orb_fast_kernel(OrbGeom g, const uint8_t 
         if (lane == 0) seg_n[wv] = cnt;
     }
     __syncthreads();
-    if (dbg & 2) return;
     const int pre1 = seg_n[0], pre2 = pre1 + seg_n[1], pre3 = pre2 + seg_n[2], nt = pre3 + seg_n[3];
     for (int i0 = 0; i0 < nt; i0 += 256) {
         const int i = i0 + threadIdx.x;
@@ -316,7 +314,6 @@ __global__ __launch_bounds__(256) void orb_fast_kernel(OrbGeom g, const uint8_t 
         wave_append(kind != 0, (uint16_t)(e | (kind << 14)), corners, &n_corners);   // e < 4356 < 2^13
     }
     __syncthreads();
-    if (dbg & 4) return;
     const int nc = n_corners;
     for (int i = threadIdx.x; i < nc; i += 256) {
         const int e = corners[i] & 0x3FFF, kind = corners[i] >> 14;
@@ -352,13 +349,13 @@ __global__ __launch_bounds__(256) void orb_fast_kernel(OrbGeom g, const uint8_t 
     }
     __syncthreads();
     const int nloc = lcount;
-    if (nloc == 0 || (dbg & 8)) return;
+    if (nloc == 0) return;
     const int seg = b * g.nlevels + l;
     int32_t *cnt = reinterpret_cast<int32_t *>(ws + g.cnt_off) + seg;
     int32_t *hist = reinterpret_cast<int32_t *>(ws + g.hist_off) + (size_t)seg * 256;
     uint32_t *cand = reinterpret_cast<uint32_t *>(ws + g.cand_off[l]) + (size_t)b * g.cand_cap[l];
     if (threadIdx.x == 0) lbase = atomicAdd(cnt, nloc);
-    if (lhist[threadIdx.x] && !(dbg & 16)) atomicAdd(&hist[threadIdx.x], lhist[threadIdx.x]);
+    if (lhist[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lhist[threadIdx.x]);
     __syncthreads();
     const int base = lbase;
     for (int e = threadIdx.x; e < nloc; e += 256)
@@ -828,7 +825,7 @@ int mm_orb_detect_compute(mm_ctx *ctx, const uint8_t *imgs, int batch, int heigh
         }
     }
     if (g.tile_start[g.nlevels] > 0) {
-        MM_LAUNCH(ctx, "orb_fast_kernel", orb_fast_kernel, dim3(g.tile_start[g.nlevels], batch), dim3(256), 0, g, imgs, w8, prm->fast_threshold, getenv("MM_ORB_DBG") ? atoi(getenv("MM_ORB_DBG")) : 0);
+        MM_LAUNCH(ctx, "orb_fast_kernel", orb_fast_kernel, dim3(g.tile_start[g.nlevels], batch), dim3(256), 0, g, imgs, w8, prm->fast_threshold);
     }
     const int segs = batch * g.nlevels;
     MM_LAUNCH(ctx, "orb_select_kernel", orb_select_kernel, dim3(segs), dim3(256), 0, g, w8);
