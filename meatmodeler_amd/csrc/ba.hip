@@ -21,19 +21,17 @@ namespace {
 
 // ---- residual + cost ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ba_residual_kernel(mm_ba_problem pb, const double *__restrict__ cams,
-                                                          const double *__restrict__ pts, double *__restrict__ res,
+                                                          const double *__restrict__ pts, const CamCoef *__restrict__ ctab, double *__restrict__ res,
                                                           double *__restrict__ partial) {
     __shared__ double sm[4];
     __shared__ double Ks[9];
-    __shared__ CamCoef ctab[COEF_MAX_F];
     if (threadIdx.x < 9) Ks[threadIdx.x] = pb.K[threadIdx.x];
-    const bool use_tab = coef_table_fill(ctab, cams, pb.F);
     __syncthreads();
     double acc = 0;
     for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < pb.O; o += (int64_t)gridDim.x * 256) {
         Proj pr;
         const int f = pb.fi[o];
-        ba_eval_cc<false, false>(cams + (size_t)f * 6, use_tab ? ctab[f] : cam_coef_of(cams + (size_t)f * 6),
+        ba_eval_cc<false, false>(cams + (size_t)f * 6, ctab[f],
                                  pts + (size_t)pb.pi[o] * 3, Ks, pb.obs[2 * o], pb.obs[2 * o + 1], pr);
         if (res) {
             res[2 * o] = pr.r0;
@@ -56,18 +54,16 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const double *__restr
 
 // ---- analytic Jacobian blocks (parity surface) --------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ba_jacobian_kernel(mm_ba_problem pb, const double *__restrict__ cams,
-                                                          const double *__restrict__ pts, double *__restrict__ Jc,
+                                                          const double *__restrict__ pts, const CamCoef *__restrict__ ctab, double *__restrict__ Jc,
                                                           double *__restrict__ Jp) {
     __shared__ double Ks[9];
-    __shared__ CamCoef ctab[COEF_MAX_F];
     if (threadIdx.x < 9) Ks[threadIdx.x] = pb.K[threadIdx.x];
-    const bool use_tab = coef_table_fill(ctab, cams, pb.F);
     __syncthreads();
     int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (o >= pb.O) return;
     Proj pr;
     const int f = pb.fi[o];
-    ba_eval_cc<true, true>(cams + (size_t)f * 6, use_tab ? ctab[f] : cam_coef_of(cams + (size_t)f * 6),
+    ba_eval_cc<true, true>(cams + (size_t)f * 6, ctab[f],
                            pts + (size_t)pb.pi[o] * 3, Ks, pb.obs[2 * o], pb.obs[2 * o + 1], pr);
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
@@ -83,12 +79,10 @@ __global__ __launch_bounds__(256) void ba_jacobian_kernel(mm_ba_problem pb, cons
 
 // ---- point blocks: C[P,6] (upper triangle) and gp[P,3]; one thread per point, its observations are contiguous ------
 __global__ __launch_bounds__(256) void ba_point_blocks_kernel(mm_ba_problem pb, const double *__restrict__ cams,
-                                                              const double *__restrict__ pts, double *__restrict__ C,
+                                                              const double *__restrict__ pts, const CamCoef *__restrict__ ctab, double *__restrict__ C,
                                                               double *__restrict__ gp) {
     __shared__ double Ks[9];
-    __shared__ CamCoef ctab[COEF_MAX_F];
     if (threadIdx.x < 9) Ks[threadIdx.x] = pb.K[threadIdx.x];
-    const bool use_tab = coef_table_fill(ctab, cams, pb.F);
     __syncthreads();
     int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= pb.P) return;
@@ -98,7 +92,7 @@ __global__ __launch_bounds__(256) void ba_point_blocks_kernel(mm_ba_problem pb, 
         int o = pb.pt_obs[e];
         Proj pr;
         const int f = pb.fi[o];
-        ba_eval_cc<false, true>(cams + (size_t)f * 6, use_tab ? ctab[f] : cam_coef_of(cams + (size_t)f * 6), Xp, Ks,
+        ba_eval_cc<false, true>(cams + (size_t)f * 6, ctab[f], Xp, Ks,
                                 pb.obs[2 * (size_t)o], pb.obs[2 * (size_t)o + 1], pr);
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
@@ -163,18 +157,16 @@ __global__ __launch_bounds__(256) void ba_camera_blocks_kernel(mm_ba_problem pb,
 
 // ---- out = Jc wc[fi] + Jp wp[pi] ----------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ba_jvp_kernel(mm_ba_problem pb, const double *__restrict__ cams,
-                                                     const double *__restrict__ pts, const double *__restrict__ wc,
+                                                     const double *__restrict__ pts, const CamCoef *__restrict__ ctab, const double *__restrict__ wc,
                                                      const double *__restrict__ wp, double *__restrict__ out) {
     __shared__ double Ks[9];
-    __shared__ CamCoef ctab[COEF_MAX_F];
     if (threadIdx.x < 9) Ks[threadIdx.x] = pb.K[threadIdx.x];
-    const bool use_tab = coef_table_fill(ctab, cams, pb.F);
     __syncthreads();
     int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (o >= pb.O) return;
     const int f = pb.fi[o], p = pb.pi[o];
     Proj pr;
-    ba_eval_cc<true, true>(cams + (size_t)f * 6, use_tab ? ctab[f] : cam_coef_of(cams + (size_t)f * 6),
+    ba_eval_cc<true, true>(cams + (size_t)f * 6, ctab[f],
                            pts + (size_t)p * 3, Ks, pb.obs[2 * o], pb.obs[2 * o + 1], pr);
     double y0 = 0, y1 = 0;
     if (wc) {
@@ -203,21 +195,19 @@ __global__ __launch_bounds__(256) void ba_jvp_kernel(mm_ba_problem pb, const dou
 // two vector passes less per iteration.  Deterministic: fixed tree per workgroup, then one small launch adds the
 // per-workgroup partials in index order.
 __global__ __launch_bounds__(256) void ba_jvp_dots_kernel(mm_ba_problem pb, const double *__restrict__ cams,
-                                                          const double *__restrict__ pts, const double *__restrict__ wc,
+                                                          const double *__restrict__ pts, const CamCoef *__restrict__ ctab, const double *__restrict__ wc,
                                                           const double *__restrict__ wp, double *__restrict__ out,
                                                           const double *__restrict__ other, double *__restrict__ partial) {
     __shared__ double Ks[9];
-    __shared__ CamCoef ctab[COEF_MAX_F];
     __shared__ double sm[(256 / 64) * 2];
     if (threadIdx.x < 9) Ks[threadIdx.x] = pb.K[threadIdx.x];
-    const bool use_tab = coef_table_fill(ctab, cams, pb.F);
     __syncthreads();
     const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
     double acc[2] = {0.0, 0.0};
     if (o < pb.O) {
         const int f = pb.fi[o], p = pb.pi[o];
         Proj pr;
-        ba_eval_cc<true, true>(cams + (size_t)f * 6, use_tab ? ctab[f] : cam_coef_of(cams + (size_t)f * 6),
+        ba_eval_cc<true, true>(cams + (size_t)f * 6, ctab[f],
                                pts + (size_t)p * 3, Ks, pb.obs[2 * o], pb.obs[2 * o + 1], pr);
         double y0 = 0, y1 = 0;
         if (wc) {
@@ -270,13 +260,11 @@ __global__ __launch_bounds__(256) void jvp_rows_kernel(const double *__restrict_
 
 // ---- back-substitution: dp = Cinv (gp - sum_o Jp_o^T (Jc_o dc[f_o])) ------------------------------------------------
 __global__ __launch_bounds__(256) void ba_backsub_kernel(mm_ba_problem pb, const double *__restrict__ cams,
-                                                         const double *__restrict__ pts,
+                                                         const double *__restrict__ pts, const CamCoef *__restrict__ ctab,
                                                          const double *__restrict__ Cinv, const double *__restrict__ gp,
                                                          const double *__restrict__ dc, double *__restrict__ dp) {
     __shared__ double Ks[9];
-    __shared__ CamCoef ctab[COEF_MAX_F];
     if (threadIdx.x < 9) Ks[threadIdx.x] = pb.K[threadIdx.x];
-    const bool use_tab = coef_table_fill(ctab, cams, pb.F);
     __syncthreads();
     int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= pb.P) return;
@@ -286,7 +274,7 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(mm_ba_problem pb, const
         int o = pb.pt_obs[e];
         int f = pb.fi[o];
         Proj pr;
-        ba_eval_cc<true, true>(cams + (size_t)f * 6, use_tab ? ctab[f] : cam_coef_of(cams + (size_t)f * 6), Xp, Ks,
+        ba_eval_cc<true, true>(cams + (size_t)f * 6, ctab[f], Xp, Ks,
                                pb.obs[2 * (size_t)o], pb.obs[2 * (size_t)o + 1], pr);
         double s0 = 0, s1 = 0;
 #pragma unroll
@@ -303,6 +291,14 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(mm_ba_problem pb, const
     dp[(size_t)p * 3] = c[0] * t0 + c[1] * t1 + c[2] * t2;
     dp[(size_t)p * 3 + 1] = c[1] * t0 + c[3] * t1 + c[4] * t2;
     dp[(size_t)p * 3 + 2] = c[2] * t0 + c[4] * t1 + c[5] * t2;
+}
+
+// ---- rotation coefficients of every camera, once per parameter vector ------------------------------------------------
+// (Every workgroup of every sweep used to fill its own LDS copy: two sincos per thread -- more arithmetic than the
+// observations it then processed -- and 40 KB of LDS.  Now: one small launch per NEW camera vector, gathers from L2.)
+__global__ __launch_bounds__(256) void cam_coef_kernel(const double *__restrict__ cams, int F, CamCoef *__restrict__ tab) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f < F) tab[f] = cam_coef_of(cams + (size_t)f * 6);
 }
 
 int check_pb(mm_ctx *ctx, const mm_ba_problem *pb, const char *who) {
@@ -335,6 +331,43 @@ __global__ void trf_damping_kernel(const double *__restrict__ gh2, const double 
 
 }  // namespace
 
+// The table lives in the context.  `cam_tab_for` remembers which camera vector it was computed from; a caller that
+// knows the vector has not changed since (the library's own trust-region loop, trf.hip) keeps it valid with
+// mm_cam_table_hold() and the sweeps then skip the launch.  Everybody else gets a fresh table per call.
+int mm_cam_coef_table(mm_ctx *ctx, const double *cams, int F, const void **tab_out) {
+    if (F > ctx->cam_tab_cap) {
+        if (ctx->cam_tab) (void)hipFree(ctx->cam_tab);
+        ctx->cam_tab = nullptr;
+        ctx->cam_tab_cap = 0;
+        const int cap = F < 1024 ? 1024 : F + F / 2;
+        MM_HIP(ctx, hipMalloc(&ctx->cam_tab, (size_t)cap * sizeof(CamCoef)));
+        ctx->cam_tab_cap = cap;
+        ctx->cam_tab_for = nullptr;
+    }
+    if (!(ctx->cam_tab_hold && ctx->cam_tab_for == cams && ctx->cam_tab_F == F)) {
+        if (F > 0)
+            MM_LAUNCH(ctx, "cam_coef_kernel", cam_coef_kernel, dim3((F + 255) / 256), dim3(256), 0, cams, F, (CamCoef *)ctx->cam_tab);
+        ctx->cam_tab_for = cams;
+        ctx->cam_tab_F = F;
+    }
+    *tab_out = ctx->cam_tab;
+    return MM_OK;
+}
+void mm_cam_table_hold(mm_ctx *ctx, bool on) {
+    ctx->cam_tab_hold = on;
+    if (!on) ctx->cam_tab_for = nullptr;
+}
+void mm_cam_table_invalidate(mm_ctx *ctx) { ctx->cam_tab_for = nullptr; }
+
+#define MM_CAM_TABLE(ctx, pb, cams)                                               \
+    const CamCoef *ctab = nullptr;                                                \
+    do {                                                                          \
+        const void *t_ = nullptr;                                                 \
+        int rc_ = mm_cam_coef_table(ctx, cams, (pb)->F, &t_);                     \
+        if (rc_) return rc_;                                                      \
+        ctab = (const CamCoef *)t_;                                               \
+    } while (0)
+
 extern "C" {
 
 int mm_ba_residual(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, const double *pts, double *res,
@@ -345,7 +378,8 @@ int mm_ba_residual(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, con
     if (!ws || ws_bytes < RES_BLOCKS * sizeof(double)) return mm_fail(ctx, MM_ERR_WORKSPACE, "mm_ba_residual: workspace < 16 KiB");
     int64_t nb = (pb->O + 255) / 256;
     int blocks = (int)(nb < 1 ? 1 : (nb > RES_BLOCKS ? RES_BLOCKS : nb));
-    MM_LAUNCH(ctx, "ba_residual_kernel", ba_residual_kernel, dim3(blocks), dim3(256), 0, *pb, cams, pts, res, (double *)ws);
+    MM_CAM_TABLE(ctx, pb, cams);
+    MM_LAUNCH(ctx, "ba_residual_kernel", ba_residual_kernel, dim3(blocks), dim3(256), 0, *pb, cams, pts, ctab, res, (double *)ws);
     MM_LAUNCH(ctx, "sum_partials_kernel", sum_partials_kernel, dim3(1), dim3(256), 0, (const double *)ws, blocks, cost2);
     return MM_OK;
 }
@@ -355,7 +389,8 @@ int mm_ba_jacobian(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, con
     if (rc) return rc;
     if (!cams || !pts || !Jc || !Jp) return mm_fail(ctx, MM_ERR_ARG, "mm_ba_jacobian: null pointer");
     if (pb->O == 0) return MM_OK;
-    MM_LAUNCH(ctx, "ba_jacobian_kernel", ba_jacobian_kernel, dim3((unsigned)((pb->O + 255) / 256)), dim3(256), 0, *pb, cams, pts, Jc, Jp);
+    MM_CAM_TABLE(ctx, pb, cams);
+    MM_LAUNCH(ctx, "ba_jacobian_kernel", ba_jacobian_kernel, dim3((unsigned)((pb->O + 255) / 256)), dim3(256), 0, *pb, cams, pts, ctab, Jc, Jp);
     return MM_OK;
 }
 
@@ -369,7 +404,8 @@ int mm_ba_normal_eq(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, co
     if (C) {
         if (!pb->pt_ptr || !pb->pt_obs) return mm_fail(ctx, MM_ERR_ARG, "mm_ba_normal_eq: point CSR missing");
         if (pb->P > 0) {
-            MM_LAUNCH(ctx, "ba_point_blocks_kernel", ba_point_blocks_kernel, dim3((pb->P + 255) / 256), dim3(256), 0, *pb, cams, pts, C, gp);
+            MM_CAM_TABLE(ctx, pb, cams);
+            MM_LAUNCH(ctx, "ba_point_blocks_kernel", ba_point_blocks_kernel, dim3((pb->P + 255) / 256), dim3(256), 0, *pb, cams, pts, ctab, C, gp);
         }
     }
     if (B) {
@@ -387,7 +423,8 @@ int mm_ba_jvp(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, const do
     if (rc) return rc;
     if (!cams || !pts || !out) return mm_fail(ctx, MM_ERR_ARG, "mm_ba_jvp: null pointer");
     if (pb->O == 0) return MM_OK;
-    MM_LAUNCH(ctx, "ba_jvp_kernel", ba_jvp_kernel, dim3((unsigned)((pb->O + 255) / 256)), dim3(256), 0, *pb, cams, pts, wc, wp, out);
+    MM_CAM_TABLE(ctx, pb, cams);
+    MM_LAUNCH(ctx, "ba_jvp_kernel", ba_jvp_kernel, dim3((unsigned)((pb->O + 255) / 256)), dim3(256), 0, *pb, cams, pts, ctab, wc, wp, out);
     return MM_OK;
 }
 
@@ -408,7 +445,8 @@ int mm_ba_jvp_dots(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, con
         return MM_OK;
     }
     const unsigned n_wg = (unsigned)((pb->O + 255) / 256);
-    MM_LAUNCH(ctx, "ba_jvp_kernel", ba_jvp_dots_kernel, dim3(n_wg), dim3(256), 0, *pb, cams, pts, wc, wp, out, other,
+    MM_CAM_TABLE(ctx, pb, cams);
+    MM_LAUNCH(ctx, "ba_jvp_kernel", ba_jvp_dots_kernel, dim3(n_wg), dim3(256), 0, *pb, cams, pts, ctab, wc, wp, out, other,
               (double *)((char *)ws + 256));
     MM_LAUNCH(ctx, "jvp_rows_kernel", jvp_rows_kernel, dim3(1), dim3(256), 0, (const double *)((char *)ws + 256), n_wg, rows);
     return MM_OK;
@@ -421,7 +459,8 @@ int mm_ba_backsub(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, cons
     if (!cams || !pts || !Cinv || !gp || !dc || !dp || !pb->pt_ptr || !pb->pt_obs)
         return mm_fail(ctx, MM_ERR_ARG, "mm_ba_backsub: null pointer");
     if (pb->P == 0) return MM_OK;
-    MM_LAUNCH(ctx, "ba_backsub_kernel", ba_backsub_kernel, dim3((pb->P + 255) / 256), dim3(256), 0, *pb, cams, pts, Cinv, gp, dc, dp);
+    MM_CAM_TABLE(ctx, pb, cams);
+    MM_LAUNCH(ctx, "ba_backsub_kernel", ba_backsub_kernel, dim3((pb->P + 255) / 256), dim3(256), 0, *pb, cams, pts, ctab, Cinv, gp, dc, dp);
     return MM_OK;
 }
 

@@ -25,6 +25,11 @@ struct mm_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // one-time kernel attributes (dynamic LDS opt-in) are per device: remembered per context, not per process
     bool attr_chol_fused = false, attr_chol_bwd = false;
+    // rotation coefficients of the cameras the BA sweeps were last called with (ba.hip: mm_cam_coef_table)
+    void *cam_tab = nullptr;
+    int cam_tab_cap = 0, cam_tab_F = 0;
+    const double *cam_tab_for = nullptr;
+    bool cam_tab_hold = false;
 };
 
 // launches of the enclosed scope go to another stream of the context
@@ -34,6 +39,11 @@ struct mm_stream_swap {
     mm_stream_swap(mm_ctx *ctx, hipStream_t s) : c(ctx), saved(ctx->stream) { ctx->stream = s; }
     ~mm_stream_swap() { c->stream = saved; }
 };
+
+// ba.hip: per-camera rotation coefficients shared by the sweeps (see there)
+int mm_cam_coef_table(mm_ctx *ctx, const double *cams, int F, const void **tab_out);
+void mm_cam_table_hold(mm_ctx *ctx, bool on);       // on: the table stays valid for the same camera pointer until ...
+void mm_cam_table_invalidate(mm_ctx *ctx);          // ... the caller says the vector behind it changed
 
 // chol.hip internals used by the overlapped Schur + solve entry point (schur.hip)
 bool mm_chol_fused_eligible(int n, int half_bandwidth);

@@ -28,6 +28,7 @@ void mm_ctx_destroy(mm_ctx *ctx) {
         (void)hipEventDestroy(r.b);
     }
     for (auto e : ctx->pool) (void)hipEventDestroy(e);
+    if (ctx->cam_tab) (void)hipFree(ctx->cam_tab);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->aux) (void)hipStreamDestroy(ctx->aux);

@@ -127,6 +127,13 @@ extern "C" int mm_ba_trf(mm_ctx *ctx, const mm_ba_problem *pb, double *cams, dou
     if (!ws || ws_bytes < mm_ba_trf_workspace_bytes(pb) || ((uintptr_t)ws & 255))
         return mm_fail(ctx, MM_ERR_WORKSPACE, "mm_ba_trf: workspace too small or misaligned");
     const TrfWs t = carve_trf(pb, ws);
+    // the sweeps share one table of per-camera rotation coefficients: this loop knows when the camera vector behind a
+    // pointer changes (only the trial point is ever rewritten), so the table is rebuilt once per trial point
+    struct TableHold {
+        mm_ctx *c;
+        explicit TableHold(mm_ctx *ctx) : c(ctx) { mm_cam_table_hold(c, true); }
+        ~TableHold() { mm_cam_table_hold(c, false); }
+    } table_hold(ctx);
     const int F = pb->F, P = pb->P;
     const int64_t nc = 6 * (int64_t)F, n = nc + 3 * (int64_t)P;
     hipStream_t st = ctx->stream;
@@ -198,6 +205,7 @@ extern "C" int mm_ba_trf(mm_ctx *ctx, const mm_ba_problem *pb, double *cams, dou
             double *outv[1] = {x_new};
             const double *sc[1] = {t.board};
             TRF_CALL(mm_trf_fused(ctx, 5, in, outv, sc, 0, 0, n, nc, nullptr, t.ws_md, t.ws_md_b));
+            mm_cam_table_invalidate(ctx);      // x_new has new contents
             TRF_CALL(mm_ba_residual(ctx, pb, cams_of(x_new), pts_of(x_new), nullptr, t.board + 14, t.ws_res, t.ws_res_b));
             return read_board(t.board, 16);   // ---- the host sync of a trial step ----
         };

@@ -12,4 +12,5 @@ cp gpurun_out/pmc_WRITE_SIZE_summary.txt profiles/${R}_pmc_write_size.txt
 python3 tools/pmc_to_json.py profiles/${R}_pmc_fetch_size.txt profiles/${R}_pmc_write_size.txt profiles/${R}_pmc_traffic.json
 cp "$(newest gpurun_out/prof_chol '*kernel_stats.csv')" profiles/${R}_chol_kernel_stats.csv
 cp gpurun_out/trace_gaps.txt profiles/${R}_trace_gaps.txt
+grep -v rocprofv3 gpurun_out/orb_kernels.txt > profiles/${R}_orb_kernels.txt
 ls -la profiles | tail -n +2

@@ -31,3 +31,4 @@ head -14 $ROOT/gpurun_out/pmc_FETCH_SIZE_summary.txt
 unset MM_SCHUR_OVERLAP
 cd $ROOT && ./tools/prof_chol.sh > gpurun_out/prof_chol_summary.txt 2>&1; tail -4 gpurun_out/prof_chol_summary.txt | cut -c1-160
 cd $ROOT && ./tools/gpu_trace.sh > gpurun_out/trace_summary.txt 2>&1; head -4 gpurun_out/trace_summary.txt
+cd $ROOT && ./tools/dev/orb_stats.sh > gpurun_out/orb_kernels.txt 2>&1; tail -8 gpurun_out/orb_kernels.txt
