@@ -234,9 +234,12 @@ int mm_trf_fused(mm_ctx *ctx, int op, const double *const *in, double *const *ou
  * bundleAdjuster.py:180-192): gh2 = |g_h|^2, d11 = |J_h g_h|^2 (device scalars), Delta the radius.
  * out [2] dev = {reg, max(reg, min_damping)}. */
 int mm_trf_damping(mm_ctx *ctx, const double *gh2, const double *d11, double Delta, double min_damping, double *out);
-/* dp [P,3] = Cinv (gp - E^T dc). */
+/* dp [P,3] = Cinv (gp - E^T dc).  With a workspace (mm_ba_backsub_workspace_bytes: 24 bytes per observation) the work is
+ * spread over the observations and added per point in a second pass -- a launch with one thread per point waits for the
+ * longest tracks; ws == NULL keeps that one-launch form.  Both are deterministic. */
+size_t mm_ba_backsub_workspace_bytes(const mm_ba_problem *pb);
 int mm_ba_backsub(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, const double *pts, const double *Cinv,
-                  const double *gp, const double *dc /*dev [F,6]*/, double *dp);
+                  const double *gp, const double *dc /*dev [F,6]*/, double *dp, void *ws /*dev|NULL*/, size_t ws_bytes);
 /* mm_ba_schur followed by mm_chol_solve(S, 6F, v, 1, half_bandwidth), overlapped: S is built in n_slabs ascending camera
  * slabs (slab s = cameras [s, s+1) * cams_per_slab; slab_seg_ptr / slab_chunk_ptr: HOST arrays [n_slabs+1] with the first
  * segment / chunk of each slab) on the context's stream while the single-launch banded factorisation runs on a second

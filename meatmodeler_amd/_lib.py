@@ -98,7 +98,8 @@ SIGNATURES = {
     "mm_trf_fused": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.c_double, C.c_double, C.c_int64,
                                C.c_int64, vp, vp, C.c_size_t]),
     "mm_trf_damping": (C.c_int, [vp, vp, vp, C.c_double, C.c_double, vp]),
-    "mm_ba_backsub": (C.c_int, [vp, C.POINTER(BAProblem), vp, vp, vp, vp, vp, vp]),
+    "mm_ba_backsub": (C.c_int, [vp, C.POINTER(BAProblem), vp, vp, vp, vp, vp, vp, vp, C.c_size_t]),
+    "mm_ba_backsub_workspace_bytes": (C.c_size_t, [C.POINTER(BAProblem)]),
     "mm_chol_workspace_bytes": (C.c_size_t, [C.c_int]),
     "mm_chol_solve": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, C.c_size_t]),
     "mm_ba_jvp_dots_workspace_bytes": (C.c_size_t, [C.POINTER(BAProblem)]),

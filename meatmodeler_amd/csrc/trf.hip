@@ -37,8 +37,8 @@ struct TrfWs {
     double *B, *Bd, *C, *Cd, *Cinv, *u1, *Jq2, *dp, *v, *S;
     double *r0, *r1, *r2, *r3, *d11, *bs, *damp, *board, *cost2, *rowsx;
     int32_t *info;
-    void *ws_res, *ws_md, *ws_jvp, *ws_schur, *ws_chol;
-    size_t ws_res_b, ws_md_b, ws_jvp_b, ws_schur_b, ws_chol_b;
+    void *ws_res, *ws_md, *ws_jvp, *ws_schur, *ws_chol, *ws_back;
+    size_t ws_res_b, ws_md_b, ws_jvp_b, ws_schur_b, ws_chol_b, ws_back_b;
     size_t total;
 };
 
@@ -80,6 +80,8 @@ TrfWs carve_trf(const mm_ba_problem *pb, void *base) {
     t.ws_schur = c.take<char>(t.ws_schur_b);
     t.ws_chol_b = mm_chol_workspace_bytes((int)nc);
     t.ws_chol = c.take<char>(t.ws_chol_b);
+    t.ws_back_b = mm_ba_backsub_workspace_bytes(pb);
+    t.ws_back = c.take<char>(t.ws_back_b);
     t.total = c.used;
     return t;
 }
@@ -213,7 +215,7 @@ extern "C" int mm_ba_trf(mm_ctx *ctx, const mm_ba_problem *pb, double *cams, dou
             TRF_CALL(mm_ba_damp(ctx, F, P, t.B, t.C, t.si, reg_eff, t.Bd, t.Cd));
             TRF_CALL(mm_ba_schur_solve(ctx, pb, cams_of(x), pts_of(x), t.Bd, t.Cd, cams_of(t.g), pts_of(t.g), t.S, t.v, t.Cinv, half_bw,
                                        t.info, t.ws_schur, t.ws_schur_b, t.ws_chol, t.ws_chol_b, 0, 0, nullptr, nullptr));
-            TRF_CALL(mm_ba_backsub(ctx, pb, cams_of(x), pts_of(x), t.Cinv, pts_of(t.g), t.v, t.dp));
+            TRF_CALL(mm_ba_backsub(ctx, pb, cams_of(x), pts_of(x), t.Cinv, pts_of(t.g), t.v, t.dp, t.ws_back, t.ws_back_b));
             {
                 const double *in[4] = {t.v, t.dp, t.si, t.gh};
                 double *outv[2] = {t.gn, t.q1};

@@ -491,8 +491,11 @@ class BADevice:
 
     def backsub(self, cams, pts, Cinv, gp, dc):
         dp = torch.empty((self.P, 3), dtype=torch.float64, device=self.device)
+        if getattr(self, "_backsub_ws", None) is None:
+            self._backsub_ws = torch.empty(lib.mm_ba_backsub_workspace_bytes(C.byref(self.pb)), dtype=torch.uint8,
+                                           device=self.device)
         self.ctx.check(lib.mm_ba_backsub(self.ctx.h, C.byref(self.pb), ptr(cams), ptr(pts), ptr(Cinv), ptr(gp), ptr(dc),
-                                         ptr(dp)), "mm_ba_backsub")
+                                         ptr(dp), ptr(self._backsub_ws), self._backsub_ws.numel()), "mm_ba_backsub")
         return dp
 
 
