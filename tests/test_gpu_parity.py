@@ -325,6 +325,15 @@ def test_ba_normal_equations_jvp_schur_backsub_consistent():
     dp = pb.backsub(cd, pd, Cinv, gp, dc)
     got = np.concatenate([dc.cpu().numpy().ravel(), dp.cpu().numpy().ravel()])
     np.testing.assert_allclose(got, sol, rtol=1e-6, atol=1e-9 * np.abs(sol).max())
+    # the back-substitution over observations (workspace given: what pb.backsub calls) and the one-launch form with a
+    # thread per point (ws = NULL) are the same sums in the same order
+    from meatmodeler_amd._lib import lib, ptr
+    import ctypes as C
+    dp1 = torch.empty_like(dp)
+    pb.ctx.check(lib.mm_ba_backsub(pb.ctx.h, C.byref(pb.pb), ptr(cd), ptr(pd), ptr(Cinv), ptr(gp), ptr(dc), ptr(dp1), None, 0),
+                 "mm_ba_backsub")
+    np.testing.assert_allclose(dp1.cpu().numpy(), dp.cpu().numpy(), rtol=1e-12, atol=1e-14 * float(dp.abs().max()))
+    assert torch.equal(pb.backsub(cd, pd, Cinv, gp, dc), dp)          # reproducible
 
 
 def test_ba_full_size_adjoint_and_reduced_system_properties():
