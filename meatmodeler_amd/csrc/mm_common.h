@@ -30,6 +30,10 @@ struct mm_ctx {
     int cam_tab_cap = 0, cam_tab_F = 0;
     const double *cam_tab_for = nullptr;
     bool cam_tab_hold = false;
+    // pinned, device-visible host mailbox of mm_ba_trf (trf.hip): the trial-step scalars are written into it by a kernel
+    // and the host spins on its sequence number instead of paying a copy + stream synchronisation per trial step
+    void *host_board = nullptr;
+    unsigned long long host_board_seq = 0;
 };
 
 // launches of the enclosed scope go to another stream of the context

@@ -29,6 +29,7 @@ void mm_ctx_destroy(mm_ctx *ctx) {
     }
     for (auto e : ctx->pool) (void)hipEventDestroy(e);
     if (ctx->cam_tab) (void)hipFree(ctx->cam_tab);
+    if (ctx->host_board) (void)hipHostFree(ctx->host_board);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->aux) (void)hipStreamDestroy(ctx->aux);

@@ -10,7 +10,9 @@
 // 16-double board copied to the host after the trial cost is known).  Everything lives in the caller's workspace; no
 // allocation, no second stream unless the overlapped build is requested.
 #include "mm_common.h"
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 
 namespace {
 
@@ -18,6 +20,22 @@ __global__ __launch_bounds__(256) void vec_mul_kernel(const double *__restrict__
                                                       double *__restrict__ out, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) out[i] = a[i] * b[i];
+}
+
+// The scalars the host needs after a trial step go through a pinned host mailbox: this kernel copies them there and then
+// raises the sequence number (system scope); the host spins on that word.  Compared with hipMemcpyAsync +
+// hipStreamSynchronize (interrupt-driven wake-up) the gap between two iterations shrinks from ~30 us to the launch latency.
+struct HostBoard {
+    double v[16];
+    unsigned long long seq;
+};
+
+__global__ __launch_bounds__(64) void board_publish_kernel(const double *__restrict__ dev, int count, HostBoard *hb,
+                                                          unsigned long long seq) {
+    if ((int)threadIdx.x < count) hb->v[threadIdx.x] = dev[threadIdx.x];
+    __threadfence_system();
+    __builtin_amdgcn_wave_barrier();
+    if (threadIdx.x == 0) __hip_atomic_store(&hb->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 struct Carve {
@@ -149,9 +167,34 @@ extern "C" int mm_ba_trf(mm_ctx *ctx, const mm_ba_problem *pb, double *cams, dou
     MM_HIP(ctx, hipMemcpyAsync(x, cams, (size_t)nc * sizeof(double), hipMemcpyDeviceToDevice, st));
     if (P) MM_HIP(ctx, hipMemcpyAsync(x + nc, pts, (size_t)3 * P * sizeof(double), hipMemcpyDeviceToDevice, st));
     double host[16];
+    static const bool spin = !(getenv("MM_TRF_SPIN") && getenv("MM_TRF_SPIN")[0] == '0');
+    if (spin && !ctx->host_board) {
+        MM_HIP(ctx, hipHostMalloc(&ctx->host_board, sizeof(HostBoard), hipHostMallocDefault));
+        memset(ctx->host_board, 0, sizeof(HostBoard));
+        ctx->host_board_seq = 0;
+    }
     auto read_board = [&](const double *dev, int count) -> int {
-        MM_HIP(ctx, hipMemcpyAsync(host, dev, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, st));
-        MM_HIP(ctx, hipStreamSynchronize(st));
+        if (!spin) {
+            MM_HIP(ctx, hipMemcpyAsync(host, dev, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, st));
+            MM_HIP(ctx, hipStreamSynchronize(st));
+            return MM_OK;
+        }
+        HostBoard *hb = (HostBoard *)ctx->host_board;
+        const unsigned long long seq = ++ctx->host_board_seq;
+        hipLaunchKernelGGL(board_publish_kernel, dim3(1), dim3(64), 0, st, dev, count, hb, seq);
+        MM_LAUNCH_CHECK(ctx, "board_publish_kernel");
+        const auto t0 = std::chrono::steady_clock::now();
+        unsigned long spins = 0;
+        while (__atomic_load_n(&hb->seq, __ATOMIC_ACQUIRE) != seq) {
+            __builtin_ia32_pause();
+            if ((++spins & 0xFFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
+                // never seen: a failed launch upstream -- let the runtime report it
+                MM_HIP(ctx, hipStreamSynchronize(st));
+                if (__atomic_load_n(&hb->seq, __ATOMIC_ACQUIRE) != seq)
+                    return mm_fail(ctx, MM_ERR_HIP, "mm_ba_trf: the trial-step scalars never arrived");
+            }
+        }
+        for (int i = 0; i < count; ++i) host[i] = ((volatile double *)hb->v)[i];
         return MM_OK;
     };
     // initial cost
