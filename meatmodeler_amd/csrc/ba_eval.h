@@ -11,8 +11,8 @@ struct Proj {
     double Jp[2][3];        // d r / d X
 };
 
-// Rotation coefficients of one camera: they depend on the camera only, so the sweeps take them from a per-workgroup
-// LDS table (or compute them once per wave) instead of paying a sincos, a sqrt and four divisions per observation.
+// Rotation coefficients of one camera: they depend on the camera only, so the sweeps take them from a table computed
+// once per camera vector (ba.hip: cam_coef_kernel) instead of paying a sincos, a sqrt and four divisions per observation.
 struct CamCoef {
     double c, a, b, a1, b1;  // cos, sin/th, (1-cos)/th^2, (th cos - sin)/th^3, (th sin - 2(1-cos))/th^4
 };
@@ -39,15 +39,6 @@ __device__ __forceinline__ CamCoef cam_coef_of(const double *__restrict__ cam) {
         k.b1 = (th * s - 2.0 * omc) / (th2 * th2);
     }
     return k;
-}
-
-constexpr int COEF_MAX_F = 1024;  // cameras whose coefficients fit the per-workgroup LDS table (40 KB)
-
-// All threads of the workgroup call this, then __syncthreads().  Returns false (table unused) for F > COEF_MAX_F.
-__device__ __forceinline__ bool coef_table_fill(CamCoef *tab, const double *__restrict__ cams, int F) {
-    if (F > COEF_MAX_F) return false;
-    for (int f = threadIdx.x; f < F; f += blockDim.x) tab[f] = cam_coef_of(cams + (size_t)f * 6);
-    return true;
 }
 
 // Camera parameters + rotation coefficients held as VALUES (11 doubles).  A wave that works on one camera makes them

@@ -327,17 +327,212 @@ __global__ __launch_bounds__(256) void ratio_filter_kernel(const int32_t *__rest
     if (threadIdx.x == 0) m_out[pair] = base_s;
 }
 
+// ---- Hamming distances on the matrix cores ------------------------------------------------------------------------------
+// With the bits of a descriptor written as 256 int8 values +1 / -1, the dot product of two descriptors is
+// (#equal bits) - (#different bits) = 256 - 2 dist: all-pairs matching is a [queries x 256] x [256 x trains] int8 GEMM, exact
+// in the int32 accumulators of v_mfma_i32_32x32x32_i8 -- 0.25 cycles per descriptor pair and SIMD at the instruction's
+// rate, against the ~19 VALU issue slots (~76 cycles per 64 pairs... 1.2 per pair) of the xor / popcount formulation, which
+// sits at 91 % of ITS roof (see the header).  The matching IS compute bound (0.02 B/pair), so this is where it belongs.
+//   * a pre-pass expands every train set once ([nt, 256] int8, 8x the packed size, written to the workspace);
+//   * a wave keeps 64 queries resident as the B operand (2 column tiles x 8 K-steps x 16 bytes per lane = 64 VGPRs,
+//     expanded from the packed descriptors at kernel start); the workgroup (4 waves, 256 queries) streams train tiles of
+//     32 descriptors through LDS (double buffered, 272-byte row pitch: conflict-free ds_read_b128) as the A operand;
+//   * D[m][n]: lane l holds column (= query) l % 32 and 16 of the 32 rows (= trains), so the two-smallest search needs
+//     no cross-lane traffic: accumulators are packed in pairs to 16 bits and turned into keys dist * 128 + tile number
+//     with one v_perm_b32 + one v_pk_mad_u16 per two values, and every (lane, packed position) is its own stream with
+//     its own two smallest keys (v_pk_max_u16 / v_pk_min_u16 x 2): 2.5 VALU instructions per descriptor pair.  The
+//     train index of a stream entry is tile * 32 + the row of its accumulator; streams are folded into 32-bit keys
+//     (dist << 16 | train index, ties -> lowest index as before) every 128 tiles and at the end, then the two lanes of a
+//     query are merged.
+typedef int bf_v4i __attribute__((ext_vector_type(4)));
+typedef int bf_v16i __attribute__((ext_vector_type(16)));
+constexpr int MF_TT = 32;        // train descriptors per tile
+constexpr int MF_PITCH = 272;    // bytes per expanded descriptor row in LDS
+constexpr int MF_SEG = 128;      // tiles per 7-bit tile number
+
+__device__ __forceinline__ uint32_t bf_expand4(uint32_t nib) {      // 4 bits -> 4 bytes +1 / -1 (bit k -> byte k)
+    const uint32_t x = (nib * 0x00204081u) & 0x01010101u;
+    return ((x ^ 0x01010101u) * 0xFFu) | x;
+}
+__device__ __forceinline__ bf_v4i bf_expand16(uint32_t bits) {
+    bf_v4i r;
+    r[0] = (int)bf_expand4(bits & 15u);
+    r[1] = (int)bf_expand4((bits >> 4) & 15u);
+    r[2] = (int)bf_expand4((bits >> 8) & 15u);
+    r[3] = (int)bf_expand4((bits >> 12) & 15u);
+    return r;
+}
+
+// out [n_pairs][ntp][256] int8 (ntp = nt_cap rounded up to a tile); one thread per 16 bits -> 16 bytes
+__global__ __launch_bounds__(256) void bf_expand_kernel(const uint8_t *__restrict__ t, int nt_cap, size_t t_stride, int ntp,
+                                                        int n_pairs, uint8_t *__restrict__ out) {
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)n_pairs * ntp * 16;
+    if (g >= total) return;
+    const int chunk = (int)(g & 15);
+    const size_t rowg = g >> 4;
+    const int row = (int)(rowg % ntp), pair = (int)(rowg / ntp);
+    uint32_t bits = 0;
+    if (row < nt_cap) bits = reinterpret_cast<const uint16_t *>(t + (size_t)pair * t_stride + (size_t)row * 32)[chunk];
+    reinterpret_cast<bf_v4i *>(out)[g] = bf_expand16(bits);
+}
+
+__device__ __forceinline__ uint32_t bf_pk_lo16(uint32_t hi_src, uint32_t lo_src) {   // {lo16(hi_src), lo16(lo_src)}
+    uint32_t r;
+    asm("v_perm_b32 %0, %1, %2, %3" : "=v"(r) : "v"(hi_src), "v"(lo_src), "v"(0x05040100u));
+    return r;
+}
+__device__ __forceinline__ uint32_t bf_pk_mad(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ void bf_pk_top2(uint32_t key, uint32_t &b0, uint32_t &b1) {
+    uint32_t hi;
+    asm("v_pk_max_u16 %0, %1, %2" : "=v"(hi) : "v"(b0), "v"(key));
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(b0) : "v"(b0), "v"(key));
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(b1) : "v"(b1), "v"(hi));
+}
+
+__global__ __launch_bounds__(BF_THREADS) void bf_knn2_mfma_kernel(
+    const uint8_t *__restrict__ q, const int32_t *__restrict__ nq_dev, int nq_cap, size_t q_stride,
+    const uint8_t *__restrict__ tx, const int32_t *__restrict__ nt_dev, int nt_cap, int ntp,
+    int32_t *__restrict__ idx, int32_t *__restrict__ dist) {
+    __shared__ __attribute__((aligned(16))) uint8_t tile[2][MF_TT][MF_PITCH];
+    const int pair = blockIdx.z;
+    const int nq = nq_dev ? min(nq_dev[pair], nq_cap) : nq_cap;
+    const int nt = nt_dev ? min(nt_dev[pair], nt_cap) : nt_cap;
+    const int qbase = blockIdx.x * BF_THREADS;
+    if (qbase >= nq) return;  // workgroup-uniform
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    // resident operand: queries qbase + 64 wv + 32 u + c; this lane supplies the 16 K-values [32 j + 16 h, +16) of step j
+    bf_v4i B[2][8];
+    const uint8_t *qp = q + (size_t)pair * q_stride;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int qi = qbase + 64 * wv + 32 * u + c;
+        uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
+        if (qi < nq) {
+            const uint4 *p = reinterpret_cast<const uint4 *>(qp + (size_t)qi * 32);
+            lo = p[0];
+            hi = p[1];
+        }
+        const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) B[u][j] = bf_expand16((w[j] >> (16 * h)) & 0xFFFFu);
+    }
+    uint32_t s0[2][8], s1[2][8];      // per (query tile, packed accumulator pair): the two smallest 16-bit keys, two streams each
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int p = 0; p < 8; ++p) s0[u][p] = s1[u][p] = 0xFFFFFFFFu;
+    uint32_t g0[2] = {BF_NONE, BF_NONE}, g1[2] = {BF_NONE, BF_NONE};   // folded: dist << 16 | train index
+    const int ntiles = (nt + MF_TT - 1) / MF_TT;
+    const uint8_t *txp = tx + (size_t)pair * ntp * 256;
+    // staging: 512 chunks of 16 bytes per tile, two per thread
+    const int e0 = threadIdx.x, e1 = threadIdx.x + 256;
+    bf_v4i st0, st1;
+    auto fetch = [&](int tt) {
+        const bf_v4i *src = reinterpret_cast<const bf_v4i *>(txp + (size_t)tt * MF_TT * 256);
+        st0 = src[e0];
+        st1 = src[e1];
+    };
+    auto commit = [&](int buf) {
+        *reinterpret_cast<bf_v4i *>(&tile[buf][e0 >> 4][(e0 & 15) * 16]) = st0;
+        *reinterpret_cast<bf_v4i *>(&tile[buf][e1 >> 4][(e1 & 15) * 16]) = st1;
+    };
+    auto fold = [&](int seg) {      // streams -> 32-bit keys; rows of packed pair p: 8 (p / 2) + 4 h + 2 (p % 2) and + 1
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int m = 8 * (p >> 1) + 4 * h + 2 * (p & 1);
+#pragma unroll
+                for (int x = 0; x < 2; ++x) {
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const uint32_t key16 = ((k == 0 ? s0[u][p] : s1[u][p]) >> (16 * x)) & 0xFFFFu;
+                        if (key16 != 0xFFFFu) {
+                            const uint32_t d = key16 >> 7, tno = key16 & 127u;
+                            top2_insert((d << 16) | (uint32_t)((seg * MF_SEG + (int)tno) * MF_TT + m + x), g0[u], g1[u]);
+                        }
+                    }
+                }
+                s0[u][p] = s1[u][p] = 0xFFFFFFFFu;
+            }
+    };
+    if (ntiles > 0) {
+        fetch(0);
+        commit(0);
+    }
+    __syncthreads();
+    for (int tt = 0; tt < ntiles; ++tt) {
+        const int buf = tt & 1;
+        if (tt + 1 < ntiles) fetch(tt + 1);
+        bf_v16i acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bf_v4i A = *reinterpret_cast<const bf_v4i *>(&tile[buf][c][32 * j + 16 * h]);
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B[0][j], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B[1][j], acc1, 0, 0, 0);
+        }
+        // key = dist * 128 + tile number = 16384 - 64 s + tno in 16-bit arithmetic, two accumulators per instruction
+        const uint32_t tno = (uint32_t)(tt & (MF_SEG - 1));
+        const uint32_t base = (16384u + tno) * 0x00010001u;
+        const bool partial = tt == ntiles - 1 && (nt & (MF_TT - 1)) != 0;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            uint32_t k0 = bf_pk_mad(bf_pk_lo16((uint32_t)acc0[2 * p + 1], (uint32_t)acc0[2 * p]), 0xFFC0FFC0u, base);
+            uint32_t k1 = bf_pk_mad(bf_pk_lo16((uint32_t)acc1[2 * p + 1], (uint32_t)acc1[2 * p]), 0xFFC0FFC0u, base);
+            if (partial) {      // (workgroup-uniform) rows past the last train never win
+                const int m = tt * MF_TT + 8 * (p >> 1) + 4 * h + 2 * (p & 1);
+                const uint32_t dead = (m >= nt ? 0x0000FFFFu : 0u) | (m + 1 >= nt ? 0xFFFF0000u : 0u);
+                k0 |= dead;
+                k1 |= dead;
+            }
+            bf_pk_top2(k0, s0[0][p], s1[0][p]);
+            bf_pk_top2(k1, s0[1][p], s1[1][p]);
+        }
+        if (tno == MF_SEG - 1 || tt == ntiles - 1) fold(tt / MF_SEG);
+        if (tt + 1 < ntiles) commit(buf ^ 1);
+        __syncthreads();
+    }
+    // the two lanes of a query (rows 4 h ..) -> one result
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const uint32_t o0 = __shfl_xor(g0[u], 32, 64), o1 = __shfl_xor(g1[u], 32, 64);
+        top2_insert(o0, g0[u], g1[u]);
+        top2_insert(o1, g0[u], g1[u]);
+        const int qi = qbase + 64 * wv + 32 * u + c;
+        if (h == 0 && qi < nq) {
+            const size_t o = ((size_t)pair * nq_cap + qi) * 2;
+            idx[o] = g0[u] == BF_NONE ? -1 : (int32_t)(g0[u] & 0xFFFFu);
+            idx[o + 1] = g1[u] == BF_NONE ? -1 : (int32_t)(g1[u] & 0xFFFFu);
+            dist[o] = g0[u] == BF_NONE ? -1 : (int32_t)(g0[u] >> 16);
+            dist[o + 1] = g1[u] == BF_NONE ? -1 : (int32_t)(g1[u] >> 16);
+        }
+    }
+}
+
 // queries per lane: 2 amortises the scalar train loads over two descriptor pairs; small launches use 1 to get more waves.
 // MM_BF_VARIANT=<qpl><unroll> (e.g. 24, 28, 44, 14) overrides for tuning runs.
 int bf_variant(int n_pairs, int nq_cap) {
     const char *e = getenv("MM_BF_VARIANT");
     const int forced = e ? atoi(e) : 0;
     if (forced) return forced;
-    return 114;  // LDS-fed, one query per lane, skip-branch bookkeeping: fastest of the measured variants (profiles/r01_bf_variants.txt)
+    return 200;  // matrix cores (bf_knn2_mfma_kernel); 114 = the best xor / popcount variant (LDS-fed, one query per lane)
 }
 
+// the MFMA formulation needs train indices below 2^16 and pays off from a few train tiles on
+bool bf_use_mfma(int n_pairs, int nq_cap, int nt_cap) { return bf_variant(n_pairs, nq_cap) == 200 && nt_cap >= 64 && nt_cap < 65536; }
+int bf_ntp(int nt_cap) { return (nt_cap + MF_TT - 1) / MF_TT * MF_TT; }
+
 int bf_choose_splits(int n_pairs, int nq_cap, int nt_cap) {
-    const int BF_QTILE = BF_THREADS * ((bf_variant(n_pairs, nq_cap) / 10) % 10);
+    if (bf_use_mfma(n_pairs, nq_cap, nt_cap)) return 1;
+    int var = bf_variant(n_pairs, nq_cap);
+    if (var == 200) var = 114;      // (shapes the matrix-core kernel does not take)
+    const int BF_QTILE = BF_THREADS * ((var / 10) % 10);
     long waves = (long)n_pairs * ((nq_cap + BF_QTILE - 1) / BF_QTILE) * (BF_THREADS / 64);
     if (waves <= 0) return 1;
     long s = (2048 + waves - 1) / waves;  // aim for >= 2 waves per SIMD on 256 CUs
@@ -353,6 +548,8 @@ int bf_choose_splits(int n_pairs, int nq_cap, int nt_cap) {
 extern "C" {
 
 size_t mm_bf_workspace_bytes(int n_pairs, int nq_cap, int nt_cap) {
+    if (n_pairs > 0 && nq_cap > 0 && bf_use_mfma(n_pairs, nq_cap, nt_cap))
+        return mm_align_up((size_t)n_pairs * bf_ntp(nt_cap) * 256, 256);      // the expanded train sets
     int s = bf_choose_splits(n_pairs, nq_cap, nt_cap);
     if (s == 1) return 256;
     return mm_align_up((size_t)n_pairs * s * nq_cap * 2 * sizeof(uint32_t), 256);
@@ -372,7 +569,19 @@ int mm_bf_knn2_batched(mm_ctx *ctx, const uint8_t *q, const int32_t *nq, int nq_
     int s = bf_choose_splits(n_pairs, nq_cap, nt_cap);
     if (s > 1 && (!ws || ws_bytes < mm_bf_workspace_bytes(n_pairs, nq_cap, nt_cap)))
         return mm_fail(ctx, MM_ERR_WORKSPACE, "mm_bf_knn2_batched: workspace too small");
-    const int var = bf_variant(n_pairs, nq_cap);
+    if (bf_use_mfma(n_pairs, nq_cap, nt_cap)) {
+        if (!ws || ws_bytes < mm_bf_workspace_bytes(n_pairs, nq_cap, nt_cap) || ((uintptr_t)ws & 15))
+            return mm_fail(ctx, MM_ERR_WORKSPACE, "mm_bf_knn2_batched: workspace too small or misaligned");
+        const int ntp = bf_ntp(nt_cap);
+        const size_t chunks = (size_t)n_pairs * ntp * 16;
+        MM_LAUNCH(ctx, "bf_expand_kernel", bf_expand_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, t, nt_cap,
+                  t_set_stride, ntp, n_pairs, (uint8_t *)ws);
+        MM_LAUNCH(ctx, "bf_knn2_kernel", bf_knn2_mfma_kernel, dim3((nq_cap + BF_THREADS - 1) / BF_THREADS, 1, n_pairs),
+                  dim3(BF_THREADS), 0, q, nq, nq_cap, q_set_stride, (const uint8_t *)ws, nt, nt_cap, ntp, idx, dist);
+        return MM_OK;
+    }
+    int var = bf_variant(n_pairs, nq_cap);
+    if (var == 200) var = 114;      // (shapes the matrix-core kernel does not take)
     const int qtile = BF_THREADS * ((var / 10) % 10);
     dim3 grid((nq_cap + qtile - 1) / qtile, s, n_pairs);
 #define BF_GO(Q, U)                                                                                              \
