@@ -402,8 +402,8 @@ int mm_cam_coef_table(mm_ctx *ctx, const double *cams, int F, const void **tab_o
 }
 void mm_cam_table_hold(mm_ctx *ctx, bool on) {
     ctx->cam_tab_hold = on;
-    if (!on) ctx->cam_tab_for = nullptr;
-}
+    ctx->cam_tab_for = nullptr;      // (also when switching ON: an earlier, un-held call may have left the address of a
+}                                    // buffer that has been reused for other camera values since)
 void mm_cam_table_invalidate(mm_ctx *ctx) { ctx->cam_tab_for = nullptr; }
 
 #define MM_CAM_TABLE(ctx, pb, cams)                                               \

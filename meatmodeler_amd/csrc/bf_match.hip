@@ -20,6 +20,7 @@
 //  * the SGPR-fed variants (train descriptor by scalar loads, bf_knn2_kernel) are kept for MM_BF_VARIANT tuning runs.
 #include "mm_common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -377,10 +378,10 @@ __global__ __launch_bounds__(256) void bf_expand_kernel(const uint8_t *__restric
     reinterpret_cast<bf_v4i *>(out)[g] = bf_expand16(bits);
 }
 
+// (a builtin, not asm: this is the first reader of the MFMA results, and the compiler's hazard recogniser has to see
+// the dependence to insert the wait states between a matrix instruction and a VALU read of its destination)
 __device__ __forceinline__ uint32_t bf_pk_lo16(uint32_t hi_src, uint32_t lo_src) {   // {lo16(hi_src), lo16(lo_src)}
-    uint32_t r;
-    asm("v_perm_b32 %0, %1, %2, %3" : "=v"(r) : "v"(hi_src), "v"(lo_src), "v"(0x05040100u));
-    return r;
+    return __builtin_amdgcn_perm(hi_src, lo_src, 0x05040100u);
 }
 __device__ __forceinline__ uint32_t bf_pk_mad(uint32_t a, uint32_t b, uint32_t c) {
     uint32_t r;
@@ -462,14 +463,11 @@ __global__ __launch_bounds__(BF_THREADS) void bf_knn2_mfma_kernel(
                 s0[u][p] = s1[u][p] = 0xFFFFFFFFu;
             }
     };
-    if (ntiles > 0) {
-        fetch(0);
-        commit(0);
-    }
-    __syncthreads();
-    for (int tt = 0; tt < ntiles; ++tt) {
+    // one train tile: 16 MFMA, then 2.5 VALU instructions per descriptor pair.  PARTIAL (the last tile of a train set
+    // whose size is no multiple of 32, peeled out of the loop): rows past the last train never win.
+    auto tile_step = [&](int tt, auto partial_tag) {
+        constexpr bool PARTIAL = decltype(partial_tag)::value;
         const int buf = tt & 1;
-        if (tt + 1 < ntiles) fetch(tt + 1);
         bf_v16i acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -480,12 +478,11 @@ __global__ __launch_bounds__(BF_THREADS) void bf_knn2_mfma_kernel(
         // key = dist * 128 + tile number = 16384 - 64 s + tno in 16-bit arithmetic, two accumulators per instruction
         const uint32_t tno = (uint32_t)(tt & (MF_SEG - 1));
         const uint32_t base = (16384u + tno) * 0x00010001u;
-        const bool partial = tt == ntiles - 1 && (nt & (MF_TT - 1)) != 0;
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             uint32_t k0 = bf_pk_mad(bf_pk_lo16((uint32_t)acc0[2 * p + 1], (uint32_t)acc0[2 * p]), 0xFFC0FFC0u, base);
             uint32_t k1 = bf_pk_mad(bf_pk_lo16((uint32_t)acc1[2 * p + 1], (uint32_t)acc1[2 * p]), 0xFFC0FFC0u, base);
-            if (partial) {      // (workgroup-uniform) rows past the last train never win
+            if constexpr (PARTIAL) {
                 const int m = tt * MF_TT + 8 * (p >> 1) + 4 * h + 2 * (p & 1);
                 const uint32_t dead = (m >= nt ? 0x0000FFFFu : 0u) | (m + 1 >= nt ? 0xFFFF0000u : 0u);
                 k0 |= dead;
@@ -494,10 +491,22 @@ __global__ __launch_bounds__(BF_THREADS) void bf_knn2_mfma_kernel(
             bf_pk_top2(k0, s0[0][p], s1[0][p]);
             bf_pk_top2(k1, s0[1][p], s1[1][p]);
         }
-        if (tno == MF_SEG - 1 || tt == ntiles - 1) fold(tt / MF_SEG);
-        if (tt + 1 < ntiles) commit(buf ^ 1);
+    };
+    if (ntiles > 0) {
+        fetch(0);
+        commit(0);
+    }
+    __syncthreads();
+    const int nfull = nt / MF_TT;      // complete tiles
+    for (int tt = 0; tt < nfull; ++tt) {
+        if (tt + 1 < ntiles) fetch(tt + 1);
+        tile_step(tt, std::false_type{});
+        if ((tt & (MF_SEG - 1)) == MF_SEG - 1) fold(tt / MF_SEG);
+        if (tt + 1 < ntiles) commit((tt & 1) ^ 1);
         __syncthreads();
     }
+    if (nfull < ntiles) tile_step(nfull, std::true_type{});
+    if (ntiles > 0) fold((ntiles - 1) / MF_SEG);
     // the two lanes of a query (rows 4 h ..) -> one result
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
