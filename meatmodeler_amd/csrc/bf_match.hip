@@ -383,16 +383,18 @@ __global__ __launch_bounds__(256) void bf_expand_kernel(const uint8_t *__restric
 __device__ __forceinline__ uint32_t bf_pk_lo16(uint32_t hi_src, uint32_t lo_src) {   // {lo16(hi_src), lo16(lo_src)}
     return __builtin_amdgcn_perm(hi_src, lo_src, 0x05040100u);
 }
+// two 16-bit lanes per instruction (v_pk_mad_u16, v_pk_max_u16, v_pk_min_u16); vector types rather than asm so that the
+// instruction scheduler knows them as VALU work it can place in the shadow of the matrix instructions
+typedef unsigned short bf_u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t bf_pk_mad(uint32_t a, uint32_t b, uint32_t c) {
-    uint32_t r;
-    asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
+    const bf_u16x2 r = __builtin_bit_cast(bf_u16x2, a) * __builtin_bit_cast(bf_u16x2, b) + __builtin_bit_cast(bf_u16x2, c);
+    return __builtin_bit_cast(uint32_t, r);
 }
 __device__ __forceinline__ void bf_pk_top2(uint32_t key, uint32_t &b0, uint32_t &b1) {
-    uint32_t hi;
-    asm("v_pk_max_u16 %0, %1, %2" : "=v"(hi) : "v"(b0), "v"(key));
-    asm("v_pk_min_u16 %0, %1, %2" : "=v"(b0) : "v"(b0), "v"(key));
-    asm("v_pk_min_u16 %0, %1, %2" : "=v"(b1) : "v"(b1), "v"(hi));
+    const bf_u16x2 k = __builtin_bit_cast(bf_u16x2, key), x0 = __builtin_bit_cast(bf_u16x2, b0), x1 = __builtin_bit_cast(bf_u16x2, b1);
+    const bf_u16x2 hi = __builtin_elementwise_max(x0, k);
+    b0 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(x0, k));
+    b1 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(x1, hi));
 }
 
 __global__ __launch_bounds__(BF_THREADS) void bf_knn2_mfma_kernel(
@@ -433,17 +435,29 @@ __global__ __launch_bounds__(BF_THREADS) void bf_knn2_mfma_kernel(
     const uint8_t *txp = tx + (size_t)pair * ntp * 256;
     // staging: 512 chunks of 16 bytes per tile, two per thread
     const int e0 = threadIdx.x, e1 = threadIdx.x + 256;
-    bf_v4i st0, st1;
-    auto fetch = [&](int tt) {
-        const bf_v4i *src = reinterpret_cast<const bf_v4i *>(txp + (size_t)tt * MF_TT * 256);
-        st0 = src[e0];
-        st1 = src[e1];
+    // Train tiles travel global -> registers -> LDS.  A tile is consumed in ~0.25 us per workgroup sharing the CU and a
+    // load from L2 / HBM takes over a microsecond, so THREE tiles are in flight in registers (sets 0..2, used round robin:
+    // the loop is unrolled by three so that the set index is static) on top of the two LDS buffers.
+    bf_v4i a0, a1, b0_, b1_, c0_, c1_;      // register sets 0, 1, 2
+    auto fetch = [&](int tt, auto set) __attribute__((always_inline)) {
+        constexpr int S = decltype(set)::value;
+        if (tt < ntiles) {      // (workgroup-uniform)
+            const bf_v4i *src = reinterpret_cast<const bf_v4i *>(txp + (size_t)tt * MF_TT * 256);
+            const bf_v4i v0 = src[e0], v1 = src[e1];
+            if constexpr (S == 0) { a0 = v0; a1 = v1; }
+            if constexpr (S == 1) { b0_ = v0; b1_ = v1; }
+            if constexpr (S == 2) { c0_ = v0; c1_ = v1; }
+        }
     };
-    auto commit = [&](int buf) {
-        *reinterpret_cast<bf_v4i *>(&tile[buf][e0 >> 4][(e0 & 15) * 16]) = st0;
-        *reinterpret_cast<bf_v4i *>(&tile[buf][e1 >> 4][(e1 & 15) * 16]) = st1;
+    auto commit = [&](int buf, auto set) __attribute__((always_inline)) {
+        constexpr int S = decltype(set)::value;
+        bf_v4i *d0 = reinterpret_cast<bf_v4i *>(&tile[buf][e0 >> 4][(e0 & 15) * 16]);
+        bf_v4i *d1 = reinterpret_cast<bf_v4i *>(&tile[buf][e1 >> 4][(e1 & 15) * 16]);
+        if constexpr (S == 0) { *d0 = a0; *d1 = a1; }
+        if constexpr (S == 1) { *d0 = b0_; *d1 = b1_; }
+        if constexpr (S == 2) { *d0 = c0_; *d1 = c1_; }
     };
-    auto fold = [&](int seg) {      // streams -> 32-bit keys; rows of packed pair p: 8 (p / 2) + 4 h + 2 (p % 2) and + 1
+    auto fold = [&](int seg) __attribute__((always_inline)) {      // streams -> 32-bit keys; rows of packed pair p: 8 (p / 2) + 4 h + 2 (p % 2) and + 1
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -465,45 +479,66 @@ __global__ __launch_bounds__(BF_THREADS) void bf_knn2_mfma_kernel(
     };
     // one train tile: 16 MFMA, then 2.5 VALU instructions per descriptor pair.  PARTIAL (the last tile of a train set
     // whose size is no multiple of 32, peeled out of the loop): rows past the last train never win.
-    auto tile_step = [&](int tt, auto partial_tag) {
+    auto tile_step = [&](int tt, auto partial_tag) __attribute__((always_inline)) {
         constexpr bool PARTIAL = decltype(partial_tag)::value;
         const int buf = tt & 1;
         bf_v16i acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
+        bf_v4i A[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const bf_v4i A = *reinterpret_cast<const bf_v4i *>(&tile[buf][c][32 * j + 16 * h]);
-            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B[0][j], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B[1][j], acc1, 0, 0, 0);
-        }
+        for (int j = 0; j < 8; ++j) A[j] = *reinterpret_cast<const bf_v4i *>(&tile[buf][c][32 * j + 16 * h]);
         // key = dist * 128 + tile number = 16384 - 64 s + tno in 16-bit arithmetic, two accumulators per instruction
         const uint32_t tno = (uint32_t)(tt & (MF_SEG - 1));
         const uint32_t base = (16384u + tno) * 0x00010001u;
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            uint32_t k0 = bf_pk_mad(bf_pk_lo16((uint32_t)acc0[2 * p + 1], (uint32_t)acc0[2 * p]), 0xFFC0FFC0u, base);
-            uint32_t k1 = bf_pk_mad(bf_pk_lo16((uint32_t)acc1[2 * p + 1], (uint32_t)acc1[2 * p]), 0xFFC0FFC0u, base);
+        auto keys = [&](const bf_v16i &acc, int u, int p) __attribute__((always_inline)) {
+            uint32_t k = bf_pk_mad(bf_pk_lo16((uint32_t)acc[2 * p + 1], (uint32_t)acc[2 * p]), 0xFFC0FFC0u, base);
             if constexpr (PARTIAL) {
                 const int m = tt * MF_TT + 8 * (p >> 1) + 4 * h + 2 * (p & 1);
-                const uint32_t dead = (m >= nt ? 0x0000FFFFu : 0u) | (m + 1 >= nt ? 0xFFFF0000u : 0u);
-                k0 |= dead;
-                k1 |= dead;
+                k |= (m >= nt ? 0x0000FFFFu : 0u) | (m + 1 >= nt ? 0xFFFF0000u : 0u);
             }
-            bf_pk_top2(k0, s0[0][p], s1[0][p]);
-            bf_pk_top2(k1, s0[1][p], s1[1][p]);
+            bf_pk_top2(k, s0[u][p], s1[u][p]);
+        };
+        // the first query tile's 8 MFMA, then the second tile's 8 with the first tile's bookkeeping in their shadow
+        // (one matrix instruction, then five vector instructions: the scheduler is told to keep that pattern)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[j], B[0][j], acc0, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {      // (scheduling barriers: keep one matrix instruction per slice of vector work)
+            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[j], B[1][j], acc1, 0, 0, 0);
+            keys(acc0, 0, j);
+            __builtin_amdgcn_sched_barrier(0);
         }
+#pragma unroll
+        for (int p = 0; p < 8; ++p) keys(acc1, 1, p);
     };
-    if (ntiles > 0) {
-        fetch(0);
-        commit(0);
-    }
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    fetch(0, I0{});
+    fetch(1, I1{});
+    fetch(2, I2{});
+    if (ntiles > 0) commit(0, I0{});
+    fetch(3, I0{});
     __syncthreads();
     const int nfull = nt / MF_TT;      // complete tiles
-    for (int tt = 0; tt < nfull; ++tt) {
-        if (tt + 1 < ntiles) fetch(tt + 1);
+    // iteration tt: tile tt is in LDS buffer tt & 1; tiles tt+1, tt+2, tt+3 are in the register sets (tt+1) % 3, (tt+2) % 3,
+    // tt % 3.  After the compute: tile tt+1 goes to the other LDS buffer and its register set takes tile tt+4.
+    auto iteration = [&](int tt, auto next_set) __attribute__((always_inline)) {
         tile_step(tt, std::false_type{});
         if ((tt & (MF_SEG - 1)) == MF_SEG - 1) fold(tt / MF_SEG);
-        if (tt + 1 < ntiles) commit((tt & 1) ^ 1);
+        if (tt + 1 < ntiles) commit((tt & 1) ^ 1, next_set);
+        fetch(tt + 4, next_set);
         __syncthreads();
+    };
+    int tt = 0;
+    for (; tt + 3 <= nfull; tt += 3) {
+        iteration(tt, I1{});
+        iteration(tt + 1, I2{});
+        iteration(tt + 2, I0{});
+    }
+    if (tt < nfull) {
+        iteration(tt, I1{});
+        if (tt + 1 < nfull) iteration(tt + 1, I2{});
     }
     if (nfull < ntiles) tile_step(nfull, std::true_type{});
     if (ntiles > 0) fold((ntiles - 1) / MF_SEG);
