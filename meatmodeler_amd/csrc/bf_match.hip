@@ -559,23 +559,228 @@ __global__ __launch_bounds__(BF_THREADS) void bf_knn2_mfma_kernel(
     }
 }
 
+// ---- the same on the FP4 path of the matrix cores ------------------------------------------------------------------------
+// +1 and -1 are exact in FP4 (E2M1: 0x2 / 0xA), their products and sums up to 256 exact in the f32 accumulators, and
+// v_mfma_scale_f32_32x32x64_f8f6f4 with FP4 operands (block scales 1.0) is the fastest matrix instruction of the chip:
+// measured 16 ns per instruction and SIMD with every SIMD busy against 29 ns for v_mfma_i32_32x32x32_i8 at half the K
+// (tools/dev/mfma_rate.hip) -- 3.6x the int8 rate per descriptor pair.  A descriptor is 256 nibbles = 128 bytes (half the
+// int8 form: half the LDS traffic too), a K-step takes 64 bits, a tile four matrix instructions per query tile.  The
+// accumulators start at 1.5 * 2^23: the sum lands in the low mantissa bits as a two's-complement integer, so the
+// 16-bit key arithmetic of the int8 kernel applies unchanged to the float's bit pattern.
+typedef int bf_v8i __attribute__((ext_vector_type(8)));
+typedef float bf_v16f __attribute__((ext_vector_type(16)));
+constexpr int F4_PITCH = 144;    // bytes per expanded descriptor row in LDS (128 + 16: conflict-free ds_read_b128)
+
+__device__ __forceinline__ uint32_t bf_fp4x8(uint32_t byte) {      // 8 bits -> 8 nibbles (+1: 0x2, -1: 0xA), bit k -> nibble k
+    uint32_t x = byte;
+    x = (x | (x << 12)) & 0x000F000Fu;
+    x = (x | (x << 6)) & 0x03030303u;
+    x = (x | (x << 3)) & 0x11111111u;
+    return 0xAAAAAAAAu ^ (x << 3);
+}
+__device__ __forceinline__ bf_v4i bf_fp4x32(uint32_t bits) {
+    bf_v4i r;
+    r[0] = (int)bf_fp4x8(bits & 255u);
+    r[1] = (int)bf_fp4x8((bits >> 8) & 255u);
+    r[2] = (int)bf_fp4x8((bits >> 16) & 255u);
+    r[3] = (int)bf_fp4x8(bits >> 24);
+    return r;
+}
+
+// out [n_pairs][ntp][128] bytes; one thread per 32 bits -> 16 bytes
+__global__ __launch_bounds__(256) void bf_expand_fp4_kernel(const uint8_t *__restrict__ t, int nt_cap, size_t t_stride, int ntp,
+                                                            int n_pairs, uint8_t *__restrict__ out) {
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)n_pairs * ntp * 8;
+    if (g >= total) return;
+    const int chunk = (int)(g & 7);
+    const size_t rowg = g >> 3;
+    const int row = (int)(rowg % ntp), pair = (int)(rowg / ntp);
+    uint32_t bits = 0;
+    if (row < nt_cap) bits = reinterpret_cast<const uint32_t *>(t + (size_t)pair * t_stride + (size_t)row * 32)[chunk];
+    reinterpret_cast<bf_v4i *>(out)[g] = bf_fp4x32(bits);
+}
+
+__global__ __launch_bounds__(BF_THREADS) void bf_knn2_fp4_kernel(
+    const uint8_t *__restrict__ q, const int32_t *__restrict__ nq_dev, int nq_cap, size_t q_stride,
+    const uint8_t *__restrict__ tx, const int32_t *__restrict__ nt_dev, int nt_cap, int ntp,
+    int32_t *__restrict__ idx, int32_t *__restrict__ dist) {
+    __shared__ __attribute__((aligned(16))) uint8_t tile[2][MF_TT][F4_PITCH];
+    const int pair = blockIdx.z;
+    const int nq = nq_dev ? min(nq_dev[pair], nq_cap) : nq_cap;
+    const int nt = nt_dev ? min(nt_dev[pair], nt_cap) : nt_cap;
+    const int qbase = blockIdx.x * BF_THREADS;
+    if (qbase >= nq) return;  // workgroup-uniform
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    // resident operand: queries qbase + 64 wv + 32 u + c; this lane supplies the 32 K-values [64 j + 32 h, +32) of step j
+    bf_v8i B[2][4];
+    const uint8_t *qp = q + (size_t)pair * q_stride;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int qi = qbase + 64 * wv + 32 * u + c;
+        uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
+        if (qi < nq) {
+            const uint4 *p = reinterpret_cast<const uint4 *>(qp + (size_t)qi * 32);
+            lo = p[0];
+            hi = p[1];
+        }
+        const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bf_v4i e = bf_fp4x32(h ? w[2 * j + 1] : w[2 * j]);
+            B[u][j] = bf_v8i{e[0], e[1], e[2], e[3], 0, 0, 0, 0};
+        }
+    }
+    uint32_t s0[2][8], s1[2][8];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int p = 0; p < 8; ++p) s0[u][p] = s1[u][p] = 0xFFFFFFFFu;
+    uint32_t g0[2] = {BF_NONE, BF_NONE}, g1[2] = {BF_NONE, BF_NONE};
+    const int ntiles = (nt + MF_TT - 1) / MF_TT;
+    const uint8_t *txp = tx + (size_t)pair * ntp * 128;
+    // staging: 256 chunks of 16 bytes per tile, one per thread; three tiles in flight in registers (see the int8 kernel)
+    const int e0 = threadIdx.x;
+    bf_v4i ra, rb, rc;
+    auto fetch = [&](int tt, auto set) __attribute__((always_inline)) {
+        constexpr int S = decltype(set)::value;
+        if (tt < ntiles) {      // (workgroup-uniform)
+            const bf_v4i v = reinterpret_cast<const bf_v4i *>(txp + (size_t)tt * MF_TT * 128)[e0];
+            if constexpr (S == 0) ra = v;
+            if constexpr (S == 1) rb = v;
+            if constexpr (S == 2) rc = v;
+        }
+    };
+    auto commit = [&](int buf, auto set) __attribute__((always_inline)) {
+        constexpr int S = decltype(set)::value;
+        bf_v4i *d = reinterpret_cast<bf_v4i *>(&tile[buf][e0 >> 3][(e0 & 7) * 16]);
+        if constexpr (S == 0) *d = ra;
+        if constexpr (S == 1) *d = rb;
+        if constexpr (S == 2) *d = rc;
+    };
+    auto fold = [&](int seg) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int m = 8 * (p >> 1) + 4 * h + 2 * (p & 1);
+#pragma unroll
+                for (int x = 0; x < 2; ++x) {
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const uint32_t key16 = ((k == 0 ? s0[u][p] : s1[u][p]) >> (16 * x)) & 0xFFFFu;
+                        if (key16 != 0xFFFFu) {
+                            const uint32_t d = key16 >> 7, tno = key16 & 127u;
+                            top2_insert((d << 16) | (uint32_t)((seg * MF_SEG + (int)tno) * MF_TT + m + x), g0[u], g1[u]);
+                        }
+                    }
+                }
+                s0[u][p] = s1[u][p] = 0xFFFFFFFFu;
+            }
+    };
+    auto tile_step = [&](int tt, auto partial_tag) __attribute__((always_inline)) {
+        constexpr bool PARTIAL = decltype(partial_tag)::value;
+        const int buf = tt & 1;
+        constexpr float MAGIC = 12582912.0f;      // 1.5 * 2^23: MAGIC + s has s in its low mantissa bits
+        bf_v16f acc0 = {MAGIC, MAGIC, MAGIC, MAGIC, MAGIC, MAGIC, MAGIC, MAGIC, MAGIC, MAGIC, MAGIC, MAGIC, MAGIC, MAGIC, MAGIC, MAGIC};
+        bf_v16f acc1 = acc0;
+        bf_v8i A[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bf_v4i a = *reinterpret_cast<const bf_v4i *>(&tile[buf][c][32 * j + 16 * h]);
+            A[j] = bf_v8i{a[0], a[1], a[2], a[3], 0, 0, 0, 0};
+        }
+        const uint32_t tno = (uint32_t)(tt & (MF_SEG - 1));
+        const uint32_t base = (16384u + tno) * 0x00010001u;
+        auto keys = [&](const bf_v16f &acc, int u, int p) __attribute__((always_inline)) {
+            const float f_hi = acc[2 * p + 1], f_lo = acc[2 * p];      // (values first: a bit cast of the element reference reads element 0)
+            uint32_t k = bf_pk_mad(bf_pk_lo16(__float_as_uint(f_hi), __float_as_uint(f_lo)), 0xFFC0FFC0u, base);
+            if constexpr (PARTIAL) {
+                const int m = tt * MF_TT + 8 * (p >> 1) + 4 * h + 2 * (p & 1);
+                k |= (m >= nt ? 0x0000FFFFu : 0u) | (m + 1 >= nt ? 0xFFFF0000u : 0u);
+            }
+            bf_pk_top2(k, s0[u][p], s1[u][p]);
+        };
+        // cbsz = blgp = 4: both operands FP4; block scales E8M0 127 = 1.0
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[j], B[0][j], acc0, 4, 4, 0, 127, 0, 127);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[j], B[1][j], acc1, 4, 4, 0, 127, 0, 127);
+            keys(acc0, 0, 2 * j);
+            keys(acc0, 0, 2 * j + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int p = 0; p < 8; ++p) keys(acc1, 1, p);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    fetch(0, I0{});
+    fetch(1, I1{});
+    fetch(2, I2{});
+    if (ntiles > 0) commit(0, I0{});
+    fetch(3, I0{});
+    __syncthreads();
+    const int nfull = nt / MF_TT;
+    auto iteration = [&](int tt, auto next_set) __attribute__((always_inline)) {
+        tile_step(tt, std::false_type{});
+        if ((tt & (MF_SEG - 1)) == MF_SEG - 1) fold(tt / MF_SEG);
+        if (tt + 1 < ntiles) commit((tt & 1) ^ 1, next_set);
+        fetch(tt + 4, next_set);
+        __syncthreads();
+    };
+    int tt = 0;
+    for (; tt + 3 <= nfull; tt += 3) {
+        iteration(tt, I1{});
+        iteration(tt + 1, I2{});
+        iteration(tt + 2, I0{});
+    }
+    if (tt < nfull) {
+        iteration(tt, I1{});
+        if (tt + 1 < nfull) iteration(tt + 1, I2{});
+    }
+    if (nfull < ntiles) tile_step(nfull, std::true_type{});
+    if (ntiles > 0) fold((ntiles - 1) / MF_SEG);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const uint32_t o0 = __shfl_xor(g0[u], 32, 64), o1 = __shfl_xor(g1[u], 32, 64);
+        top2_insert(o0, g0[u], g1[u]);
+        top2_insert(o1, g0[u], g1[u]);
+        const int qi = qbase + 64 * wv + 32 * u + c;
+        if (h == 0 && qi < nq) {
+            const size_t o = ((size_t)pair * nq_cap + qi) * 2;
+            idx[o] = g0[u] == BF_NONE ? -1 : (int32_t)(g0[u] & 0xFFFFu);
+            idx[o + 1] = g1[u] == BF_NONE ? -1 : (int32_t)(g1[u] & 0xFFFFu);
+            dist[o] = g0[u] == BF_NONE ? -1 : (int32_t)(g0[u] >> 16);
+            dist[o + 1] = g1[u] == BF_NONE ? -1 : (int32_t)(g1[u] >> 16);
+        }
+    }
+}
+
 // queries per lane: 2 amortises the scalar train loads over two descriptor pairs; small launches use 1 to get more waves.
 // MM_BF_VARIANT=<qpl><unroll> (e.g. 24, 28, 44, 14) overrides for tuning runs.
 int bf_variant(int n_pairs, int nq_cap) {
     const char *e = getenv("MM_BF_VARIANT");
     const int forced = e ? atoi(e) : 0;
     if (forced) return forced;
-    return 200;  // matrix cores (bf_knn2_mfma_kernel); 114 = the best xor / popcount variant (LDS-fed, one query per lane)
-}
+    return 300;  // 300: matrix cores, FP4 operands (bf_knn2_fp4_kernel); 200: int8 (bf_knn2_mfma_kernel); 114: the best
+}                // xor / popcount variant (LDS-fed, one query per lane)
 
 // the MFMA formulation needs train indices below 2^16 and pays off from a few train tiles on
-bool bf_use_mfma(int n_pairs, int nq_cap, int nt_cap) { return bf_variant(n_pairs, nq_cap) == 200 && nt_cap >= 64 && nt_cap < 65536; }
+bool bf_use_mfma(int n_pairs, int nq_cap, int nt_cap) {
+    const int v = bf_variant(n_pairs, nq_cap);
+    return (v == 200 || v == 300) && nt_cap >= 64 && nt_cap < 65536;
+}
 int bf_ntp(int nt_cap) { return (nt_cap + MF_TT - 1) / MF_TT * MF_TT; }
 
 int bf_choose_splits(int n_pairs, int nq_cap, int nt_cap) {
     if (bf_use_mfma(n_pairs, nq_cap, nt_cap)) return 1;
     int var = bf_variant(n_pairs, nq_cap);
-    if (var == 200) var = 114;      // (shapes the matrix-core kernel does not take)
+    if (var == 200 || var == 300) var = 114;      // (shapes the matrix-core kernels do not take)
     const int BF_QTILE = BF_THREADS * ((var / 10) % 10);
     long waves = (long)n_pairs * ((nq_cap + BF_QTILE - 1) / BF_QTILE) * (BF_THREADS / 64);
     if (waves <= 0) return 1;
@@ -617,15 +822,24 @@ int mm_bf_knn2_batched(mm_ctx *ctx, const uint8_t *q, const int32_t *nq, int nq_
         if (!ws || ws_bytes < mm_bf_workspace_bytes(n_pairs, nq_cap, nt_cap) || ((uintptr_t)ws & 15))
             return mm_fail(ctx, MM_ERR_WORKSPACE, "mm_bf_knn2_batched: workspace too small or misaligned");
         const int ntp = bf_ntp(nt_cap);
+        const dim3 grid((nq_cap + BF_THREADS - 1) / BF_THREADS, 1, n_pairs);
+        if (bf_variant(n_pairs, nq_cap) == 300) {
+            const size_t chunks = (size_t)n_pairs * ntp * 8;
+            MM_LAUNCH(ctx, "bf_expand_kernel", bf_expand_fp4_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, t, nt_cap,
+                      t_set_stride, ntp, n_pairs, (uint8_t *)ws);
+            MM_LAUNCH(ctx, "bf_knn2_kernel", bf_knn2_fp4_kernel, grid, dim3(BF_THREADS), 0, q, nq, nq_cap, q_set_stride,
+                      (const uint8_t *)ws, nt, nt_cap, ntp, idx, dist);
+            return MM_OK;
+        }
         const size_t chunks = (size_t)n_pairs * ntp * 16;
         MM_LAUNCH(ctx, "bf_expand_kernel", bf_expand_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, t, nt_cap,
                   t_set_stride, ntp, n_pairs, (uint8_t *)ws);
-        MM_LAUNCH(ctx, "bf_knn2_kernel", bf_knn2_mfma_kernel, dim3((nq_cap + BF_THREADS - 1) / BF_THREADS, 1, n_pairs),
-                  dim3(BF_THREADS), 0, q, nq, nq_cap, q_set_stride, (const uint8_t *)ws, nt, nt_cap, ntp, idx, dist);
+        MM_LAUNCH(ctx, "bf_knn2_kernel", bf_knn2_mfma_kernel, grid, dim3(BF_THREADS), 0, q, nq, nq_cap, q_set_stride,
+                  (const uint8_t *)ws, nt, nt_cap, ntp, idx, dist);
         return MM_OK;
     }
     int var = bf_variant(n_pairs, nq_cap);
-    if (var == 200) var = 114;      // (shapes the matrix-core kernel does not take)
+    if (var == 200 || var == 300) var = 114;      // (shapes the matrix-core kernels do not take)
     const int qtile = BF_THREADS * ((var / 10) % 10);
     dim3 grid((nq_cap + qtile - 1) / qtile, s, n_pairs);
 #define BF_GO(Q, U)                                                                                              \
