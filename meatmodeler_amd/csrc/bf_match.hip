@@ -628,7 +628,7 @@ __global__ __launch_bounds__(BF_THREADS) void bf_knn2_fp4_kernel(
         const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const bf_v4i e = bf_fp4x32(h ? w[2 * j + 1] : w[2 * j]);
+            const bf_v4i e = bf_fp4x32(~(h ? w[2 * j + 1] : w[2 * j]));      // queries enter NEGATED (see tile_step)
             B[u][j] = bf_v8i{e[0], e[1], e[2], e[3], 0, 0, 0, 0};
         }
     }
@@ -682,8 +682,14 @@ __global__ __launch_bounds__(BF_THREADS) void bf_knn2_fp4_kernel(
     auto tile_step = [&](int tt, auto partial_tag) __attribute__((always_inline)) {
         constexpr bool PARTIAL = decltype(partial_tag)::value;
         const int buf = tt & 1;
-        constexpr float MAGIC = 12582912.0f;      // 1.5 * 2^23: MAGIC + s has s in its low mantissa bits
-        bf_v16f acc0 = {MAGIC, MAGIC, MAGIC, MAGIC, MAGIC, MAGIC, MAGIC, MAGIC, MAGIC, MAGIC, MAGIC, MAGIC, MAGIC, MAGIC, MAGIC, MAGIC};
+        // The matrix instruction delivers the 16-bit key itself: the queries are negated and the train operand carries the
+        // block scale 2^6, so a tile adds -64 s to accumulators that start at 1.5 * 2^23 + 16384 + tile number -- the key
+        // dist * 128 + tile number = 16384 - 64 s + tno then sits in the low 16 mantissa bits (all sums are integers below
+        // 2^24: exact).  Left for the vector unit: pack two keys (v_perm_b32) and the two-smallest update, 2 instructions
+        // per descriptor pair.
+        const uint32_t tno = (uint32_t)(tt & (MF_SEG - 1));
+        const float init = 12582912.0f + 16384.0f + (float)tno;
+        bf_v16f acc0 = {init, init, init, init, init, init, init, init, init, init, init, init, init, init, init, init};
         bf_v16f acc1 = acc0;
         bf_v8i A[4];
 #pragma unroll
@@ -691,24 +697,22 @@ __global__ __launch_bounds__(BF_THREADS) void bf_knn2_fp4_kernel(
             const bf_v4i a = *reinterpret_cast<const bf_v4i *>(&tile[buf][c][32 * j + 16 * h]);
             A[j] = bf_v8i{a[0], a[1], a[2], a[3], 0, 0, 0, 0};
         }
-        const uint32_t tno = (uint32_t)(tt & (MF_SEG - 1));
-        const uint32_t base = (16384u + tno) * 0x00010001u;
         auto keys = [&](const bf_v16f &acc, int u, int p) __attribute__((always_inline)) {
             const float f_hi = acc[2 * p + 1], f_lo = acc[2 * p];      // (values first: a bit cast of the element reference reads element 0)
-            uint32_t k = bf_pk_mad(bf_pk_lo16(__float_as_uint(f_hi), __float_as_uint(f_lo)), 0xFFC0FFC0u, base);
+            uint32_t k = bf_pk_lo16(__float_as_uint(f_hi), __float_as_uint(f_lo));
             if constexpr (PARTIAL) {
                 const int m = tt * MF_TT + 8 * (p >> 1) + 4 * h + 2 * (p & 1);
                 k |= (m >= nt ? 0x0000FFFFu : 0u) | (m + 1 >= nt ? 0xFFFF0000u : 0u);
             }
             bf_pk_top2(k, s0[u][p], s1[u][p]);
         };
-        // cbsz = blgp = 4: both operands FP4; block scales E8M0 127 = 1.0
+        // cbsz = blgp = 4: both operands FP4; block scales (E8M0): train operand 133 = 2^6, queries 127 = 1.0
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[j], B[0][j], acc0, 4, 4, 0, 127, 0, 127);
+        for (int j = 0; j < 4; ++j) acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[j], B[0][j], acc0, 4, 4, 0, 133, 0, 127);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[j], B[1][j], acc1, 4, 4, 0, 127, 0, 127);
+            acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[j], B[1][j], acc1, 4, 4, 0, 133, 0, 127);
             keys(acc0, 0, 2 * j);
             keys(acc0, 0, 2 * j + 1);
             __builtin_amdgcn_sched_barrier(0);
