@@ -31,6 +31,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_PEAK_TLOPS = 78.6         # 256 CU x 4 SIMD-32 x 2.4 GHz (157.3 TF FP32 vector / 2)
 MFMA_F64_PEAK_TF = 78.6        # v_mfma_f64_16x16x4: 2048 flop / 64 clk / SIMD
+MFMA_FP4_PEAK_PF = 10.0        # MI355X_MICROARCH.md: FP4 / FP6 ~10 PF dense (block-scaled f8f6f4 MFMA)
 
 
 def parse():
@@ -303,15 +304,21 @@ def main():
     bf = next((k for k in kernels if k["kernel"] == "bf_knn2_kernel"), None)
     if bf is not None and "valu_Tlops" in bf:
         bf = dict(bf)
-        # the roof SURVEY section 8(d) fixes (16 lane-ops per pair at the nominal 78.6 T lane-ops/s = 4.9 T pairs/s) ...
-        bf["valu_frac_of_16op_roof"] = bf["valu_Tlops"] / VALU_PEAK_TLOPS
+        # the roof SURVEY section 8(d) fixes for the xor / popcount formulation (16 lane-ops per pair at the nominal
+        # 78.6 T lane-ops/s = 4.9 T pairs/s) ...
         bf["T_pairs_per_s"] = bf["valu_Tlops"] / 16.0
-        # ... and the issue roof of the instruction mix the kernel really executes, from the SQ counters of
-        # profiles/r02_bf_pmc.txt: 18.83 VALU instructions per pair (8 xor at 2.63 + 10.83 quarter-rate ops at 4.14 cycles)
-        bf["instr_per_pair_measured"] = 18.83
-        bf["issue_cycles_per_pair_roof"] = 8 * 2.63 + 10.83 * 4.14
-        bf["note"] = ("VALU-integer issue bound, 0.02 B of HBM per pair; counters: 3.84 cycles per VALU instruction at the "
-                      "2.1 GHz held under this load = 91 % of the issue roof of the mix (profiles/r02_bf_pmc.txt)")
+        bf["frac_of_16op_valu_roof"] = bf["valu_Tlops"] / VALU_PEAK_TLOPS
+        # ... which the kernel no longer lives under: the distances are computed on the matrix cores (descriptors as +1 / -1
+        # FP4 values, v_mfma_scale_f32_32x32x64_f8f6f4: 512 flop per descriptor pair, exact), the vector unit keeps the
+        # two-smallest bookkeeping (2 packed 16-bit instructions per pair)
+        bf["mfma_fp4_PFLOPs"] = bf["T_pairs_per_s"] * 512.0 / 1e3
+        bf["mfma_fp4_peak_PFLOPs"] = MFMA_FP4_PEAK_PF
+        bf["frac_of_fp4_mfma_roof"] = bf["mfma_fp4_PFLOPs"] / MFMA_FP4_PEAK_PF
+        bf["note"] = ("matrix cores (FP4 operands) + 2 VALU instructions per pair; the xor / popcount kernel it replaces ran at "
+                      "2.0-2.1 T pairs/s = 91 % of the VALU issue roof of its instruction mix (profiles/r02_bf_pmc.txt); "
+                      "MM_BF_VARIANT=114 selects it, 200 the int8 MFMA form; all three return identical results")
+        for k_ in ("valu_Tlops",):
+            bf.pop(k_, None)
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

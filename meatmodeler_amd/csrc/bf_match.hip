@@ -3,7 +3,14 @@
 // Replaces cv2.FlannBasedMatcher(...).knnMatch(prev_desc, new_desc, k=2) and the ratio filter of
 // processor.featureTracking (reference processor.py:132-137) by the exact search FLANN-LSH approximates.
 //
-// Mapping to the hardware:
+// Mapping to the hardware.  The search is compute bound (0.02 B of HBM per descriptor pair), and
+// there are three formulations of the distance in this file, all returning identical results (ties -> lowest train
+// index); MM_BF_VARIANT selects one, the default is the fastest:
+//  300  matrix cores, FP4 operands (bf_knn2_fp4_kernel): 1.25 ms per 500-frame clip = 6.4 T pairs/s    <- default
+//  200  matrix cores, int8 operands (bf_knn2_mfma_kernel): 1.9 ms = 4.2 T pairs/s
+//  114  xor / popcount on the vector unit (bf_knn2_lds_kernel, below): 3.9-4.2 ms = 2.0 T pairs/s; also what small
+//       train sets (< 64) and train sets of 65536 or more descriptors take
+// The matrix-core kernels are described where they are defined; the vector-unit formulation:
 //  * one lane owns one query descriptor (8 VGPRs); a wave covers 64 queries, a workgroup 256;
 //  * the workgroup stages 128 train descriptors at a time in LDS (double buffered, the next chunk's global loads fly
 //    during the current chunk's compute); every lane reads the same train with two same-address ds_read_b128 (LDS
@@ -13,9 +20,10 @@
 //    index, ties -> lowest train index) if its distance is below the current second-best distance, so the group's
 //    minimum is tested and the min / med3 bookkeeping sits behind a wave-uniform, rarely taken branch:
 //    18.8 VALU instructions per descriptor pair, 16 of them the xor / popcount floor;
-//  * no cross-lane traffic, 0.02 B of HBM per pair: the bound is VALU integer issue.  Measured
-//    with the SQ counters (profiles/r02_bf_pmc.txt): 3.84 cycles per VALU instruction at the 2.1 GHz the chip holds
-//    under this load = 91 % of the issue roof of this instruction mix (v_bcnt / v_min issue at quarter rate);
+//  * no cross-lane traffic: the bound is VALU integer issue.  Measured with the SQ counters
+//    (profiles/r02_bf_pmc.txt): 3.84 cycles per VALU instruction at the 2.1 GHz the chip holds under this load = 91 %
+//    of the issue roof of this instruction mix (v_bcnt / v_min issue at quarter rate) -- which is why the distances
+//    moved to the matrix cores;
 //  * small launches split the train range over blockIdx.y and merge partial top-2 keys in a second kernel;
 //  * the SGPR-fed variants (train descriptor by scalar loads, bf_knn2_kernel) are kept for MM_BF_VARIANT tuning runs.
 #include "mm_common.h"
@@ -332,8 +340,9 @@ __global__ __launch_bounds__(256) void ratio_filter_kernel(const int32_t *__rest
 // With the bits of a descriptor written as 256 int8 values +1 / -1, the dot product of two descriptors is
 // (#equal bits) - (#different bits) = 256 - 2 dist: all-pairs matching is a [queries x 256] x [256 x trains] int8 GEMM, exact
 // in the int32 accumulators of v_mfma_i32_32x32x32_i8 -- 0.25 cycles per descriptor pair and SIMD at the instruction's
-// rate, against the ~19 VALU issue slots (~76 cycles per 64 pairs... 1.2 per pair) of the xor / popcount formulation, which
-// sits at 91 % of ITS roof (see the header).  The matching IS compute bound (0.02 B/pair), so this is where it belongs.
+// nominal rate, against the 19 VALU instructions per pair (1.2 cycles per pair and SIMD) of the xor / popcount formulation,
+// which sits at 91 % of ITS roof (see the header).  (Measured: the int8 instruction issues every 29 ns per SIMD with the
+// whole chip busy, 2.3 POP/s -- tools/dev/mfma_rate.hip -- and this kernel runs at that rate: 4.2 T pairs/s.)  The matching IS compute bound (0.02 B/pair), so this is where it belongs.
 //   * a pre-pass expands every train set once ([nt, 256] int8, 8x the packed size, written to the workspace);
 //   * a wave keeps 64 queries resident as the B operand (2 column tiles x 8 K-steps x 16 bytes per lane = 64 VGPRs,
 //     expanded from the packed descriptors at kernel start); the workgroup (4 waves, 256 queries) streams train tiles of
