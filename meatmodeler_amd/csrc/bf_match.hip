@@ -610,7 +610,7 @@ __global__ __launch_bounds__(256) void bf_expand_fp4_kernel(const uint8_t *__res
     reinterpret_cast<bf_v4i *>(out)[g] = bf_fp4x32(bits);
 }
 
-__global__ __launch_bounds__(BF_THREADS) void bf_knn2_fp4_kernel(
+__global__ __launch_bounds__(BF_THREADS, 3) void bf_knn2_fp4_kernel(
     const uint8_t *__restrict__ q, const int32_t *__restrict__ nq_dev, int nq_cap, size_t q_stride,
     const uint8_t *__restrict__ tx, const int32_t *__restrict__ nt_dev, int nt_cap, int ntp,
     int32_t *__restrict__ idx, int32_t *__restrict__ dist) {
@@ -688,14 +688,29 @@ __global__ __launch_bounds__(BF_THREADS) void bf_knn2_fp4_kernel(
                 s0[u][p] = s1[u][p] = 0xFFFFFFFFu;
             }
     };
-    auto tile_step = [&](int tt, auto partial_tag) __attribute__((always_inline)) {
-        constexpr bool PARTIAL = decltype(partial_tag)::value;
+    // One train tile = two phases of 4 matrix instructions; the vector work that goes with a phase's results runs in the
+    // shadow of the NEXT phase's matrix instructions (4 MFMA ~ 136 cycles beside 8 key updates = 32 VALU instructions):
+    //   phase 1 of tile t: MFMA of query tile 0  |  bookkeeping of query tile 1 of tile t-1 (carried across the barrier)
+    //   phase 2 of tile t: MFMA of query tile 1  |  bookkeeping of query tile 0 of tile t
+    // The matrix instruction delivers the 16-bit key itself: the queries are negated and the train operand carries the
+    // block scale 2^6, so a tile adds -64 s to accumulators that start at 1.5 * 2^23 + 16384 + tile number -- the key
+    // dist * 128 + tile number = 16384 - 64 s + tno then sits in the low 16 mantissa bits (all sums are integers below
+    // 2^24: exact).  Left for the vector unit: pack two keys (v_perm_b32) and the two-smallest update, 2 instructions
+    // per descriptor pair.
+    auto keys = [&](const bf_v16f &acc, int u, int p, int dead_from) __attribute__((always_inline)) {
+        const float f_hi = acc[2 * p + 1], f_lo = acc[2 * p];      // (values first: a bit cast of the element reference reads element 0)
+        uint32_t k = bf_pk_lo16(__float_as_uint(f_hi), __float_as_uint(f_lo));
+        if (dead_from >= 0) {      // (compile-time -1 in the loop) partial last tile: rows past the last train never win
+            const int m = 8 * (p >> 1) + 4 * h + 2 * (p & 1);
+            k |= (m >= dead_from ? 0x0000FFFFu : 0u) | (m + 1 >= dead_from ? 0xFFFF0000u : 0u);
+        }
+        bf_pk_top2(k, s0[u][p], s1[u][p]);
+    };
+    bf_v16f acc1_prev;      // query tile 1 of the previous train tile, bookkeeping pending
+    bool pending = false;   // (workgroup-uniform)
+    auto tile_step = [&](int tt, auto first_tag) __attribute__((always_inline)) {
+        constexpr bool HAVE_PREV = !decltype(first_tag)::value;
         const int buf = tt & 1;
-        // The matrix instruction delivers the 16-bit key itself: the queries are negated and the train operand carries the
-        // block scale 2^6, so a tile adds -64 s to accumulators that start at 1.5 * 2^23 + 16384 + tile number -- the key
-        // dist * 128 + tile number = 16384 - 64 s + tno then sits in the low 16 mantissa bits (all sums are integers below
-        // 2^24: exact).  Left for the vector unit: pack two keys (v_perm_b32) and the two-smallest update, 2 instructions
-        // per descriptor pair.
         const uint32_t tno = (uint32_t)(tt & (MF_SEG - 1));
         const float init = 12582912.0f + 16384.0f + (float)tno;
         bf_v16f acc0 = {init, init, init, init, init, init, init, init, init, init, init, init, init, init, init, init};
@@ -706,28 +721,25 @@ __global__ __launch_bounds__(BF_THREADS) void bf_knn2_fp4_kernel(
             const bf_v4i a = *reinterpret_cast<const bf_v4i *>(&tile[buf][c][32 * j + 16 * h]);
             A[j] = bf_v8i{a[0], a[1], a[2], a[3], 0, 0, 0, 0};
         }
-        auto keys = [&](const bf_v16f &acc, int u, int p) __attribute__((always_inline)) {
-            const float f_hi = acc[2 * p + 1], f_lo = acc[2 * p];      // (values first: a bit cast of the element reference reads element 0)
-            uint32_t k = bf_pk_lo16(__float_as_uint(f_hi), __float_as_uint(f_lo));
-            if constexpr (PARTIAL) {
-                const int m = tt * MF_TT + 8 * (p >> 1) + 4 * h + 2 * (p & 1);
-                k |= (m >= nt ? 0x0000FFFFu : 0u) | (m + 1 >= nt ? 0xFFFF0000u : 0u);
-            }
-            bf_pk_top2(k, s0[u][p], s1[u][p]);
-        };
         // cbsz = blgp = 4: both operands FP4; block scales (E8M0): train operand 133 = 2^6, queries 127 = 1.0
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[j], B[0][j], acc0, 4, 4, 0, 133, 0, 127);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int j = 0; j < 4; ++j) {
+            acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[j], B[0][j], acc0, 4, 4, 0, 133, 0, 127);
+            if constexpr (HAVE_PREV) {
+                keys(acc1_prev, 1, 2 * j, -1);
+                keys(acc1_prev, 1, 2 * j + 1, -1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (HAVE_PREV && ((tt - 1) & (MF_SEG - 1)) == MF_SEG - 1) fold((tt - 1) / MF_SEG);      // the previous tile closed a segment
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[j], B[1][j], acc1, 4, 4, 0, 133, 0, 127);
-            keys(acc0, 0, 2 * j);
-            keys(acc0, 0, 2 * j + 1);
+            keys(acc0, 0, 2 * j, -1);
+            keys(acc0, 0, 2 * j + 1, -1);
             __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int p = 0; p < 8; ++p) keys(acc1, 1, p);
+        acc1_prev = acc1;
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
@@ -739,24 +751,53 @@ __global__ __launch_bounds__(BF_THREADS) void bf_knn2_fp4_kernel(
     fetch(3, I0{});
     __syncthreads();
     const int nfull = nt / MF_TT;
-    auto iteration = [&](int tt, auto next_set) __attribute__((always_inline)) {
-        tile_step(tt, std::false_type{});
-        if ((tt & (MF_SEG - 1)) == MF_SEG - 1) fold(tt / MF_SEG);
+    auto iteration = [&](int tt, auto next_set, auto first_tag) __attribute__((always_inline)) {
+        tile_step(tt, first_tag);
         if (tt + 1 < ntiles) commit((tt & 1) ^ 1, next_set);
         fetch(tt + 4, next_set);
         __syncthreads();
     };
     int tt = 0;
+    if (nfull > 0) {      // peeled: the first tile has no predecessor
+        iteration(0, I1{}, std::true_type{});
+        pending = true;
+        tt = 1;
+        if (tt < nfull) { iteration(tt, I2{}, std::false_type{}); ++tt; }
+        if (tt < nfull) { iteration(tt, I0{}, std::false_type{}); ++tt; }
+    }
     for (; tt + 3 <= nfull; tt += 3) {
-        iteration(tt, I1{});
-        iteration(tt + 1, I2{});
-        iteration(tt + 2, I0{});
+        iteration(tt, I1{}, std::false_type{});
+        iteration(tt + 1, I2{}, std::false_type{});
+        iteration(tt + 2, I0{}, std::false_type{});
     }
     if (tt < nfull) {
-        iteration(tt, I1{});
-        if (tt + 1 < nfull) iteration(tt + 1, I2{});
+        iteration(tt, I1{}, std::false_type{});
+        if (tt + 1 < nfull) iteration(tt + 1, I2{}, std::false_type{});
     }
-    if (nfull < ntiles) tile_step(nfull, std::true_type{});
+    if (pending) {      // bookkeeping of the last complete tile's second query tile
+#pragma unroll
+        for (int p = 0; p < 8; ++p) keys(acc1_prev, 1, p, -1);
+        if (((nfull - 1) & (MF_SEG - 1)) == MF_SEG - 1) fold((nfull - 1) / MF_SEG);
+    }
+    if (nfull < ntiles) {      // the partial last tile, unpipelined
+        const int buf = nfull & 1;
+        const float init = 12582912.0f + 16384.0f + (float)(nfull & (MF_SEG - 1));
+        bf_v16f acc0 = {init, init, init, init, init, init, init, init, init, init, init, init, init, init, init, init};
+        bf_v16f acc1 = acc0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bf_v4i a = *reinterpret_cast<const bf_v4i *>(&tile[buf][c][32 * j + 16 * h]);
+            const bf_v8i A = bf_v8i{a[0], a[1], a[2], a[3], 0, 0, 0, 0};
+            acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B[0][j], acc0, 4, 4, 0, 133, 0, 127);
+            acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B[1][j], acc1, 4, 4, 0, 133, 0, 127);
+        }
+        const int dead_from = nt - nfull * MF_TT;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            keys(acc0, 0, p, dead_from);
+            keys(acc1, 1, p, dead_from);
+        }
+    }
     if (ntiles > 0) fold((ntiles - 1) / MF_SEG);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
