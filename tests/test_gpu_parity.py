@@ -48,6 +48,33 @@ def test_bf_knn2_single_pair_bit_exact(n, seed):
     np.testing.assert_array_equal(pairs[0, :len(po)].cpu().numpy(), po)
 
 
+@pytest.mark.parametrize("variant", ["114", "200", "300"])
+def test_bf_knn2_formulations_agree_with_oracle(variant, monkeypatch):
+    """The three formulations of the Hamming search in csrc/bf_match.hip -- xor / popcount on the vector unit (114), the
+    +1 / -1 GEMM on the int8 matrix instruction (200) and on the FP4 one (300, the default) -- against the C oracle on a
+    ragged batch: per-pair counts that end inside a 32-train tile, an empty train set, duplicates (ties -> lowest train
+    index), and a pair with more than 128 tiles (the 7-bit tile number of the packed keys wraps: segment folding)."""
+    monkeypatch.setenv("MM_BF_VARIANT", variant)
+    rng = np.random.default_rng(11)
+    n_pairs, cap = 4, 4300
+    q = rng.integers(0, 256, (n_pairs, cap, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (n_pairs, cap, 32), dtype=np.uint8)
+    t[0, 70:80] = t[0, 3]                  # ten copies of one train row
+    q[0, 5] = t[0, 3]
+    t[3, 4200] = q[3, 17]                  # an exact match beyond tile 128
+    nq = np.array([300, 1, 257, 4300], np.int32)
+    nt = np.array([1000, 77, 0, 4241], np.int32)      # 1000 = 31 tiles + 8, 77 = 2 tiles + 13, empty, 132 tiles + 17
+    idx, dist = ops.bf_knn2_batched(dev(q), dev(t), dev(nq), dev(nt))
+    idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+    for p in range(n_pairs):
+        io, do = oo.bf_knn2(q[p, :nq[p]], t[p, :nt[p]])
+        np.testing.assert_array_equal(dist[p, :nq[p]], do)
+        np.testing.assert_array_equal(idx[p, :nq[p]], io)
+    assert list(idx[0, 5]) == [3, 70] and list(dist[0, 5]) == [0, 0]
+    assert idx[3, 17, 0] == 4200 and dist[3, 17, 0] == 0
+    assert (idx[2, :257] == -1).all() and (dist[2, :257] == -1).all()
+
+
 def test_bf_knn2_ties_resolve_to_lowest_train_index():
     rng = np.random.default_rng(5)
     t = rng.integers(0, 256, (300, 32), dtype=np.uint8)
