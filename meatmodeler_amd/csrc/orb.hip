@@ -411,22 +411,50 @@ __global__ __launch_bounds__(256) void orb_select_kernel(OrbGeom g, uint8_t *__r
 }
 
 // ---- compaction + Harris ------------------------------------------------------------------------------------------------
+// 25 x the Harris bracket of the 7 x 7 block around (x, y): a = sum Ix^2, b = sum Iy^2, c = sum Ix Iy with 3 x 3 Sobel
+// derivatives.  The 9 x 9 window is read as three (unaligned) words per row; per row the horizontal differences
+// D[c] = p[c+1] - p[c-1] and smoothings S[c] = p[c-1] + 2 p[c] + p[c+1] are formed once, Ix = D[r-1] + 2 D[r] + D[r+1],
+// Iy = S[r+1] - S[r-1]; the sums fit 32 bits (|I| <= 1020, 49 terms).  (One thread per candidate reading 8 bytes per
+// derivative pair from global memory was latency bound: 1.4 ms per clip.)
 __device__ __forceinline__ long long harris25(const uint8_t *img, int pitch, int x, int y) {
-    long long a = 0, bb = 0, c = 0;
-    for (int dy = -3; dy <= 3; ++dy) {
-        const uint8_t *rm = img + (size_t)(y + dy - 1) * pitch + x;
-        const uint8_t *r0 = rm + pitch, *rp = r0 + pitch;
-        for (int dx = -3; dx <= 3; ++dx) {
-            const int ix = 2 * ((int)r0[dx + 1] - (int)r0[dx - 1]) + ((int)rm[dx + 1] - (int)rm[dx - 1]) +
-                           ((int)rp[dx + 1] - (int)rp[dx - 1]);
-            const int iy = 2 * ((int)rp[dx] - (int)rm[dx]) + ((int)rp[dx - 1] - (int)rm[dx - 1]) +
-                           ((int)rp[dx + 1] - (int)rm[dx + 1]);
+    int D[3][7], S[3][7];      // rows r-1, r, r+1 (rotating)
+    int a = 0, bb = 0, c = 0;
+    auto load_row = [&](int r, int slot) __attribute__((always_inline)) {      // r = 0..8 <-> image row y - 4 + r
+        const uint8_t *p = img + (size_t)(y - 4 + r) * pitch + (x - 4);
+        uint32_t w0, w1, w2;
+        __builtin_memcpy(&w0, p, 4);
+        __builtin_memcpy(&w1, p + 4, 4);
+        __builtin_memcpy(&w2, p + 8, 4);
+        int v[9];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[k] = (int)((w0 >> (8 * k)) & 255u);
+            v[4 + k] = (int)((w1 >> (8 * k)) & 255u);
+        }
+        v[8] = (int)(w2 & 255u);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            D[slot][k] = v[k + 2] - v[k];
+            S[slot][k] = v[k] + 2 * v[k + 1] + v[k + 2];
+        }
+    };
+    load_row(0, 0);
+    load_row(1, 1);
+#pragma unroll
+    for (int r = 1; r <= 7; ++r) {      // centre rows y - 3 .. y + 3
+        load_row(r + 1, (r + 1) % 3);
+        const int up = (r - 1) % 3, mid = r % 3, dn = (r + 1) % 3;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const int ix = D[up][k] + 2 * D[mid][k] + D[dn][k];
+            const int iy = S[dn][k] - S[up][k];
             a += ix * ix;
             bb += iy * iy;
             c += ix * iy;
         }
     }
-    return 25 * (a * bb - c * c) - (a + bb) * (a + bb);
+    const long long A = a, B = bb, C = c;
+    return 25 * (A * B - C * C) - (A + B) * (A + B);
 }
 
 __global__ __launch_bounds__(256) void orb_harris_kernel(OrbGeom g, const uint8_t *__restrict__ imgs,
@@ -481,16 +509,33 @@ __global__ __launch_bounds__(256) void orb_rank_kernel(OrbGeom g, uint8_t *__res
         hi = kh[i];
         pi = kkey[i] & 0xFFFFFFu;
     }
-    int rank = 0;
+    // rank = #{j : H_j > H_i} + #{j : H_j == H_i and position_j < position_i}.  Equal Harris values at different positions
+    // are rare, so the main loop only counts the first term and NOTES whether an equal value was seen (itself included:
+    // more than one); the few threads that saw one redo the pass with the tie rule.
+    int rank = 0, n_eq = 0;
     for (int j0 = 0; j0 < m; j0 += 256) {
         __syncthreads();
-        if (j0 + (int)threadIdx.x < m) {
-            sh[threadIdx.x] = kh[j0 + threadIdx.x];
-            sp[threadIdx.x] = kkey[j0 + threadIdx.x] & 0xFFFFFFu;
-        }
+        if (j0 + (int)threadIdx.x < m) sh[threadIdx.x] = kh[j0 + threadIdx.x];
         __syncthreads();
         const int nj = min(256, m - j0);
-        for (int j = 0; j < nj; ++j) rank += (sh[j] > hi) || (sh[j] == hi && sp[j] < pi);
+        for (int j = 0; j < nj; ++j) {
+            rank += sh[j] > hi;
+            n_eq += sh[j] == hi;
+        }
+    }
+    if (__syncthreads_or(i < m && n_eq > 1)) {      // (workgroup-uniform) ties: second pass over the positions
+        for (int j0 = 0; j0 < m; j0 += 256) {
+            __syncthreads();
+            if (j0 + (int)threadIdx.x < m) {
+                sh[threadIdx.x] = kh[j0 + threadIdx.x];
+                sp[threadIdx.x] = kkey[j0 + threadIdx.x] & 0xFFFFFFu;
+            }
+            __syncthreads();
+            if (n_eq > 1) {
+                const int nj = min(256, m - j0);
+                for (int j = 0; j < nj; ++j) rank += sh[j] == hi && sp[j] < pi;
+            }
+        }
     }
     if (i < m && rank < g.nfeat[l]) {
         const size_t o = (size_t)b * g.cap_out + base + rank;
