@@ -52,6 +52,30 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const double *__restr
     if (threadIdx.x == 0) out[0] = t;
 }
 
+// sum_partials_kernel (same sum, same order) that also delivers the trust-region driver's scalar board to the host
+// mailbox: board[cost_slot] = the sum, then board[0 .. count) and a sequence number (system-scope release) go to pinned
+// host memory -- one launch instead of two at the end of every trial step (trf.hip).
+struct MMHostBoard {
+    double v[16];
+    unsigned long long seq;
+};
+__global__ __launch_bounds__(256) void sum_partials_publish_kernel(const double *__restrict__ partial, int n,
+                                                                   double *__restrict__ board, int cost_slot, int count,
+                                                                   MMHostBoard *hb, unsigned long long seq) {
+    __shared__ double sm[4];
+    double acc = 0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
+    const double t = block_sum<256>(acc, sm);
+    if (threadIdx.x == 0) board[cost_slot] = t;
+    if (threadIdx.x < 64) {      // wave 0 (which holds t in its lane 0)
+        const double t0 = __shfl(t, 0, 64);      // (by the whole wave: a shuffle under divergence reads inactive lanes)
+        if ((int)threadIdx.x < count) hb->v[threadIdx.x] = (int)threadIdx.x == cost_slot ? t0 : board[threadIdx.x];
+        __threadfence_system();
+        __builtin_amdgcn_wave_barrier();
+        if (threadIdx.x == 0) __hip_atomic_store(&hb->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // ---- analytic Jacobian blocks (parity surface) --------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ba_jacobian_kernel(mm_ba_problem pb, const double *__restrict__ cams,
                                                           const double *__restrict__ pts, const CamCoef *__restrict__ ctab, double *__restrict__ Jc,
@@ -406,6 +430,10 @@ void mm_cam_table_hold(mm_ctx *ctx, bool on) {
 }                                    // buffer that has been reused for other camera values since)
 void mm_cam_table_invalidate(mm_ctx *ctx) { ctx->cam_tab_for = nullptr; }
 
+// mm_ba_residual whose final sum lands in board[cost_slot] AND in the host mailbox (see sum_partials_publish_kernel)
+int mm_ba_residual_publish(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, const double *pts, void *ws,
+                           size_t ws_bytes, double *board, int cost_slot, int count, void *host_board, unsigned long long seq);
+
 #define MM_CAM_TABLE(ctx, pb, cams)                                               \
     const CamCoef *ctab = nullptr;                                                \
     do {                                                                          \
@@ -532,3 +560,19 @@ int mm_trf_damping(mm_ctx *ctx, const double *gh2, const double *d11, double Del
 }
 
 }  // extern "C"
+
+int mm_ba_residual_publish(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, const double *pts, void *ws,
+                           size_t ws_bytes, double *board, int cost_slot, int count, void *host_board, unsigned long long seq) {
+    int rc = check_pb(ctx, pb, "mm_ba_residual");
+    if (rc) return rc;
+    if (!cams || !pts || !board || !host_board || count > 16 || cost_slot >= count) return mm_fail(ctx, MM_ERR_ARG, "mm_ba_residual_publish: bad argument");
+    if (!ws || ws_bytes < RES_BLOCKS * sizeof(double)) return mm_fail(ctx, MM_ERR_WORKSPACE, "mm_ba_residual: workspace < 16 KiB");
+    int64_t nb = (pb->O + 255) / 256;
+    int blocks = (int)(nb < 1 ? 1 : (nb > RES_BLOCKS ? RES_BLOCKS : nb));
+    MM_CAM_TABLE(ctx, pb, cams);
+    MM_LAUNCH(ctx, "ba_residual_kernel", ba_residual_kernel, dim3(blocks), dim3(256), 0, *pb, cams, pts, ctab, (double *)nullptr, (double *)ws);
+    MM_LAUNCH(ctx, "sum_partials_kernel", sum_partials_publish_kernel, dim3(1), dim3(256), 0, (const double *)ws, blocks, board,
+              cost_slot, count, (MMHostBoard *)host_board, seq);
+    return MM_OK;
+}
+

@@ -49,6 +49,10 @@ int mm_cam_coef_table(mm_ctx *ctx, const double *cams, int F, const void **tab_o
 void mm_cam_table_hold(mm_ctx *ctx, bool on);       // on: the table stays valid for the same camera pointer until ...
 void mm_cam_table_invalidate(mm_ctx *ctx);          // ... the caller says the vector behind it changed
 
+// ba.hip: the residual sweep whose final sum also delivers mm_ba_trf's scalar board to the pinned host mailbox
+int mm_ba_residual_publish(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, const double *pts, void *ws,
+                           size_t ws_bytes, double *board, int cost_slot, int count, void *host_board, unsigned long long seq);
+
 // chol.hip internals used by the overlapped Schur + solve entry point (schur.hip)
 bool mm_chol_fused_eligible(int n, int half_bandwidth);
 int mm_chol_solve_gated(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int half_bandwidth, int32_t *info, void *ws,

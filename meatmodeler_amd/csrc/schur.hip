@@ -370,6 +370,50 @@ __global__ void schur_diag_fill_kernel(mm_ba_problem pb, const double *__restric
     if (threadIdx.x < 6) v[(size_t)i * 6 + threadIdx.x] = gc[(size_t)i * 6 + threadIdx.x];
 }
 
+// point_inverse + schur_diag_fill + cam_table in ONE launch (the banded build's three small preparation steps: each was a
+// launch of a few microseconds in front of every build).  Workgroup b: the points 256 b .., camera b's diagonal block if it
+// has no observation, the table rows of cameras 256 b .. (and its share of the finished-chunk counters).
+__global__ __launch_bounds__(256) void schur_prepare_kernel(mm_ba_problem pb, const double *__restrict__ cams,
+                                                            const double *__restrict__ Bd, const double *__restrict__ Cd,
+                                                            const double *__restrict__ gc, double *__restrict__ Cinv,
+                                                            double *__restrict__ S, double *__restrict__ v,
+                                                            double *__restrict__ tab, int32_t *__restrict__ seg_done) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int64_t k = (int64_t)b * 256 + tid; k < pb.n_seg; k += (int64_t)gridDim.x * 256) seg_done[k] = 0;
+    const int f = b * 256 + tid;
+    if (f < pb.F) {
+        const double *c = cams + (size_t)f * 6;
+        const CamCoef k = cam_coef_of(c);
+        double *t = tab + (size_t)f * CAMTAB;
+        for (int q = 0; q < 6; ++q) t[q] = c[q];
+        t[6] = k.c;
+        t[7] = k.a;
+        t[8] = k.b;
+        t[9] = k.a1;
+        t[10] = k.b1;
+    }
+    if (b < pb.F && pb.cam_ptr[b + 1] == pb.cam_ptr[b]) {      // camera b never appears in a segment: (Bd, gc) as they are
+        const size_t n = (size_t)pb.F * 6;
+        if (tid < 36) S[((size_t)b * 6 + tid / 6) * n + (size_t)b * 6 + tid % 6] = Bd[(size_t)b * 36 + tid];
+        if (tid < 6) v[(size_t)b * 6 + tid] = gc[(size_t)b * 6 + tid];
+    }
+    const int p = b * 256 + tid;
+    if (p < pb.P) {
+        const double *c = Cd + (size_t)p * 6;
+        const double a = c[0], bq = c[1], d = c[2], e = c[3], ff = c[4], g = c[5];
+        const double m00 = e * g - ff * ff, m01 = d * ff - bq * g, m02 = bq * ff - d * e;
+        const double det = a * m00 + bq * m01 + d * m02;
+        const double id = 1.0 / det;
+        double *o = Cinv + (size_t)p * 6;
+        o[0] = m00 * id;
+        o[1] = m01 * id;
+        o[2] = m02 * id;
+        o[3] = (a * g - d * d) * id;
+        o[4] = (bq * d - a * ff) * id;
+        o[5] = (a * e - bq * bq) * id;
+    }
+}
+
 // ---- device-side construction of the co-observation pair list ------------------------------------------------------
 // cnt[o] = number of observations o2 of the same point with camera(o2) <= camera(o); span = max camera distance.
 __global__ __launch_bounds__(256) void pairs_count_kernel(mm_ba_problem pb, int32_t *__restrict__ cnt,
@@ -470,25 +514,25 @@ extern "C" int mm_ba_schur(mm_ctx *ctx, const mm_ba_problem *pb, const double *c
         (pb->O > 0 && (!pb->pt_obs || !pb->cam_obs || !pb->fi || !pb->pi || !pb->obs)))
         return mm_fail(ctx, MM_ERR_ARG, "mm_ba_schur: null pointer");
     if (pb->F == 0) return MM_OK;
-    if (pb->P > 0)
-        MM_LAUNCH(ctx, "point_inverse_kernel", point_inverse_kernel, dim3((pb->P + 255) / 256), dim3(256), 0, pb->P, Cd,
-                  Cinv);
     if (pb->n_seg > 0 && pb->n_chunks > 0 && pb->seg_ids && pb->seg_chunk_ptr && pb->chunk_seg && pb->chunk_begin &&
         pb->chunk_end && pb->pair_o && pb->pair_o2) {
         if (!ws || ws_bytes < mm_ba_schur_workspace_bytes(pb)) return mm_fail(ctx, MM_ERR_WORKSPACE, "mm_ba_schur: workspace too small");
         // banded + deterministic: zero S (the Cholesky touches whole 64-blocks of the band), then the lower blocks
         MM_HIP(ctx, hipMemsetAsync(S, 0, (size_t)pb->F * 6 * pb->F * 6 * sizeof(double), ctx->stream));
-        MM_LAUNCH(ctx, "schur_diag_fill_kernel", schur_diag_fill_kernel, dim3(pb->F), dim3(64), 0, *pb, Bd, gc, S, v);
         const int64_t wgs = (pb->n_chunks + SP_WAVES - 1) / SP_WAVES;
         const SchurWs w = carve_schur_ws(pb, ws);
         SlabSync none = {};
-        MM_LAUNCH(ctx, "cam_table_kernel", cam_table_kernel, dim3((pb->F + 63) / 64), dim3(64), 0, pb->F, cams, w.camtab, w.seg_done,
-                  (int64_t)pb->n_seg);
+        const int prep = (pb->P + 255) / 256 > pb->F ? (pb->P + 255) / 256 : pb->F;
+        MM_LAUNCH(ctx, "schur_prepare_kernel", schur_prepare_kernel, dim3(prep), dim3(256), 0, *pb, cams, Bd, Cd, gc, Cinv, S, v,
+                  w.camtab, w.seg_done);
         MM_LAUNCH(ctx, "schur_pairs_kernel", schur_pairs_kernel, dim3((unsigned)wgs), dim3(64 * SP_WAVES), 0, *pb,
                   (const double *)w.camtab, pts, (const double *)Cinv, gp, w.partial, Bd, gc, S, v, w.seg_done, none, 0u,
                   (unsigned)wgs);
         return MM_OK;
     }
+    if (pb->P > 0)
+        MM_LAUNCH(ctx, "point_inverse_kernel", point_inverse_kernel, dim3((pb->P + 255) / 256), dim3(256), 0, pb->P, Cd,
+                  Cinv);
     const int nwin = (pb->F + SR_WIN - 1) / SR_WIN;
     MM_LAUNCH(ctx, "schur_rows_kernel", schur_rows_kernel, dim3(pb->F, nwin), dim3(256), 0, *pb, cams, pts, Bd, Cinv, gc,
               gp, S, v);

@@ -173,16 +173,8 @@ extern "C" int mm_ba_trf(mm_ctx *ctx, const mm_ba_problem *pb, double *cams, dou
         memset(ctx->host_board, 0, sizeof(HostBoard));
         ctx->host_board_seq = 0;
     }
-    auto read_board = [&](const double *dev, int count) -> int {
-        if (!spin) {
-            MM_HIP(ctx, hipMemcpyAsync(host, dev, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, st));
-            MM_HIP(ctx, hipStreamSynchronize(st));
-            return MM_OK;
-        }
+    auto wait_board = [&](unsigned long long seq, int count) -> int {
         HostBoard *hb = (HostBoard *)ctx->host_board;
-        const unsigned long long seq = ++ctx->host_board_seq;
-        hipLaunchKernelGGL(board_publish_kernel, dim3(1), dim3(64), 0, st, dev, count, hb, seq);
-        MM_LAUNCH_CHECK(ctx, "board_publish_kernel");
         const auto t0 = std::chrono::steady_clock::now();
         unsigned long spins = 0;
         while (__atomic_load_n(&hb->seq, __ATOMIC_ACQUIRE) != seq) {
@@ -196,6 +188,18 @@ extern "C" int mm_ba_trf(mm_ctx *ctx, const mm_ba_problem *pb, double *cams, dou
         }
         for (int i = 0; i < count; ++i) host[i] = ((volatile double *)hb->v)[i];
         return MM_OK;
+    };
+    auto read_board = [&](const double *dev, int count) -> int {
+        if (!spin) {
+            MM_HIP(ctx, hipMemcpyAsync(host, dev, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, st));
+            MM_HIP(ctx, hipStreamSynchronize(st));
+            return MM_OK;
+        }
+        HostBoard *hb = (HostBoard *)ctx->host_board;
+        const unsigned long long seq = ++ctx->host_board_seq;
+        hipLaunchKernelGGL(board_publish_kernel, dim3(1), dim3(64), 0, st, dev, count, hb, seq);
+        MM_LAUNCH_CHECK(ctx, "board_publish_kernel");
+        return wait_board(seq, count);
     };
     // initial cost
     TRF_CALL(mm_ba_residual(ctx, pb, cams_of(x), pts_of(x), nullptr, t.cost2, t.ws_res, t.ws_res_b));
@@ -251,8 +255,14 @@ extern "C" int mm_ba_trf(mm_ctx *ctx, const mm_ba_problem *pb, double *cams, dou
             const double *sc[1] = {t.board};
             TRF_CALL(mm_trf_fused(ctx, 5, in, outv, sc, 0, 0, n, nc, nullptr, t.ws_md, t.ws_md_b));
             mm_cam_table_invalidate(ctx);      // x_new has new contents
+            if (spin) {      // the residual's final sum and the hand-over to the host mailbox are one launch
+                const unsigned long long seq = ++ctx->host_board_seq;
+                TRF_CALL(mm_ba_residual_publish(ctx, pb, cams_of(x_new), pts_of(x_new), t.ws_res, t.ws_res_b, t.board, 14, 16,
+                                                ctx->host_board, seq));
+                return wait_board(seq, 16);   // ---- the host sync of a trial step ----
+            }
             TRF_CALL(mm_ba_residual(ctx, pb, cams_of(x_new), pts_of(x_new), nullptr, t.board + 14, t.ws_res, t.ws_res_b));
-            return read_board(t.board, 16);   // ---- the host sync of a trial step ----
+            return read_board(t.board, 16);
         };
         for (int attempt = 0; attempt < 6 && !solved; ++attempt) {
             TRF_CALL(mm_ba_damp(ctx, F, P, t.B, t.C, t.si, reg_eff, t.Bd, t.Cd));
