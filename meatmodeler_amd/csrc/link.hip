@@ -146,13 +146,14 @@ __device__ __forceinline__ void block_exscan3(const int (&f0)[LK_IPT], const int
     tot[2] = s_w[2][16];
 }
 
-template <bool STATE_IN_LDS>
+template <int LDS_MODE>      // 2: the whole per-pair state in LDS; 1: the three scatter tables only; 0: all in global memory
 __global__ __launch_bounds__(LK_THREADS) void link_kernel(int F, int cap, const int32_t *__restrict__ kp_count,
                                                           const int32_t *__restrict__ match_count,
                                                           const int32_t *__restrict__ matches, LinkWs ws,
                                                           int32_t *__restrict__ track_ptr, int64_t *__restrict__ counts) {
     // The per-pair state (first-owner table, last-match table, hit positions, the two live lists: 9 arrays of `cap`
-    // words) lives in LDS when it fits (cap <= 4096: 144 KB of the CU's 160 KB) -- every phase of a pair is a dependent
+    // words) lives in LDS when it fits (cap <= 4096: 144 KB of the CU's 160 KB; up to the 8192 key points of a 4K frame the
+    // three scatter tables still do: 96 KB) -- every phase of a pair is a dependent
     // round trip to these arrays, ~2 us each through global memory, a few hundred ns through LDS.
     // (A template parameter, not a run-time choice, and the two live lists addressed by offset rather than through an
     // array of pointers indexed by `cur`: with one provenance per access the compiler emits ds_* instructions.  Flat
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(LK_THREADS) void link_kernel(int F, int cap, const 
     // before it: 8 of the 14 us of a pair.)
     extern __shared__ int32_t lds_state[];
     int32_t *owner, *lastm, *hitpos;
-    if constexpr (STATE_IN_LDS) {
+    if constexpr (LDS_MODE >= 1) {
         owner = lds_state;
         lastm = lds_state + cap;
         hitpos = lds_state + 2 * cap;
@@ -170,15 +171,15 @@ __global__ __launch_bounds__(LK_THREADS) void link_kernel(int F, int cap, const 
         hitpos = ws.hitpos;
     }
     auto live_track = [&](int b, int i) -> int32_t & {
-        if constexpr (STATE_IN_LDS) return lds_state[(3 + 3 * b) * cap + i];
+        if constexpr (LDS_MODE == 2) return lds_state[(3 + 3 * b) * cap + i];
         else return ws.live_track[b][i];
     };
     auto live_kp = [&](int b, int i) -> int32_t & {
-        if constexpr (STATE_IN_LDS) return lds_state[(4 + 3 * b) * cap + i];
+        if constexpr (LDS_MODE == 2) return lds_state[(4 + 3 * b) * cap + i];
         else return ws.live_kp[b][i];
     };
     auto live_node = [&](int b, int i) -> int32_t & {
-        if constexpr (STATE_IN_LDS) return lds_state[(5 + 3 * b) * cap + i];
+        if constexpr (LDS_MODE == 2) return lds_state[(5 + 3 * b) * cap + i];
         else return ws.live_node[b][i];
     };
     __shared__ int s_wave[17];
@@ -409,21 +410,20 @@ int mm_link_tracks_device(mm_ctx *ctx, int n_frames, int cap, const int32_t *kp_
     if (ws_bytes < carve(w, (uint8_t *)ws, n_frames, cap)) return mm_fail(ctx, MM_ERR_WORKSPACE, "mm_link_tracks_device: workspace too small");
     MM_LAUNCH(ctx, "link_canon_kernel", link_canon_kernel, dim3((cap + 255) / 256, n_frames), dim3(256), 0, cap, kp_count,
               kp_xy, w.canon);
-    const bool state_in_lds = cap <= 4096;
-    if (state_in_lds) {
-        const size_t lds_bytes = (size_t)9 * cap * sizeof(int32_t);
-        static size_t lds_set = 0;
-        if (lds_bytes > 48 * 1024 && lds_bytes > lds_set) {
-            MM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(link_kernel<true>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-            lds_set = lds_bytes;
-        }
-        MM_LAUNCH(ctx, "link_kernel", link_kernel<true>, dim3(1), dim3(LK_THREADS), lds_bytes, n_frames, cap, kp_count,
-                  match_count, matches, w, track_ptr, counts);
-    } else {
-        MM_LAUNCH(ctx, "link_kernel", link_kernel<false>, dim3(1), dim3(LK_THREADS), 0, n_frames, cap, kp_count, match_count,
-                  matches, w, track_ptr, counts);
+    const int lds_mode = cap <= 4096 ? 2 : 1;      // (cap <= LK_MAX_CAP = 8192: the three tables always fit)
+    const size_t lds_bytes = (size_t)(lds_mode == 2 ? 9 : 3) * cap * sizeof(int32_t);
+    static size_t lds_set[3] = {0, 0, 0};
+    if (lds_bytes > 48 * 1024 && lds_bytes > lds_set[lds_mode]) {
+        const void *fn = lds_mode == 2 ? reinterpret_cast<const void *>(link_kernel<2>) : reinterpret_cast<const void *>(link_kernel<1>);
+        MM_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        lds_set[lds_mode] = lds_bytes;
     }
+    if (lds_mode == 2)
+        MM_LAUNCH(ctx, "link_kernel", link_kernel<2>, dim3(1), dim3(LK_THREADS), lds_bytes, n_frames, cap, kp_count,
+                  match_count, matches, w, track_ptr, counts);
+    else
+        MM_LAUNCH(ctx, "link_kernel", link_kernel<1>, dim3(1), dim3(LK_THREADS), lds_bytes, n_frames, cap, kp_count,
+                  match_count, matches, w, track_ptr, counts);
     const size_t max_tracks = (size_t)(n_frames - 1) * cap;
     MM_LAUNCH(ctx, "link_emit_kernel", link_emit_kernel, dim3((unsigned)((max_tracks + 255) / 256)), dim3(256), 0, w,
               (const int32_t *)track_ptr, (const int64_t *)counts, obs_frame, obs_kp);
