@@ -61,6 +61,11 @@ int mm_profile_report(mm_ctx *ctx, char *buf, size_t buf_len);
  *   idx  [n_pairs, nq_cap, 2] int32 : train index of the nearest / second nearest (-1 if absent)
  *   dist [n_pairs, nq_cap, 2] int32 : their Hamming distances (-1 if absent)
  * Rows >= nq[p] are left untouched.
+ * The distances are computed on the matrix cores (descriptors expanded to +1 / -1 FP4 values: dot product = 256 - 2 dist,
+ * exact); the workspace holds the expanded train sets, 128 bytes per train descriptor (mm_bf_workspace_bytes; 16-byte
+ * aligned).  Train sets of fewer than 64 or of 65536 and more descriptors take the xor / popcount kernel instead;
+ * MM_BF_VARIANT=114 (xor / popcount), 200 (int8 MFMA), 300 (FP4 MFMA, default) in the environment selects one -- all
+ * return identical results.
  */
 size_t mm_bf_workspace_bytes(int n_pairs, int nq_cap, int nt_cap);
 int mm_bf_knn2_batched(mm_ctx *ctx, const uint8_t *q /*dev*/, const int32_t *nq /*dev|NULL*/, int nq_cap,
