@@ -852,7 +852,7 @@ extern "C" {
 
 size_t mm_bf_workspace_bytes(int n_pairs, int nq_cap, int nt_cap) {
     if (n_pairs > 0 && nq_cap > 0 && bf_use_mfma(n_pairs, nq_cap, nt_cap))
-        return mm_align_up((size_t)n_pairs * bf_ntp(nt_cap) * 256, 256);      // the expanded train sets
+        return mm_align_up((size_t)n_pairs * bf_ntp(nt_cap) * (bf_variant(n_pairs, nq_cap) == 300 ? 128 : 256), 256);   // expanded train sets
     int s = bf_choose_splits(n_pairs, nq_cap, nt_cap);
     if (s == 1) return 256;
     return mm_align_up((size_t)n_pairs * s * nq_cap * 2 * sizeof(uint32_t), 256);
