@@ -226,9 +226,9 @@ __global__ __launch_bounds__(256) void ba_jvp_dots_kernel(mm_ba_problem pb, cons
     __shared__ double sm[(256 / 64) * 2];
     if (threadIdx.x < 9) Ks[threadIdx.x] = pb.K[threadIdx.x];
     __syncthreads();
-    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    // (grid-stride: at most JVP_MAX_WG workgroups, so the follow-up launch adds a few hundred partials, not thousands)
     double acc[2] = {0.0, 0.0};
-    if (o < pb.O) {
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < pb.O; o += (int64_t)gridDim.x * 256) {
         const int f = pb.fi[o], p = pb.pi[o];
         Proj pr;
         ba_eval_cc<true, true>(cams + (size_t)f * 6, ctab[f],
@@ -252,8 +252,9 @@ __global__ __launch_bounds__(256) void ba_jvp_dots_kernel(mm_ba_problem pb, cons
         }
         out[2 * o] = y0;
         out[2 * o + 1] = y1;
-        acc[1] = y0 * y0 + y1 * y1;
-        acc[0] = other ? y0 * other[2 * o] + y1 * other[2 * o + 1] : acc[1];
+        const double sq = y0 * y0 + y1 * y1;
+        acc[1] += sq;
+        acc[0] += other ? y0 * other[2 * o] + y1 * other[2 * o + 1] : sq;
     }
     block_sum_n<2, 256>(acc, sm);
     if (threadIdx.x == 0) {
@@ -380,6 +381,7 @@ int check_pb(mm_ctx *ctx, const mm_ba_problem *pb, const char *who) {
 }
 
 constexpr int RES_BLOCKS = 2048;
+constexpr int JVP_MAX_WG = 2048;      // workgroups of the Jacobian product with fused inner products (grid-stride beyond)
 
 // Regulariser of the 2-D subspace trust-region step, on the device so that the host does not have to wait for the
 // three scalars before the reduced system can be built (SciPy trf.py:473-477 via least_squares(method='trf',
@@ -519,7 +521,8 @@ int mm_ba_jvp_dots(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, con
         MM_HIP(ctx, hipMemsetAsync(rows, 0, 6 * sizeof(double), ctx->stream));
         return MM_OK;
     }
-    const unsigned n_wg = (unsigned)((pb->O + 255) / 256);
+    const int64_t n_all = (pb->O + 255) / 256;
+    const unsigned n_wg = (unsigned)(n_all < JVP_MAX_WG ? n_all : JVP_MAX_WG);
     MM_CAM_TABLE(ctx, pb, cams);
     MM_LAUNCH(ctx, "ba_jvp_kernel", ba_jvp_dots_kernel, dim3(n_wg), dim3(256), 0, *pb, cams, pts, ctab, wc, wp, out, other,
               (double *)((char *)ws + 256));
