@@ -560,7 +560,7 @@ constexpr int DB = 33;  // blurred patch side, offsets -16..16
 constexpr int DESC_WAVES = 4;
 constexpr int DESC_KP_PER_WAVE = 8;  // key points a wave describes one after the other (the next patch prefetched)
 
-__global__ __launch_bounds__(64 * DESC_WAVES) void orb_describe_kernel(OrbGeom g, const uint8_t *__restrict__ imgs,
+__global__ __launch_bounds__(64 * DESC_WAVES, 5) void orb_describe_kernel(OrbGeom g, const uint8_t *__restrict__ imgs,
                                                                        const uint8_t *__restrict__ ws,
                                                                        const int8_t *__restrict__ pattern,
                                                                        const int32_t *__restrict__ kp_meta,
