@@ -306,3 +306,12 @@ int orc_ratio_filter(const int32_t *idx, const int32_t *dist, int nq, double thr
     }
     return m;
 }
+
+/* ---- single-stage entry points for tests/test_oracle_definitions.py (the stages above, one at a time) ---- */
+void orc_fast_score_map(const uint8_t *img, int H, int W, int pitch, int t, uint8_t *score /*[H*W], 0 on the 3-px rim*/) {
+    memset(score, 0, (size_t)H * W);
+    for (int y = 3; y < H - 3; ++y)
+        for (int x = 3; x < W - 3; ++x) score[(size_t)y * W + x] = (uint8_t)fast_score_at(img, pitch, x, y, t);
+}
+long long orc_harris25_at(const uint8_t *img, int pitch, int x, int y) { return harris25(img, pitch, x, y); }
+int orc_blurred_at(const uint8_t *img, int pitch, int x, int y) { return blurred(img, pitch, x, y); }

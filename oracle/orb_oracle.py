@@ -90,3 +90,36 @@ def ratio_filter(idx, dist, threshold=0.75):
     pairs = np.zeros((len(idx), 2), np.int32)
     m = _lib().orc_ratio_filter(_p(idx), _p(dist), C.c_int(len(idx)), C.c_double(threshold), _p(pairs))
     return pairs[:m]
+
+
+# ---- single stages (tests/test_oracle_definitions.py) ---------------------------------------------------------------
+def fast_score_map(img, t=20):
+    img = np.ascontiguousarray(img, np.uint8)
+    H, W = img.shape
+    out = np.zeros((H, W), np.uint8)
+    _lib().orc_fast_score_map(_p(img), C.c_int(H), C.c_int(W), C.c_int(W), C.c_int(t), _p(out))
+    return out
+
+
+def harris25_at(img, x, y):
+    img = np.ascontiguousarray(img, np.uint8)
+    f = _lib().orc_harris25_at
+    f.restype = C.c_longlong
+    return int(f(_p(img), C.c_int(img.shape[1]), C.c_int(int(x)), C.c_int(int(y))))
+
+
+def blurred_at(img, x, y):
+    img = np.ascontiguousarray(img, np.uint8)
+    f = _lib().orc_blurred_at
+    f.restype = C.c_int
+    return int(f(_p(img), C.c_int(img.shape[1]), C.c_int(int(x)), C.c_int(int(y))))
+
+
+def describe(img, x, y, pattern):
+    img = np.ascontiguousarray(img, np.uint8)
+    pattern = np.ascontiguousarray(pattern, np.int8)
+    desc = np.zeros(32, np.uint8)
+    m10, m01 = C.c_int(0), C.c_int(0)
+    _lib().orc_describe(_p(img), C.c_int(img.shape[1]), C.c_int(int(x)), C.c_int(int(y)), _p(pattern), _p(desc),
+                        C.byref(m10), C.byref(m01))
+    return desc, m10.value, m01.value
