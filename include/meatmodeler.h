@@ -39,6 +39,21 @@ int mm_ctx_create(int device, void *hip_stream, mm_ctx **out);
 void mm_ctx_destroy(mm_ctx *ctx);
 const char *mm_last_error(mm_ctx *ctx);
 int mm_ctx_sync(mm_ctx *ctx); /* (sync) hipStreamSynchronize on the context stream */
+/* Knobs and queries of a context (tests, diagnostics).  Returns the queried value, MM_OK, or a negative error.
+ *   MM_CTL_CHOL_FORCE_ABANDON: the next `value` single-launch banded factorisations on this context give up as if one of
+ *     their workgroups had not become resident (info = -1) -- exercises the fall-back to the launch-per-column path;
+ *   MM_CTL_CHOL_LAST_PATH: path of the last mm_chol_solve* on this context: 1 single launch, 0 per column, -1 none yet;
+ *   MM_CTL_CHOL_RESERVED: workgroups this context currently holds of the per-process budget of co-resident
+ *     factorisation workgroups (one compute unit each; given back at the context's next synchronisation);
+ *   MM_CTL_CU_COUNT: compute units of the device;
+ *   MM_CTL_CHOL_AVOID_FUSED: value != 0: this context takes the launch-per-column factorisation from now on (what a
+ *     caller that sequences the solver itself does after it has seen info = -1); 0: back to the default. */
+#define MM_CTL_CHOL_FORCE_ABANDON 1
+#define MM_CTL_CHOL_LAST_PATH 2
+#define MM_CTL_CHOL_RESERVED 3
+#define MM_CTL_CU_COUNT 4
+#define MM_CTL_CHOL_AVOID_FUSED 5
+long long mm_ctx_control(mm_ctx *ctx, int what, long long value);
 /* HIP-event timing on the context stream (bench.py's roofline leg). */
 int mm_timer_create(mm_ctx *ctx, void **timer_out);
 int mm_timer_start(mm_ctx *ctx, void *timer);
@@ -289,7 +304,8 @@ typedef struct mm_trf_row {
 } mm_trf_row;
 typedef struct mm_trf_report {
     double cost0, cost, optimality, min_damping /* as raised during the solve */;
-    int32_t nfev, njev, status, iterations, log_rows, reserved;
+    int32_t nfev, njev, status, iterations, log_rows;
+    int32_t chol_fallbacks;   /* times the solve switched to the launch-per-column factorisation (info = -1 seen): 0 or 1 */
 } mm_trf_report;
 size_t mm_ba_trf_workspace_bytes(const mm_ba_problem *pb);
 int mm_ba_trf(mm_ctx *ctx, const mm_ba_problem *pb, double *cams /*dev, in/out*/, double *pts /*dev, in/out*/,
@@ -299,9 +315,13 @@ int mm_ba_trf(mm_ctx *ctx, const mm_ba_problem *pb, double *cams /*dev, in/out*/
  * overwritten by L; b [nrhs,n] is overwritten by x.  half_bandwidth: A[i][j] == 0 whenever i - j > half_bandwidth
  * (pass n for a dense matrix); the factorisation and the substitutions skip blocks outside the band.
  * info [1] dev int32: 0 ok, k>0 = non-positive pivot at column k, -1 = the single-launch banded factorisation gave up
- * waiting for a block (never seen; its spin loops are bounded so that a scheduling surprise cannot hang the GPU).
+ * waiting for a block (its spin loops are bounded so that a scheduling surprise cannot hang the GPU; mm_ba_trf then
+ * repeats the solve on the launch-per-column path).
  * Narrow bands (<= 15 blocks of 64) are factored by ONE data-flow scheduled launch, everything else by three launches
- * per block column; MM_CHOL_FUSED=0 in the environment forces the latter. */
+ * per block column; MM_CHOL_FUSED=0 in the environment forces the latter.  The workgroups of the single launch wait for
+ * each other, so all of them must be resident (one per compute unit): every launch reserves its grid out of a
+ * per-process budget of the device's compute units, held until the context's next synchronisation (mm_ctx_sync, the
+ * end of mm_ba_trf); a launch that does not fit -- several contexts solving at once -- takes the per-column path. */
 size_t mm_chol_workspace_bytes(int n);
 /* Solution only: A x = b for ONE right-hand side, A destroyed (the layout of the factor it is overwritten with is
  * unspecified).  both_triangles != 0: both triangles of the band hold A on input; 0: only the lower one (the band of the

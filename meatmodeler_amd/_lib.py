@@ -49,7 +49,7 @@ class TrfRow(C.Structure):
 class TrfReport(C.Structure):
     _fields_ = [("cost0", C.c_double), ("cost", C.c_double), ("optimality", C.c_double), ("min_damping", C.c_double),
                 ("nfev", C.c_int32), ("njev", C.c_int32), ("status", C.c_int32), ("iterations", C.c_int32),
-                ("log_rows", C.c_int32), ("reserved", C.c_int32)]
+                ("log_rows", C.c_int32), ("chol_fallbacks", C.c_int32)]
 
 
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header.
@@ -57,6 +57,7 @@ SIGNATURES = {
     "mm_abi_version": (C.c_int, []),
     "mm_ctx_create": (C.c_int, [C.c_int, vp, C.POINTER(vp)]),
     "mm_ctx_destroy": (None, [vp]),
+    "mm_ctx_control": (C.c_longlong, [vp, C.c_int, C.c_longlong]),
     "mm_last_error": (C.c_char_p, [vp]),
     "mm_ctx_sync": (C.c_int, [vp]),
     "mm_timer_create": (C.c_int, [vp, C.POINTER(vp)]),
@@ -174,6 +175,15 @@ class Context:
 
     def sync(self):
         self.check(lib.mm_ctx_sync(self.h), "mm_ctx_sync")
+
+    CTL_CHOL_FORCE_ABANDON, CTL_CHOL_LAST_PATH, CTL_CHOL_RESERVED, CTL_CU_COUNT, CTL_CHOL_AVOID_FUSED = 1, 2, 3, 4, 5
+
+    def control(self, what, value=0):
+        """mm_ctx_control: knobs / queries of the context (see include/meatmodeler.h)."""
+        r = int(lib.mm_ctx_control(self.h, int(what), int(value)))
+        if r < -1 or (r == -1 and what != self.CTL_CHOL_LAST_PATH):
+            self.check(r, "mm_ctx_control")
+        return r
 
     def profile(self, level):
         """0 off, 1 every launch, 2 launches of >= 64 workgroups only."""

@@ -233,6 +233,7 @@ class SchurTRF:
         # here (what the sharded path and the CPU stand-in of the tests use).  Same kernels, bit-identical iterates.
         self.driver = driver or os.environ.get("MM_TRF_DRIVER", "library")
         self._overlap_checked = False
+        self._avoid_fused = False
 
     # -- reductions that need the cross-rank sum when sharded --
     def _ar(self, *tensors):
@@ -552,7 +553,7 @@ def _solve_library(self, x, ftol, xtol, gtol, max_nfev, verbose):
             print(f"... ({rep.log_rows - len(rows)} more iterations)")
     return BAResult(cams=self._cams(x).clone(), pts=self._pts(x).clone(), cost=rep.cost, optimality=rep.optimality,
                     nfev=rep.nfev, njev=rep.njev, status=rep.status, message=_MESSAGES[rep.status],
-                    success=rep.status > 0, iterations=rep.iterations,
+                    success=rep.status > 0, iterations=rep.iterations, chol_fallbacks=rep.chol_fallbacks,
                     host_segments_ms={"library": 1e3 * (time.perf_counter() - t0)})
 
 
@@ -679,6 +680,15 @@ def _solve_device(self, x, g, cost, half_bw, band_exchange, ftol, xtol, gtol, ma
                 if ar is None and getattr(pb, "overlap", False):
                     self._serial_fallback(x, Bd, Cd, gc, gp, half_bw, solve=False)
                     continue
+                if not self._avoid_fused and hasattr(pb, "ctx"):
+                    # its workgroups were not co-resident (another tenant on the GPU): repeat the attempt, same
+                    # damping, on the launch-per-column factorisation and stay there for the rest of the solve.
+                    # (Sharded: every rank reads the same replicated board... but info is LOCAL -- a rank-local decision
+                    # would desynchronise the collectives, so the switch is only taken on one GPU.)
+                    if ar is None:
+                        self._avoid_fused = True
+                        pb.ctx.control(pb.ctx.CTL_CHOL_AVOID_FUSED, 1)
+                        continue
                 raise MMError("mm_chol_solve: the fused banded factorisation was abandoned (info = -1)")
             if vals[13] <= self.min_damping * (1.0 + 1e-12):      # failed AT the floor: the floor was too low
                 self.min_damping *= 100.0

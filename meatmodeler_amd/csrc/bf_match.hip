@@ -815,6 +815,215 @@ __global__ __launch_bounds__(BF_THREADS, 3) void bf_knn2_fp4_kernel(
     }
 }
 
+// ---- FP4 matrix cores, one candidate per (lane, train tile): the bookkeeping cut from 2 to ~0.4 VALU per pair ------------
+// In bf_knn2_fp4_kernel the vector unit is the limiter: pack + two-smallest update of every accumulator is 2 instructions
+// per descriptor pair, 64 per wave and train tile, plus 32 v_mov to re-initialise the accumulators with the tile number:
+// ~400 cycles beside ~270 cycles of matrix instructions, and the two do not overlap well.  Here the 16 accumulators of a
+// lane (16 trains x 1 query) only feed a MINIMUM: the row of each accumulator rides in the low bits of the value itself
+// (C operand = 1.5 * 2^23 + 2^18 + row, a per-lane constant in registers that is never rewritten; train block scale 2^10:
+// acc = 1.5 * 2^23 + 2^11 * dist + row, exact), so the tile's best (dist, row) is an 8-instruction v_min3_u32 tree over
+// the raw bit patterns, 3 instructions turn it into a key  dist << 22 | tile * 32 + row, 2 more (v_med3 / v_min) keep the
+// lane's two smallest tile minima: 13 instructions per 16 pairs.  The exact two smallest of a query are then
+//     best   = the smallest tile minimum (tile t0),
+//     second = min(the smallest minimum of the other tiles, the SECOND smallest inside tile t0),
+// and the second term is recomputed once per (lane, query) at the end of the kernel with xor / popcount on the 15 other
+// rows of that one tile (packed descriptors from global memory): ~300 instructions per lane and query against ~6000 saved.
+// Ties go to the lowest train index as everywhere (keys order by (dist, tile, row)).
+constexpr uint32_t F4M_BASE = 0x4B400000u;      // bit pattern of 1.5 * 2^23
+
+template <bool PARTIAL>
+__device__ __forceinline__ uint32_t f4m_tile_key(const bf_v16f &acc, uint32_t tile32, int h, int dead_from) {
+    uint32_t v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float f = acc[i];      // (value first: a bit cast of the element reference reads element 0)
+        v[i] = __float_as_uint(f);
+        if constexpr (PARTIAL) {
+            const int m = 8 * (i >> 2) + 4 * h + (i & 3);
+            if (m >= dead_from) v[i] = 0xFFFFFFFFu;
+        }
+    }
+    // minimum of 16 as v_min3_u32 x 8 (all values share sign and exponent: unsigned order = numeric order)
+    const uint32_t m0 = min(min(v[0], v[1]), v[2]), m1 = min(min(v[3], v[4]), v[5]), m2 = min(min(v[6], v[7]), v[8]);
+    const uint32_t m3 = min(min(v[9], v[10]), v[11]), m4 = min(min(v[12], v[13]), v[14]);
+    const uint32_t n0 = min(min(m0, m1), m2), n1 = min(min(m3, m4), v[15]);
+    const uint32_t m = min(n0, n1);
+    // key = dist << 22 | tile * 32 + row   (mask: mantissa bits 5..21 = dist << 11; bit 22 is the 1.5)
+    uint32_t k = ((m & 0x003FFFE0u) << 11) + tile32;
+    k = (m & 31u) | k;
+    if constexpr (PARTIAL) k = m == 0xFFFFFFFFu ? BF_NONE : k;
+    return k;
+}
+
+__device__ __forceinline__ void f4m_update(uint32_t k, uint32_t &b0, uint32_t &b1) {      // b0 <= b1
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(b1) : "v"(b0), "v"(b1), "v"(k));      // = min(max(b0, k), b1) for b0 <= b1
+    b0 = min(b0, k);
+}
+
+__global__ __launch_bounds__(BF_THREADS, 3) void bf_knn2_fp4min_kernel(
+    const uint8_t *__restrict__ q, const int32_t *__restrict__ nq_dev, int nq_cap, size_t q_stride,
+    const uint8_t *__restrict__ tx, const uint8_t *__restrict__ tpk, size_t t_stride, const int32_t *__restrict__ nt_dev,
+    int nt_cap, int ntp, int32_t *__restrict__ idx, int32_t *__restrict__ dist) {
+    __shared__ __attribute__((aligned(16))) uint8_t tile[2][MF_TT][F4_PITCH];
+    const int pair = blockIdx.z;
+    const int nq = nq_dev ? min(nq_dev[pair], nq_cap) : nq_cap;
+    const int nt = nt_dev ? min(nt_dev[pair], nt_cap) : nt_cap;
+    const int qbase = blockIdx.x * BF_THREADS;
+    if (qbase >= nq) return;  // workgroup-uniform
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    bf_v8i B[2][4];
+    const uint8_t *qp = q + (size_t)pair * q_stride;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int qi = qbase + 64 * wv + 32 * u + c;
+        uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
+        if (qi < nq) {
+            const uint4 *p = reinterpret_cast<const uint4 *>(qp + (size_t)qi * 32);
+            lo = p[0];
+            hi = p[1];
+        }
+        const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bf_v4i e = bf_fp4x32(~(h ? w[2 * j + 1] : w[2 * j]));      // queries enter NEGATED
+            B[u][j] = bf_v8i{e[0], e[1], e[2], e[3], 0, 0, 0, 0};
+        }
+    }
+    // C operand: 1.5 * 2^23 + 2^18 + row of accumulator i (rows 8 (i / 4) + 4 h + i % 4): never rewritten
+    bf_v16f cinit;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) cinit[i] = 12582912.0f + 262144.0f + (float)(8 * (i >> 2) + 4 * h + (i & 3));
+    uint32_t b0[2] = {BF_NONE, BF_NONE}, b1[2] = {BF_NONE, BF_NONE};      // the two smallest tile minima per query
+    const int ntiles = (nt + MF_TT - 1) / MF_TT;
+    const uint8_t *txp = tx + (size_t)pair * ntp * 128;
+    const int e0 = threadIdx.x;
+    bf_v4i ra, rb, rc;
+    auto fetch = [&](int tt, auto set) __attribute__((always_inline)) {
+        constexpr int S = decltype(set)::value;
+        if (tt < ntiles) {      // (workgroup-uniform)
+            const bf_v4i v = reinterpret_cast<const bf_v4i *>(txp + (size_t)tt * MF_TT * 128)[e0];
+            if constexpr (S == 0) ra = v;
+            if constexpr (S == 1) rb = v;
+            if constexpr (S == 2) rc = v;
+        }
+    };
+    auto commit = [&](int buf, auto set) __attribute__((always_inline)) {
+        constexpr int S = decltype(set)::value;
+        bf_v4i *d = reinterpret_cast<bf_v4i *>(&tile[buf][e0 >> 3][(e0 & 7) * 16]);
+        if constexpr (S == 0) *d = ra;
+        if constexpr (S == 1) *d = rb;
+        if constexpr (S == 2) *d = rc;
+    };
+    // One train tile = two phases of 4 matrix instructions (query tile 0, query tile 1); the 13 vector instructions that
+    // go with a phase's results run in the shadow of the NEXT phase's matrix instructions (query tile 1 of tile t-1 beside
+    // query tile 0 of tile t: carried across the barrier).  cbsz = blgp = 4: FP4 operands; block scales (E8M0): train
+    // operand 137 = 2^10, queries 127 = 1.0.
+    bf_v16f acc1_prev;
+    auto tile_step = [&](int tt, auto first_tag) __attribute__((always_inline)) {
+        constexpr bool HAVE_PREV = !decltype(first_tag)::value;
+        const int buf = tt & 1;
+        bf_v8i A[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bf_v4i a = *reinterpret_cast<const bf_v4i *>(&tile[buf][c][32 * j + 16 * h]);
+            A[j] = bf_v8i{a[0], a[1], a[2], a[3], 0, 0, 0, 0};
+        }
+        bf_v16f acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[0], B[0][0], cinit, 4, 4, 0, 137, 0, 127);
+        if constexpr (HAVE_PREV) f4m_update(f4m_tile_key<false>(acc1_prev, (uint32_t)(tt - 1) * MF_TT, h, 0), b0[1], b1[1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 1; j < 4; ++j) acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[j], B[0][j], acc0, 4, 4, 0, 137, 0, 127);
+        bf_v16f acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[0], B[1][0], cinit, 4, 4, 0, 137, 0, 127);
+        f4m_update(f4m_tile_key<false>(acc0, (uint32_t)tt * MF_TT, h, 0), b0[0], b1[0]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 1; j < 4; ++j) acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[j], B[1][j], acc1, 4, 4, 0, 137, 0, 127);
+        acc1_prev = acc1;
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    fetch(0, I0{});
+    fetch(1, I1{});
+    fetch(2, I2{});
+    if (ntiles > 0) commit(0, I0{});
+    fetch(3, I0{});
+    __syncthreads();
+    const int nfull = nt / MF_TT;
+    auto iteration = [&](int tt, auto next_set, auto first_tag) __attribute__((always_inline)) {
+        tile_step(tt, first_tag);
+        if (tt + 1 < ntiles) commit((tt & 1) ^ 1, next_set);
+        fetch(tt + 4, next_set);
+        __syncthreads();
+    };
+    int tt = 0;
+    if (nfull > 0) {      // peeled: the first tile has no predecessor
+        iteration(0, I1{}, std::true_type{});
+        tt = 1;
+        if (tt < nfull) { iteration(tt, I2{}, std::false_type{}); ++tt; }
+        if (tt < nfull) { iteration(tt, I0{}, std::false_type{}); ++tt; }
+    }
+    for (; tt + 3 <= nfull; tt += 3) {
+        iteration(tt, I1{}, std::false_type{});
+        iteration(tt + 1, I2{}, std::false_type{});
+        iteration(tt + 2, I0{}, std::false_type{});
+    }
+    if (tt < nfull) {
+        iteration(tt, I1{}, std::false_type{});
+        if (tt + 1 < nfull) iteration(tt + 1, I2{}, std::false_type{});
+    }
+    if (nfull > 0) f4m_update(f4m_tile_key<false>(acc1_prev, (uint32_t)(nfull - 1) * MF_TT, h, 0), b0[1], b1[1]);
+    if (nfull < ntiles) {      // the partial last tile, unpipelined: rows past the last train never win
+        const int buf = nfull & 1;
+        bf_v16f acc0 = cinit, acc1 = cinit;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bf_v4i a = *reinterpret_cast<const bf_v4i *>(&tile[buf][c][32 * j + 16 * h]);
+            const bf_v8i A = bf_v8i{a[0], a[1], a[2], a[3], 0, 0, 0, 0};
+            acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B[0][j], acc0, 4, 4, 0, 137, 0, 127);
+            acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B[1][j], acc1, 4, 4, 0, 137, 0, 127);
+        }
+        const int dead_from = nt - nfull * MF_TT;
+        f4m_update(f4m_tile_key<true>(acc0, (uint32_t)nfull * MF_TT, h, dead_from), b0[0], b1[0]);
+        f4m_update(f4m_tile_key<true>(acc1, (uint32_t)nfull * MF_TT, h, dead_from), b0[1], b1[1]);
+    }
+    // the second smallest INSIDE the best tile, by xor / popcount on the lane's 15 other rows of that tile
+    const uint8_t *tp = tpk + (size_t)pair * t_stride;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int qi = qbase + 64 * wv + 32 * u + c;
+        if (b0[u] != BF_NONE) {
+            const uint4 *p = reinterpret_cast<const uint4 *>(qp + (size_t)min(qi, nq - 1) * 32);
+            const uint4 lo = p[0], hi = p[1];
+            const uint32_t a[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            const uint32_t best_idx = b0[u] & 0xFFFFu, t0 = best_idx & ~31u;
+            uint32_t c2 = BF_NONE;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const uint32_t ti = t0 + (uint32_t)(8 * (i >> 2) + 4 * h + (i & 3));
+                if (ti != best_idx && ti < (uint32_t)nt) {
+                    const uint4 *r = reinterpret_cast<const uint4 *>(tp + (size_t)ti * 32);
+                    const uint32_t d = ham256(a, r[0], r[1]);
+                    c2 = min(c2, (d << 22) | ti);
+                }
+            }
+            b1[u] = min(b1[u], c2);
+        }
+        // the two lanes of a query (rows 4 h ..) -> one result
+        const uint32_t o0 = __shfl_xor(b0[u], 32, 64), o1 = __shfl_xor(b1[u], 32, 64);
+        top2_insert(o0, b0[u], b1[u]);
+        top2_insert(o1, b0[u], b1[u]);
+        if (h == 0 && qi < nq) {
+            const size_t o = ((size_t)pair * nq_cap + qi) * 2;
+            idx[o] = b0[u] == BF_NONE ? -1 : (int32_t)(b0[u] & 0xFFFFu);
+            idx[o + 1] = b1[u] == BF_NONE ? -1 : (int32_t)(b1[u] & 0xFFFFu);
+            dist[o] = b0[u] == BF_NONE ? -1 : (int32_t)(b0[u] >> 22);
+            dist[o + 1] = b1[u] == BF_NONE ? -1 : (int32_t)(b1[u] >> 22);
+        }
+    }
+}
+
 // queries per lane: 2 amortises the scalar train loads over two descriptor pairs; small launches use 1 to get more waves.
 // MM_BF_VARIANT=<qpl><unroll> (e.g. 24, 28, 44, 14) overrides for tuning runs.
 int bf_variant(int n_pairs, int nq_cap) {
@@ -827,14 +1036,14 @@ int bf_variant(int n_pairs, int nq_cap) {
 // the MFMA formulation needs train indices below 2^16 and pays off from a few train tiles on
 bool bf_use_mfma(int n_pairs, int nq_cap, int nt_cap) {
     const int v = bf_variant(n_pairs, nq_cap);
-    return (v == 200 || v == 300) && nt_cap >= 64 && nt_cap < 65536;
+    return (v == 200 || v == 300 || v == 310) && nt_cap >= 64 && nt_cap < 65536;
 }
 int bf_ntp(int nt_cap) { return (nt_cap + MF_TT - 1) / MF_TT * MF_TT; }
 
 int bf_choose_splits(int n_pairs, int nq_cap, int nt_cap) {
     if (bf_use_mfma(n_pairs, nq_cap, nt_cap)) return 1;
     int var = bf_variant(n_pairs, nq_cap);
-    if (var == 200 || var == 300) var = 114;      // (shapes the matrix-core kernels do not take)
+    if (var == 200 || var == 300 || var == 310) var = 114;      // (shapes the matrix-core kernels do not take)
     const int BF_QTILE = BF_THREADS * ((var / 10) % 10);
     long waves = (long)n_pairs * ((nq_cap + BF_QTILE - 1) / BF_QTILE) * (BF_THREADS / 64);
     if (waves <= 0) return 1;
@@ -852,7 +1061,7 @@ extern "C" {
 
 size_t mm_bf_workspace_bytes(int n_pairs, int nq_cap, int nt_cap) {
     if (n_pairs > 0 && nq_cap > 0 && bf_use_mfma(n_pairs, nq_cap, nt_cap))
-        return mm_align_up((size_t)n_pairs * bf_ntp(nt_cap) * (bf_variant(n_pairs, nq_cap) == 300 ? 128 : 256), 256);   // expanded train sets
+        return mm_align_up((size_t)n_pairs * bf_ntp(nt_cap) * (bf_variant(n_pairs, nq_cap) >= 300 ? 128 : 256), 256);   // expanded train sets
     int s = bf_choose_splits(n_pairs, nq_cap, nt_cap);
     if (s == 1) return 256;
     return mm_align_up((size_t)n_pairs * s * nq_cap * 2 * sizeof(uint32_t), 256);
@@ -877,10 +1086,15 @@ int mm_bf_knn2_batched(mm_ctx *ctx, const uint8_t *q, const int32_t *nq, int nq_
             return mm_fail(ctx, MM_ERR_WORKSPACE, "mm_bf_knn2_batched: workspace too small or misaligned");
         const int ntp = bf_ntp(nt_cap);
         const dim3 grid((nq_cap + BF_THREADS - 1) / BF_THREADS, 1, n_pairs);
-        if (bf_variant(n_pairs, nq_cap) == 300) {
+        if (bf_variant(n_pairs, nq_cap) >= 300) {
             const size_t chunks = (size_t)n_pairs * ntp * 8;
             MM_LAUNCH(ctx, "bf_expand_kernel", bf_expand_fp4_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, t, nt_cap,
                       t_set_stride, ntp, n_pairs, (uint8_t *)ws);
+            if (bf_variant(n_pairs, nq_cap) == 310) {
+                MM_LAUNCH(ctx, "bf_knn2_kernel", bf_knn2_fp4min_kernel, grid, dim3(BF_THREADS), 0, q, nq, nq_cap, q_set_stride,
+                          (const uint8_t *)ws, t, t_set_stride, nt, nt_cap, ntp, idx, dist);
+                return MM_OK;
+            }
             MM_LAUNCH(ctx, "bf_knn2_kernel", bf_knn2_fp4_kernel, grid, dim3(BF_THREADS), 0, q, nq, nq_cap, q_set_stride,
                       (const uint8_t *)ws, nt, nt_cap, ntp, idx, dist);
             return MM_OK;
@@ -893,7 +1107,7 @@ int mm_bf_knn2_batched(mm_ctx *ctx, const uint8_t *q, const int32_t *nq, int nq_
         return MM_OK;
     }
     int var = bf_variant(n_pairs, nq_cap);
-    if (var == 200 || var == 300) var = 114;      // (shapes the matrix-core kernels do not take)
+    if (var == 200 || var == 300 || var == 310) var = 114;      // (shapes the matrix-core kernels do not take)
     const int qtile = BF_THREADS * ((var / 10) % 10);
     dim3 grid((nq_cap + qtile - 1) / qtile, s, n_pairs);
 #define BF_GO(Q, U)                                                                                              \

@@ -18,6 +18,7 @@
 // MFMA fragment maps for f64 16x16x4 (guide section 3): A lane l -> A[l&15][l>>4], B lane l -> B[l>>4][l&15],
 // D reg i of lane l -> D[(l>>4) + 4 i][l&15].
 #include "mm_common.h"
+#include <atomic>
 #include <cstdlib>
 
 namespace {
@@ -30,6 +31,28 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// wave index inside the workgroup as a SCALAR (the compiler treats threadIdx.x >> 6 as divergent: every row / column
+// offset derived from it would be per-lane arithmetic, and hoisted out of the loops, per-lane registers)
+__device__ __forceinline__ int wave_id() {
+    int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    asm volatile("" : "+s"(w));
+    return w;
+}
+// Lane / thread index behind an opaque barrier: the fused kernel inlines every block operation into loops over block
+// rows, and the optimiser hoists the (cheap) per-lane LDS and global offsets of ALL of them out of those loops -- several
+// hundred live registers, spilled to scratch on the dependency chain.  An index the optimiser cannot see through keeps
+// the address arithmetic next to its use.
+__device__ __forceinline__ int lane_id() {
+    int l = (int)(threadIdx.x & 63);
+    asm volatile("" : "+v"(l));
+    return l;
+}
+__device__ __forceinline__ int thread_id() {
+    int t = (int)threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
 }
 
 __device__ __forceinline__ double readlane_f64(double x, int src_lane /*wave-uniform*/) {
@@ -49,7 +72,7 @@ __device__ __forceinline__ double readlane_f64(double x, int src_lane /*wave-uni
 template <int PB>
 __device__ __forceinline__ void panel16_update(double (*M)[NB + 1]) {
     constexpr int c0 = PB * 16;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = lane_id(), w = wave_id();
     if (16 * w + 15 >= c0) {  // rows above the panel hold final entries / structural zeros
         double4_t acc = {0, 0, 0, 0};
         const int lr = lane & 15, lk = lane >> 4;
@@ -154,7 +177,7 @@ __device__ __forceinline__ void panel16_column(double (&a)[16], double &piv, dou
 template <int PB>
 __device__ __forceinline__ void panel16_factor(double (*M)[NB + 1], double *R) {
     constexpr int c0 = PB * 16;
-    const int lane = threadIdx.x & 63;
+    const int lane = lane_id();
     double a[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
@@ -186,7 +209,7 @@ __device__ __forceinline__ void panel16_factor(double (*M)[NB + 1], double *R) {
 // first column (1-based, offset by k0) whose diagonal entry of L is not a positive number, 0 if none; call with one
 // full wave after the factorisation
 __device__ __forceinline__ int block_first_bad(const double (*M)[NB + 1], int k0) {
-    const int lane = threadIdx.x & 63;
+    const int lane = lane_id();
     const double d = M[lane][lane];
     const unsigned long long m = __ballot(!(d > 0.0 && d < 1.0e300));
     return m ? k0 + (int)__builtin_ctzll(m) + 1 : 0;
@@ -222,7 +245,7 @@ __device__ __forceinline__ void inv_diag16(const double (*M)[NB + 1], double (*X
     // in registers (lane i keeps row i) and its entries reach the FMAs as scalars through v_readlane, like the panel
     // factorisation: no LDS access and no accumulation chain inside the 16 dependent steps.  (Reading L[i][k] from
     // LDS as needed, the compiler serialised ~120 load-wait-FMA triples: 2.5 us instead of ~1.)
-    const int lane = threadIdx.x & 63;
+    const int lane = lane_id();
     const int o = 16 * bi;
     double Lrow[16], x[16];
 #pragma unroll
@@ -255,7 +278,7 @@ __device__ __forceinline__ void inv_diag16(const double (*M)[NB + 1], double (*X
 
 __device__ __forceinline__ void inv_offdiag16(const double (*M)[NB + 1], double (*X)[NB + 1], double (*Tw)[17], int bi,
                                               int bj) {
-    const int lane = threadIdx.x & 63;
+    const int lane = lane_id();
     const int lr = lane & 15, lk = lane >> 4;
     double4_t acc = {0, 0, 0, 0};
     for (int bk = bj; bk < bi; ++bk) {
@@ -283,15 +306,17 @@ __device__ __forceinline__ void inv_offdiag16(const double (*M)[NB + 1], double 
 
 // L (in place, lower triangle of M), the reciprocal pivots R and the four 16 x 16 diagonal blocks of X = L^-1 (the
 // rest of X zeroed); 256 threads.  The diagonal inverses ride on an idle wave while wave 0 factors the next panel.
-struct NoStageA {
-    __device__ void operator()() const {}
+// `pub` streams the block out while it is being factored (the fused kernel): pub.l(k), called by wave 2 as soon as
+// column panel k is final, hands over the 16 x 16 blocks of L below diagonal block k; pub.x(k), called by the wave
+// that inverted diagonal block k, hands over X_kk.  Consumers work panel by panel behind the factorisation.
+struct NoPub {
+    __device__ void l(int) const {}
+    __device__ void x(int) const {}
 };
-// stage_a() is called by wave 2 while wave 0 factors the last panel: at that point every 16 x 16 block of L below the
-// diagonal blocks and the inverses X_00, X_11 are final (the fused kernel publishes them early)
-template <class StageA = NoStageA>
+template <class Pub = NoPub>
 __device__ __forceinline__ void factor_block_lds(double (*M)[NB + 1], double (*X)[NB + 1], double *R, int k0, int &bad,
-                                                 StageA stage_a = StageA()) {
-    const int w = threadIdx.x >> 6;
+                                                 Pub pub = Pub()) {
+    const int w = wave_id();
     if (w == 0) {
         panel16_factor<0>(M, R);
     } else {
@@ -299,26 +324,40 @@ __device__ __forceinline__ void factor_block_lds(double (*M)[NB + 1], double (*X
     }
     __syncthreads();
     panel16_update<1>(M);
+    if (w == 2) pub.l(0);   // (after the update: wave 2 is idle from here, and its store acknowledgements stay off wave 0's path)
     if (w == 0) panel16_factor<1>(M, R);
-    if (w == 1) inv_diag16(M, X, R, 0);
+    if (w == 1) {
+        inv_diag16(M, X, R, 0);
+        pub.x(0);
+    }
     __syncthreads();
     panel16_update<2>(M);
+    if (w == 2) pub.l(1);
     if (w == 0) panel16_factor<2>(M, R);
-    if (w == 1) inv_diag16(M, X, R, 1);
+    if (w == 1) {
+        inv_diag16(M, X, R, 1);
+        pub.x(1);
+    }
     __syncthreads();
     panel16_update<3>(M);
+    if (w == 2) pub.l(2);
     if (w == 0) panel16_factor<3>(M, R);
-    if (w == 1) inv_diag16(M, X, R, 2);
-    if (w == 2) stage_a();
+    if (w == 1) {
+        inv_diag16(M, X, R, 2);
+        pub.x(2);
+    }
     __syncthreads();
-    if (w == 0) inv_diag16(M, X, R, 3);
+    if (w == 0) {
+        inv_diag16(M, X, R, 3);
+        pub.x(3);
+    }
     if (w == 1) bad = block_first_bad(M, k0);
     __syncthreads();
 }
 
 // the blocks of X below the diagonal, level by level (block (w + d, w) on wave w), after factor_block_lds
 __device__ __forceinline__ void inverse_offdiag_lds(const double (*M)[NB + 1], double (*X)[NB + 1], double (*T)[16][17]) {
-    const int w = threadIdx.x >> 6;
+    const int w = wave_id();
 #pragma unroll
     for (int d = 1; d < 4; ++d) {
         if (w + d < 4) inv_offdiag16(M, X, T[w], w + d, w);
@@ -342,7 +381,7 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(double *__restrict__ A, 
     __shared__ double X[NB][NB + 1];
     __shared__ double T[4][16][17];
     __shared__ double R[NB];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = lane_id(), w = wave_id();
     const int nb = min(NB, n - k0);
     {   // wave w loads rows 16w..16w+15, lane = column: coalesced rows, 16 loads in flight per lane
         double v[16];
@@ -369,7 +408,7 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(double *__restrict__ A, 
 
 // 64x64 tile product  acc += As (64 x 64, rows) * Bs^T  on f64 MFMA; wave w owns the 32x32 quadrant (w>>1, w&1).
 __device__ __forceinline__ void tile_gemm_nt(const double (*As)[LDT], const double (*Bs)[LDT], double4_t (&acc)[2][2]) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = lane_id(), w = wave_id();
     const int r0 = (w >> 1) * 32, c0 = (w & 1) * 32;
     const int lr = lane & 15, lk = lane >> 4;
 #pragma unroll 4
@@ -390,7 +429,7 @@ __device__ __forceinline__ void load_tile(double (*T)[LDT], const double *__rest
     double2 v[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        const int e = threadIdx.x + 256 * q;
+        const int e = thread_id() + 256 * q;
         const int r = e / (NB / 2), c = (e % (NB / 2)) * 2;
         double2 t = make_double2(0.0, 0.0);
         if (r < rows) {
@@ -404,7 +443,7 @@ __device__ __forceinline__ void load_tile(double (*T)[LDT], const double *__rest
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        const int e = threadIdx.x + 256 * q;
+        const int e = thread_id() + 256 * q;
         const int r = e / (NB / 2), c = (e % (NB / 2)) * 2;
         T[r][c] = v[q].x;
         T[r][c + 1] = v[q].y;
@@ -428,7 +467,7 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double *__restrict__ A,
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = (double4_t){0, 0, 0, 0};
     tile_gemm_nt(As, Bs, acc);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = lane_id(), w = wave_id();
     const int r0 = (w >> 1) * 32, c0 = (w & 1) * 32;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -462,7 +501,7 @@ __global__ __launch_bounds__(256) void chol_update_kernel(double *__restrict__ A
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = (double4_t){0, 0, 0, 0};
     tile_gemm_nt(As, Bs, acc);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = lane_id(), w = wave_id();
     const int r0 = (w >> 1) * 32, c0 = (w & 1) * 32;
     double *tile = A + (size_t)i0 * n + j0;
 #pragma unroll
@@ -517,10 +556,9 @@ struct TwGeom {
 // [c_lo, c_hi) (outside: structural zero / identity padding, never dereferenced).
 struct TileRef {
     double *p;
-    long sr;
-    int sc;
+    int ld, sgn;   // element (row, col) sits sgn * (row * ld + col) doubles from p (32-bit offsets: the host checks 64 nblk n < 2^31)
     int r_lo, r_hi, c_lo, c_hi;
-    __device__ __forceinline__ double *at(int row, int col) const { return p + (long)row * sr + (long)col * sc; }
+    __device__ __forceinline__ double *at(int row, int col) const { return p + (long)(sgn * (row * ld + col)); }
     __device__ __forceinline__ bool rv(int row) const { return row >= r_lo && row < r_hi; }
     __device__ __forceinline__ bool cv(int col) const { return col >= c_lo && col < c_hi; }
 };
@@ -530,8 +568,8 @@ __device__ __forceinline__ TileRef tile_ref(double *A, const TwGeom &g, int side
     const long ld = g.n;
     if (side == 0) {
         t.p = A + (long)rb * NB * ld + (long)cb * NB;
-        t.sr = ld;
-        t.sc = 1;
+        t.ld = g.n;
+        t.sgn = 1;
         t.r_lo = 0;
         t.c_lo = 0;
         t.r_hi = max(0, min(NB, g.n - rb * NB));
@@ -539,8 +577,8 @@ __device__ __forceinline__ TileRef tile_ref(double *A, const TwGeom &g, int side
     } else {
         const long N1 = (long)NB * g.nblk - 1;
         t.p = A + (N1 - (long)rb * NB) * ld + (N1 - (long)cb * NB);
-        t.sr = -ld;
-        t.sc = -1;
+        t.ld = g.n;
+        t.sgn = -1;
         t.r_lo = max(0, g.pad - rb * NB);
         t.c_lo = max(0, g.pad - cb * NB);
         t.r_hi = NB;
@@ -578,13 +616,13 @@ __device__ __forceinline__ void load_tile_shared(double (*T)[LDT], const TileRef
     double v[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-        const int e = threadIdx.x + 256 * q;
+        const int e = thread_id() + 256 * q;
         const int r = e / NB, c = e % NB;
         v[q] = (t.rv(r) && t.cv(c)) ? ld_shared<MODE>(t.at(r, c)) : 0.0;
     }
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-        const int e = threadIdx.x + 256 * q;
+        const int e = thread_id() + 256 * q;
         T[e / NB][e % NB] = v[q];
     }
 }
@@ -633,7 +671,7 @@ __device__ __forceinline__ void zero_acc(double4_t (&acc)[2][2]) {
 // element (row, col) of accumulator register acc[a][b][i] (tile_gemm_nt layout)
 #define MM_ACC_FOREACH(body)                                                                      \
     {                                                                                             \
-        const int lane_ = threadIdx.x & 63, w_ = threadIdx.x >> 6;                                \
+        const int lane_ = lane_id(), w_ = wave_id();                                       \
         const int r0_ = (w_ >> 1) * 32, c0_ = (w_ & 1) * 32;                                       \
         _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int b = 0; b < 2; ++b) \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                       \
@@ -645,7 +683,7 @@ __device__ __forceinline__ void zero_acc(double4_t (&acc)[2][2]) {
 // out[row] (+)= sign * sum_k Tm[row][k] v[k] for a 64 x 64 tile in LDS (leading dimension LD); 256 threads, 4 per row
 template <int LD>
 __device__ __forceinline__ double tile_matvec(const double (*Tm)[LD], const double *v) {
-    const int r = threadIdx.x >> 2, part = threadIdx.x & 3;
+    const int tid_ = thread_id(), r = tid_ >> 2, part = tid_ & 3;
     double s = 0.0;
 #pragma unroll
     for (int q = 0; q < 16; ++q) s += Tm[r][part * 16 + q] * v[part * 16 + q];
@@ -654,24 +692,30 @@ __device__ __forceinline__ double tile_matvec(const double (*Tm)[LD], const doub
     return s;  // valid in the threads with (threadIdx.x & 3) == 0, row threadIdx.x >> 2
 }
 
-// finish an off-diagonal block: solve P L_cc^T = A0 - acc, written to `tile` (global) and left in As.  The producer
-// publishes L_cc in two stages: (A) while it still factors its last panel, the 16 x 16 blocks below the diagonal blocks
-// and the inverses X_00, X_11; (B) X_22, X_33.  The solve runs by 16-column blocks,
-//   P_j = (V_j - sum_{k<j} P_k L_jk^T) X_jj^T,   wave w on rows 16w..16w+15 (40 MFMA per wave, wave-local LDS traffic),
-// and everything that does not need X_22 / X_33 happens after (A): only 12 MFMA and a 4 KB load follow (B).
+// finish an off-diagonal block: solve P L_cc^T = V (V = A0 - acc, staged in As), written to `tile` (global) and left
+// in As.  The producer streams L_cc out while it factors it (factor_block_lds): after column panel k the 16 x 16 blocks
+// L_jk (j > k) below diagonal block k, and X_kk = L_kk^-1 once an idle wave has inverted it.  The solve runs by
+// 16-column blocks behind the producer,
+//   stage k:  P_k = W_k X_kk^T,   W_j -= P_k L_jk^T  (j > k),
+// wave w on rows 16w..16w+15 with wave-local LDS traffic and no workgroup barrier: each wave waits for the two stage
+// counters itself and fetches the pieces it needs (all four waves store identical values into Bs / Xd).  When the last
+// stage arrives, four MFMAs and a 2 KB load are all that is left; the owner of the diagonal block (r, r) also adds
+// P_k P_k^T to its accumulator stage by stage, so the rank-64 update is off the chain as well.
 template <int MODE>
-__device__ __forceinline__ void load_xdiag(double (*Xd)[16][17], const double *Linv_c, int blk0) {
-    double v[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int e = threadIdx.x + 256 * q, blk = blk0 + (e >> 8), rr = (e >> 4) & 15, cc = e & 15;
-        v[q] = ld_shared<MODE>(Linv_c + (size_t)(16 * blk + rr) * NB + 16 * blk + cc);
+__device__ __forceinline__ bool wave_wait_ge(const int32_t *flag, int want, int32_t *abort_flag) {
+    for (long it = 0; it < SPIN_LIMIT; ++it) {
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) {
+            if (MODE == 1)
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            else
+                asm volatile("" ::: "memory");
+            return true;
+        }
+        if ((it & 255) == 255 && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+        __builtin_amdgcn_s_sleep(1);
     }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int e = threadIdx.x + 256 * q;
-        Xd[blk0 + (e >> 8)][(e >> 4) & 15][e & 15] = v[q];
-    }
+    __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return false;
 }
 
 // s = sum_{k in [K0, K1)} P_k L_jk^T for this wave's 16 rows, subtracted from block j of As
@@ -714,35 +758,147 @@ __device__ __forceinline__ void trsm_finish(double (*As)[LDT], const double (*Xd
     wave_lds_sync();
 }
 
-template <int MODE>
-__device__ __forceinline__ void finish_off_block_a(double (*As)[LDT], double (*Bs)[LDT], double (*Xd)[16][17],
-                                                   const double4_t (&a0)[2][2], const double4_t (&acc)[2][2],
-                                                   const TileRef &Lcc /*diagonal tile of the column*/,
-                                                   const double *Linv_c, const TileRef &t) {
-    MM_ACC_FOREACH(As[row][col] = a0[a][b][i] - acc[a][b][i];)
-    load_tile_shared<MODE>(Bs, Lcc);
-    load_xdiag<MODE>(Xd, Linv_c, 0);
-    __syncthreads();
-    const int lane = threadIdx.x & 63, row0 = 16 * (threadIdx.x >> 6);
+#ifdef MM_CHOL_TRACE
+__device__ unsigned long long g_chol_trace[128][12];
+#define MM_TRACE(r, e) do { if (side == 0 && threadIdx.x == 0 && (r) < 128) g_chol_trace[r][e] = wall_clock64(); } while (0)
+#define MM_TRACE_ROW(r, e) do { if (threadIdx.x == 0 && (r) >= 0 && (r) < 128) g_chol_trace[r][e] = wall_clock64(); } while (0)
+#else
+#define MM_TRACE(r, e) do { } while (0)
+#define MM_TRACE_ROW(r, e) do { } while (0)
+#endif
+
+// one stage of the streamed solve (this wave's 16 rows); false: the wait was abandoned.
+// No flag: the producer's pieces land in buffers that start out as a NaN sentinel (chol_init_kernel) -- X_kk in its place
+// inside L_cc^-1, the blocks L_jk in the hand-over buffer `lpub` -- and every lane polls the very values it needs, so a
+// hand-over costs one trip to memory instead of store-acknowledge + flag + load (the backward kernel's trick).
+constexpr unsigned long long STAGE_SENTINEL = ~0ull;
+constexpr int LPUB_BLOCK = 6 * 256;      // doubles per diagonal block: (1,0) (2,0) (3,0) | (2,1) (3,1) | (3,2), 16 x 16 row-major
+__device__ __forceinline__ constexpr int lpub_first(int k) { return k == 0 ? 0 : (k == 1 ? 3 : 5); }
+
+template <int MODE, int K>
+__device__ __forceinline__ bool trsm_stage(double (*As)[LDT], double (*Bs)[LDT], double (*Xd)[16][17], const double *lpub_c,
+                                           const double *Linv_c, int32_t *abort_flag, const TileRef &t, int trace_row) {
+    const int lane = lane_id(), row0 = 16 * wave_id();
     const int lr = lane & 15, lk = lane >> 4;
-    trsm_finish<MODE, 0>(As, Xd, t, row0, lr, lk);
-    trsm_update<1, 0, 1>(As, Bs, row0, lr, lk);
-    trsm_finish<MODE, 1>(As, Xd, t, row0, lr, lk);
-    trsm_update<2, 0, 2>(As, Bs, row0, lr, lk);
-    trsm_update<3, 0, 2>(As, Bs, row0, lr, lk);
+    constexpr int NL = K < 3 ? 4 * (3 - K) : 0;
+    double lv[NL > 0 ? NL : 1], xv[4];
+    bool ok = false;
+    for (long it = 0; it < SPIN_LIMIT; ++it) {
+        bool missing = false;
+#pragma unroll
+        for (int q = 0; q < NL; ++q) {
+            lv[q] = __hip_atomic_load(lpub_c + 256 * lpub_first(K) + lane + 64 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            missing |= (unsigned long long)__double_as_longlong(lv[q]) == STAGE_SENTINEL;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = lane + 64 * q;
+            xv[q] = __hip_atomic_load(Linv_c + (size_t)(16 * K + (e >> 4)) * NB + 16 * K + (e & 15), __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_AGENT);
+            missing |= (unsigned long long)__double_as_longlong(xv[q]) == STAGE_SENTINEL;
+        }
+        if (!__builtin_amdgcn_ballot_w64(missing)) {
+            ok = true;
+            break;
+        }
+        if ((it & 63) == 63 && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    if (!ok) __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (K == 3) MM_TRACE_ROW(trace_row, 2);
+#pragma unroll
+    for (int q = 0; q < NL; ++q) {
+        const int e = lane + 64 * q;
+        Bs[16 * (K + 1) + (e >> 4)][16 * K + (e & 15)] = lv[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = lane + 64 * q;
+        Xd[K][e >> 4][e & 15] = xv[q];
+    }
+    wave_lds_sync();
+    trsm_finish<MODE, K>(As, Xd, t, row0, lr, lk);
+    if (K == 3) MM_TRACE_ROW(trace_row, 3);
+    if constexpr (K < 1) trsm_update<1, K, K + 1>(As, Bs, row0, lr, lk);
+    if constexpr (K < 2) trsm_update<2, K, K + 1>(As, Bs, row0, lr, lk);
+    if constexpr (K < 3) trsm_update<3, K, K + 1>(As, Bs, row0, lr, lk);
+    return ok;
 }
 
-template <int MODE>
-__device__ __forceinline__ void finish_off_block_b(double (*As)[LDT], double (*Bs)[LDT], double (*Xd)[16][17],
-                                                   const double *Linv_c, const TileRef &t) {
-    load_xdiag<MODE>(Xd, Linv_c, 2);
-    __syncthreads();
-    const int lane = threadIdx.x & 63, row0 = 16 * (threadIdx.x >> 6);
+// acc += P_K P_K^T (columns 16K .. 16K+15 of As, all 64 rows: call after a workgroup barrier), tile_gemm_nt layout
+template <int K>
+__device__ __forceinline__ void syrk_slice(const double (*As)[LDT], double4_t (&acc)[2][2]) {
+    const int lane = lane_id(), w = wave_id();
+    const int r0 = (w >> 1) * 32, c0 = (w & 1) * 32;
     const int lr = lane & 15, lk = lane >> 4;
-    trsm_finish<MODE, 2>(As, Xd, t, row0, lr, lk);
-    trsm_update<3, 2, 3>(As, Bs, row0, lr, lk);
-    trsm_finish<MODE, 3>(As, Xd, t, row0, lr, lk);
+#pragma unroll
+    for (int ks = 4 * K; ks < 4 * K + 4; ++ks) {
+        const int k = ks * 4 + lk;
+        double a0 = As[r0 + lr][k], a1 = As[r0 + 16 + lr][k];
+        double b0 = As[c0 + lr][k], b1 = As[c0 + 16 + lr][k];
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
 }
+
+// The whole streamed solve of one off-diagonal block; V must be staged in As behind a workgroup barrier.  SYRK: also
+// acc += P P^T (the owner of the diagonal block of the same row).  Returns false (uniformly) if a wait was abandoned.
+template <int MODE, bool SYRK>
+__device__ __forceinline__ bool finish_off_block_streamed(double (*As)[LDT], double (*Bs)[LDT], double (*Xd)[16][17],
+                                                          const double *lpub_c, const double *Linv_c, int32_t *abort_flag,
+                                                          const TileRef &t, double4_t (&acc)[2][2], int trace_row = -1) {
+    bool ok = trsm_stage<MODE, 0>(As, Bs, Xd, lpub_c, Linv_c, abort_flag, t, trace_row);
+    if constexpr (SYRK) {
+        __syncthreads();
+        syrk_slice<0>(As, acc);
+    }
+    ok = trsm_stage<MODE, 1>(As, Bs, Xd, lpub_c, Linv_c, abort_flag, t, trace_row) && ok;
+    if constexpr (SYRK) {
+        __syncthreads();
+        syrk_slice<1>(As, acc);
+    }
+    ok = trsm_stage<MODE, 2>(As, Bs, Xd, lpub_c, Linv_c, abort_flag, t, trace_row) && ok;
+    if constexpr (SYRK) {
+        __syncthreads();
+        syrk_slice<2>(As, acc);
+    }
+    ok = trsm_stage<MODE, 3>(As, Bs, Xd, lpub_c, Linv_c, abort_flag, t, trace_row) && ok;
+    const bool all_ok = !__syncthreads_or(!ok);
+    if constexpr (SYRK) syrk_slice<3>(As, acc);
+    return all_ok;
+}
+
+// producer side of the streamed hand-over (factor_block_lds calls l(k) on wave 2, x(k) on the wave that inverted
+// diagonal block k): write-through stores and nothing else -- the consumers poll the values
+template <int MODE>
+struct StagePub {
+    const double (*M)[NB + 1];
+    const double (*X)[NB + 1];
+    TileRef dt;
+    double *Lr, *lpub;
+    __device__ __forceinline__ void l(int k) const {   // blocks (j, k), j > k: 16 (3 - k) rows x 16 columns
+        const int lane = lane_id();
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            const int e = lane + 64 * q, rr = 16 * (k + 1) + (e >> 4), cc = 16 * k + (e & 15);
+            if (q < 4 * (3 - k)) {
+                const double v = M[rr][cc];
+                __hip_atomic_store(lpub + 256 * lpub_first(k) + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (dt.rv(rr) && dt.cv(cc)) st_shared<MODE>(dt.at(rr, cc), v);      // (the copy the later kernels read)
+            }
+        }
+    }
+    __device__ __forceinline__ void x(int k) const {
+        const int lane = lane_id();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = lane + 64 * q, rr = 16 * k + (e >> 4), cc = 16 * k + (e & 15);
+            __hip_atomic_store(Lr + rr * NB + cc, X[rr][cc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+};
 
 #define MM_FUSED_ABANDON                       \
     {                                          \
@@ -750,26 +906,21 @@ __device__ __forceinline__ void finish_off_block_b(double (*As)[LDT], double (*B
         return;                                \
     }
 
-// flags (int32): [0] abort, then per side: flag[nblk][W] block (r, d) published | yflag[nblk] | cflag[nblk][W] forward
-// contribution of block (r, d) written | aflag[nblk] stage (A) of diagonal block r
+// flags (int32): [0] abort, then per side: flag[nblk][W] block (r, d) published (d >= 1; the diagonal blocks are handed
+// over piecewise through polled data, see trsm_stage) | yflag[nblk] | cflag[nblk][W] forward contribution of block (r, d)
+// written | [nblk] unused
 __device__ __forceinline__ size_t tw_side_flags(int nblk, int W) { return 2 * (size_t)nblk * W + 2 * (size_t)nblk; }
 
 // Forward substitution L y = b rides along (b_fwd != nullptr): the owner of block (r, c) multiplies it with y_c as
 // soon as that exists and hands the 64-vector to the owner of the diagonal block r, which adds the contributions in
 // a fixed order (deterministic), applies L_rr^-1 and publishes y_r.  The y chain trails the factorisation by a hop or
 // two, so the forward solve costs no extra time.  (Two-ended: the rows of M receive contributions from both sides.)
-#ifdef MM_CHOL_TRACE
-__device__ unsigned long long g_chol_trace[128][12];
-#define MM_TRACE(r, e) do { if (side == 0 && threadIdx.x == 0 && (r) < 128) g_chol_trace[r][e] = wall_clock64(); } while (0)
-#else
-#define MM_TRACE(r, e) do { } while (0)
-#endif
 
 template <int MODE>
 __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, TwGeom g, double *Linv,
                                                               int32_t *__restrict__ flags, int32_t *__restrict__ info,
                                                               const double *b_fwd, double *y,
-                                                              double *contrib, const int32_t *slab_ready,
+                                                              double *contrib, double *lpub, const int32_t *slab_ready,
                                                               int cams_per_slab, int n_cams) {
     // these waves form a latency chain; when the reduced system is being built by a concurrent launch they share their
     // SIMDs with its waves, so ask the instruction arbiter to prefer them
@@ -796,11 +947,11 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, TwGeom 
     auto flag = [&](int32_t *base, int r, int d) { return base + (size_t)r * W + d; };
     auto yflag = [&](int32_t *base, int r) { return base + (size_t)nblk * W + r; };
     auto cflag = [&](int32_t *base, int r, int d) { return base + (size_t)nblk * W + nblk + (size_t)r * W + d; };
-    auto aflag = [&](int32_t *base, int r) { return base + 2 * (size_t)nblk * W + nblk + r; };
     auto pflag = [&](int i, int jj) { return flags + 1 + 2 * tw_side_flags(nblk, W) + (size_t)i * g.m + jj; };
     auto nat = [&](int s, int blk) { return s == 0 ? blk : nblk - 1 - blk; };  // block index in natural order
     auto cslot = [&](int s, int r, int d) { return contrib + (((size_t)s * nblk + r) * W + d) * NB; };
     auto linv = [&](int s, int blk) { return Linv + (size_t)nat(s, blk) * NB * NB; };
+    auto lpubp = [&](int s, int blk) { return lpub + (size_t)nat(s, blk) * LPUB_BLOCK; };
     // Entries of A (and of the right-hand side) may still be under construction by a concurrent launch on another
     // stream (the reduced camera system, built in camera slabs).  The entries (i, j) and (j, i), i >= j, are written
     // together with camera row i / 6: a tile is complete when the slabs of its LARGER natural block index are
@@ -888,11 +1039,10 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, TwGeom 
             } else if (!rows_ready(side == 0 ? r : nat(1, c))) {
                 MM_FUSED_ABANDON;
             }
-            MM_ACC_FOREACH(a0[a][b][i] = (t.rv(row) && t.cv(col)) ? ld_shared<MODE>(t.at(row, col)) : 0.0;)
-            if (!wg_wait<MODE>(aflag(fb, c), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
-            finish_off_block_a<MODE>(As, Bs, T, a0, acc, tile_ref(A, g, side, c, c), linv(side, c), t);
-            if (!wg_wait<MODE>(flag(fb, c, 0), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
-            finish_off_block_b<MODE>(As, Bs, T, linv(side, c), t);
+            __syncthreads();   // the last tile product has read As / Bs
+            MM_ACC_FOREACH(As[row][col] = ((t.rv(row) && t.cv(col)) ? ld_shared<MODE>(t.at(row, col)) : 0.0) - acc[a][b][i];)
+            __syncthreads();
+            if (!finish_off_block_streamed<MODE, false>(As, Bs, T, lpubp(side, c), linv(side, c), abort_flag, t, acc)) MM_FUSED_ABANDON;
             wg_publish<MODE>(flag(fb, r, d));
             if (b_fwd) {  // L_rc y_c for the forward substitution (the block is still in As)
                 if (!wg_wait<MODE>(yflag(fb, c), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
@@ -924,37 +1074,59 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, TwGeom 
         // rows of M (two-ended, side 0): the diagonal block -- and the block left of it when that is in M too -- come
         // pre-accumulated over the columns of T and of the other end; only the columns of M are left to add
         const bool diag_pre = tw && side == 0 && r >= g.a, sub_pre = diag_pre && r - 1 >= g.a;
+        // The block's own entries (a0: diagonal tile, a1: the tile left of it) are fetched right before the LAST column's
+        // waits -- late enough for a matrix that is still being produced by a concurrent launch, early enough that their
+        // latency hides behind those waits.  What follows the last column sits on the critical chain
+        //   L_{r-1,r-2} -> this row's product with it -> streamed solve behind the factorisation of L_{r-1,r-1},
+        // so the products are ordered by what they wait for: the row's own block first (its square goes to the diagonal
+        // accumulator), the block of the row above last.
+        bool fetched = false, fetch_ok = true;
+        auto fetch_own = [&]() {
+            fetched = true;
+            if (diag_pre && !wg_wait<MODE>(pflag(r - g.a, r - g.a), sub_pre ? pflag(r - g.a, r - 1 - g.a) : nullptr, abort_flag, &s_ok)) fetch_ok = false;
+            if (fetch_ok && diag_here && !rows_ready(nat(side, r))) fetch_ok = false;
+            if (fetch_ok && side == 1 && has_sub && !rows_ready(nat(1, r - 1))) fetch_ok = false;
+            if (!fetch_ok) return;
+            if (diag_here)
+                MM_ACC_FOREACH(a0[a][b][i] = (dt.rv(row) && dt.cv(col) && col <= row) ? ld_shared<MODE>(dt.at(row, col)) : 0.0;)
+            if (has_sub) MM_ACC_FOREACH(a1[a][b][i] = (st.rv(row) && st.cv(col)) ? ld_shared<MODE>(st.at(row, col)) : 0.0;)
+        };
         for (int k = max(0, r - bwb); k + 1 < r; ++k) {
             const bool do_diag = diag_here && !(diag_pre && k < g.a), do_sub = !(sub_pre && k < g.a);
+            if (k + 2 == r) {
+                fetch_own();
+                if (!fetch_ok) MM_FUSED_ABANDON;
+            }
             if (!do_diag && !do_sub) continue;
-            if (!wg_wait<MODE>(flag(fb, r, r - k), do_sub ? flag(fb, r - 1, r - 1 - k) : nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
+            if (!wg_wait<MODE>(flag(fb, r, r - k), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
             load_tile_shared<MODE>(As, tile_ref(A, g, side, r, k));
-            if (do_sub) load_tile_shared<MODE>(Bs, tile_ref(A, g, side, r - 1, k));
             __syncthreads();
-            if (do_sub) tile_gemm_nt(As, Bs, acc1);
             if (do_diag) tile_gemm_nt(As, As, acc);
+            if (do_sub) {
+                if (!wg_wait<MODE>(flag(fb, r - 1, r - 1 - k), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
+                load_tile_shared<MODE>(Bs, tile_ref(A, g, side, r - 1, k));
+                __syncthreads();
+                tile_gemm_nt(As, Bs, acc1);
+            }
         }
-        // (see the off-diagonal owner: fetched late, hidden behind the next wait)
-        if (diag_pre) {
-            if (!wg_wait<MODE>(pflag(r - g.a, r - g.a), sub_pre ? pflag(r - g.a, r - 1 - g.a) : nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
+        if (!fetched) {
+            fetch_own();
+            if (!fetch_ok) MM_FUSED_ABANDON;
         }
-        if (diag_here && !rows_ready(nat(side, r))) MM_FUSED_ABANDON;
-        if (side == 1 && has_sub && !rows_ready(nat(1, r - 1))) MM_FUSED_ABANDON;
-        if (diag_here)
-            MM_ACC_FOREACH(a0[a][b][i] = (dt.rv(row) && dt.cv(col) && col <= row) ? ld_shared<MODE>(dt.at(row, col)) : 0.0;)
-        if (has_sub) MM_ACC_FOREACH(a1[a][b][i] = (st.rv(row) && st.cv(col)) ? ld_shared<MODE>(st.at(row, col)) : 0.0;)
         if (has_sub) {
             MM_TRACE(r, 1);
-            if (!wg_wait<MODE>(aflag(fb, r - 1), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
-            MM_TRACE(r, 2);
-            finish_off_block_a<MODE>(As, Bs, T, a1, acc1, tile_ref(A, g, side, r - 1, r - 1), linv(side, r - 1), st);
-            MM_TRACE(r, 3);
-            if (!wg_wait<MODE>(flag(fb, r - 1, 0), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
+            __syncthreads();   // the last tile product has read As / Bs
+            MM_ACC_FOREACH(As[row][col] = a1[a][b][i] - acc1[a][b][i];)
+            __syncthreads();
+            // the solve streams behind the factorisation of L_{r-1,r-1}; acc += L_{r,r-1} L_{r,r-1}^T rides along
+            const bool ok = diag_here ? finish_off_block_streamed<MODE, true>(As, Bs, T, lpubp(side, r - 1), linv(side, r - 1), abort_flag,
+                                                                              st, acc, side == 0 ? r : -1)
+                                      : finish_off_block_streamed<MODE, false>(As, Bs, T, lpubp(side, r - 1), linv(side, r - 1),
+                                                                               abort_flag, st, acc);
+            if (!ok) MM_FUSED_ABANDON;
             MM_TRACE(r, 4);
-            finish_off_block_b<MODE>(As, Bs, T, linv(side, r - 1), st);
             wg_publish<MODE>(flag(fb, r, 1));  // (its barrier also orders the LDS copy of the block)
             MM_TRACE(r, 5);
-            if (diag_here) tile_gemm_nt(As, As, acc);
         }
         if (!diag_here) {  // side 1, block (b, b - 1): its row belongs to M, side 0 finishes it
             if (b_fwd) {
@@ -977,45 +1149,17 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, TwGeom 
         __syncthreads();
         int bad = 0;
         double *Lr = linv(side, r);
-        // stage (A), by wave 2 during the last panel: the six 16 x 16 blocks of L_rr below its diagonal blocks and the
-        // inverses X_00, X_11 -- what the blocks below need for all but the last 12 MFMA of their solve
-        auto stage_a = [&]() {
-            const int lane = threadIdx.x & 63;
-#pragma unroll
-            for (int q = 0; q < 6; ++q) {
-                constexpr int BI[6] = {1, 2, 2, 3, 3, 3}, BJ[6] = {0, 0, 1, 0, 1, 2};
-#pragma unroll
-                for (int h = 0; h < 4; ++h) {
-                    const int rr = 16 * BI[q] + 4 * h + (lane >> 4), cc = 16 * BJ[q] + (lane & 15);
-                    if (dt.rv(rr) && dt.cv(cc)) st_shared<MODE>(dt.at(rr, cc), M[rr][cc]);
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int e = lane + 64 * q, blk = e >> 8, rr = 16 * blk + ((e >> 4) & 15), cc = 16 * blk + (e & 15);
-                st_shared<MODE>(Lr + rr * NB + cc, X[rr][cc]);
-            }
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-            if (lane == 0) __hip_atomic_store(aflag(fb, r), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        };
         MM_TRACE(r, 6);
-        factor_block_lds(M, X, R, 0, bad, stage_a);
+        // the block streams out while it is factored: column panel k's sub-diagonal blocks, then X_kk (see trsm_stage)
+        factor_block_lds(M, X, R, 0, bad, StagePub<MODE>{M, X, dt, Lr, lpubp(side, r)});
         MM_TRACE(r, 7);
         if (bad && threadIdx.x == 64) {  // `bad` = 1-based position inside the block; report the natural column
             const long col = vec_index(g, side, r, bad - 1);
             report_bad(info, (int)(col >= 0 && col < n ? col + 1 : n));
         }
-        // stage (B): the inverses X_22, X_33
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int e = 512 + threadIdx.x + 256 * q, blk = e >> 8, rr = 16 * blk + ((e >> 4) & 15), cc = 16 * blk + (e & 15);
-            st_shared<MODE>(Lr + rr * NB + cc, X[rr][cc]);
-        }
-        wg_publish<MODE>(flag(fb, r, 0));
         MM_TRACE(r, 8);
         for (int q = 0; q < 4; ++q) {  // diagonal 16 x 16 blocks of L_rr: only the later kernels read them
-            const int e = threadIdx.x + 256 * q, blk = e >> 8, rr = 16 * blk + ((e >> 4) & 15), cc = 16 * blk + (e & 15);
+            const int e = thread_id() + 256 * q, blk = e >> 8, rr = 16 * blk + ((e >> 4) & 15), cc = 16 * blk + (e & 15);
             if (dt.rv(rr) && dt.cv(cc) && cc <= rr) *dt.at(rr, cc) = M[rr][cc];
         }
         // the rest of L_rr^-1 (for the substitution kernels) is nobody's critical path
@@ -1257,13 +1401,22 @@ __global__ __launch_bounds__(256) void chol_band_bwd_kernel(double *A, TwGeom g,
     if (dead) MM_FUSED_ABANDON;
 }
 
-// one launch instead of three fills per solve: info = 0, flags = 0, the backward kernel's contribution buffer = sentinel
+// one launch instead of a handful of fills per solve: info = 0, flags = 0, sentinels into the backward kernel's
+// contribution buffer, the hand-over buffer of the streamed blocks and the diagonal 16 x 16 blocks of L^-1 (what the
+// consumers of the factorisation poll on)
 __global__ __launch_bounds__(256) void chol_init_kernel(int32_t *__restrict__ info, int32_t *__restrict__ flags, size_t nflags,
-                                                        unsigned long long *__restrict__ sentinel_buf, size_t nsent) {
+                                                        unsigned long long *__restrict__ sentinel_buf, size_t nsent,
+                                                        unsigned long long *__restrict__ lpub, size_t nlpub,
+                                                        unsigned long long *__restrict__ Linv, size_t nblk) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
     if (i == 0) info[0] = 0;
     for (size_t k = i; k < nflags; k += stride) flags[k] = 0;
     for (size_t k = i; k < nsent; k += stride) sentinel_buf[k] = BWD_SENTINEL;
+    for (size_t k = i; k < nlpub; k += stride) lpub[k] = STAGE_SENTINEL;
+    for (size_t k = i; k < nblk * 1024; k += stride) {
+        const size_t b = k >> 10, d = (k >> 8) & 3, e = k & 255;
+        Linv[b * NB * NB + (16 * d + (e >> 4)) * NB + 16 * d + (e & 15)] = STAGE_SENTINEL;
+    }
 }
 
 // copy the band of the lower triangle into the upper triangle for the columns side 1 eliminates: (j, i) <- (i, j) for
@@ -1358,7 +1511,8 @@ size_t mm_chol_workspace_bytes(int n) {
     size_t nblk = (size_t)(n + NB - 1) / NB;
     return mm_align_up(nblk * NB * NB * sizeof(double), 256) + mm_align_up((size_t)(n + NB) * sizeof(double), 256) +
            mm_align_up((2 * (2 * nblk * (FUSED_MAX_BWB + 1) + 2 * nblk) + 64 + FUSED_MAX_BWB * FUSED_MAX_BWB) * sizeof(int32_t), 256) +
-           2 * mm_align_up(2 * nblk * (FUSED_MAX_BWB + 1) * NB * sizeof(double), 256);   // forward + backward contributions
+           2 * mm_align_up(2 * nblk * (FUSED_MAX_BWB + 1) * NB * sizeof(double), 256) +  // forward + backward contributions
+           mm_align_up(nblk * LPUB_BLOCK * sizeof(double), 256);                          // hand-over buffer of the streamed blocks
 }
 
 int mm_chol_solve(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int half_bandwidth, int32_t *info, void *ws,
@@ -1372,6 +1526,35 @@ int mm_chol_solve_sym(mm_ctx *ctx, double *A, int n, double *b, int half_bandwid
 }
 
 }  // extern "C"
+
+// Co-residency budget of the single-launch factorisation: its workgroups spin on each other's results, so every one of
+// them must hold a compute unit (512 registers per lane: one workgroup per CU) for the grid to make progress.  One grid is
+// far below the CU count, but several contexts may solve at once (the sliding-window schedule runs 8 streams): each
+// launch reserves its grid here, a launch that would push the sum past the device's CUs takes the launch-per-column path
+// instead, and a context returns its share at its next host synchronisation.  (Conservative: a reservation outlives its
+// kernel until the owner synchronises.  Per process and device 0..15; other processes on the GPU are not seen -- their
+// case is covered by the bounded spins + mm_ba_trf's retry on the per-column path.)
+static std::atomic<int> g_fused_reserved[16];
+
+void mm_chol_release_budget(mm_ctx *ctx) {
+    if (ctx && ctx->fused_wgs > 0) {
+        g_fused_reserved[ctx->device & 15].fetch_sub(ctx->fused_wgs);
+        ctx->fused_wgs = 0;
+    }
+}
+
+static bool chol_reserve_budget(mm_ctx *ctx, int grid) {
+    std::atomic<int> &total = g_fused_reserved[ctx->device & 15];
+    const int delta = grid - ctx->fused_wgs;      // this context's earlier launch is stream-ordered before the new one
+    const int after = total.fetch_add(delta) + delta;
+    ctx->fused_wgs = grid;
+    if (ctx->cu_count > 0 && after > ctx->cu_count) {
+        total.fetch_sub(grid);
+        ctx->fused_wgs = 0;
+        return false;
+    }
+    return true;
+}
 
 static int chol_fused_mode() {
     static const int mode = [] {
@@ -1418,17 +1601,28 @@ int mm_chol_solve_gated(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int 
     const int fused_mode = chol_fused_mode();
     if (slab_ready && !mm_chol_fused_eligible(n, half_bandwidth))
         return mm_fail(ctx, MM_ERR_ARG, "mm_chol_solve_gated: gating needs the single-launch factorisation");
-    const bool fused = fused_mode > 0 && nblk >= 2 && bwb >= 1 && bwb <= FUSED_MAX_BWB;
+    bool fused = fused_mode > 0 && nblk >= 2 && bwb >= 1 && bwb <= FUSED_MAX_BWB && (long)NB * nblk * n < (1L << 31);
+    if (fused && ctx->chol_avoid_fused && !slab_ready) fused = false;      // (after an abandoned attempt: mm_ba_trf)
     TwGeom g = {n, nblk, bwb, nblk, 0, 0, nblk * NB - n};
     if (fused && sym_mode > 0 && nrhs == 1 && chol_twisted_enabled() && nblk - bwb >= 4) {
         g.m = bwb;                       // the separator: no coupling across 64 m + 1 > half_bandwidth
         g.a = (nblk - g.m + 1) / 2;
         g.b = nblk - g.m - g.a;
     }
+    const int G_side = (bwb + 1) + bwb * (bwb - 1) / 2;
+    // two-ended: a third group of workgroups, one per block of M x M (fewer than G: m = bwb), pre-accumulates
+    const int fused_grid = g.b > 0 ? 2 * G_side + g.m * (g.m + 1) / 2 : G_side;
+    if (fused && !chol_reserve_budget(ctx, fused_grid)) {
+        if (slab_ready) return mm_fail(ctx, MM_ERR_HIP, "mm_chol_solve_gated: no room for the single-launch factorisation");
+        fused = false;
+        g = TwGeom{n, nblk, bwb, nblk, 0, 0, nblk * NB - n};
+    }
+    ctx->chol_last_path = fused ? 1 : 0;
     int32_t *flags = (int32_t *)((char *)ytmp + mm_align_up((size_t)(n + NB) * sizeof(double), 256));
     double *contrib = (double *)((char *)flags + mm_align_up((2 * (2 * (size_t)nblk * (FUSED_MAX_BWB + 1) + 2 * nblk) + 64 + FUSED_MAX_BWB * FUSED_MAX_BWB) * sizeof(int32_t), 256));
     const int sides = g.b > 0 ? 2 : 1;
     double *contrib_bwd = (double *)((char *)contrib + mm_align_up(2 * (size_t)nblk * (FUSED_MAX_BWB + 1) * NB * sizeof(double), 256));
+    double *lpub = (double *)((char *)contrib_bwd + mm_align_up(2 * (size_t)nblk * (FUSED_MAX_BWB + 1) * NB * sizeof(double), 256));
     if (!fused) MM_HIP(ctx, hipMemsetAsync(info, 0, sizeof(int32_t), ctx->stream));
     if (fused) {
         if (!ctx->attr_chol_fused) {
@@ -1443,13 +1637,16 @@ int mm_chol_solve_gated(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int 
         }
         const size_t nflags = 1 + 2 * (2 * (size_t)nblk * (bwb + 1) + 2 * nblk) + (size_t)g.m * g.m;
         const double *b_fwd = nrhs >= 1 ? b : nullptr;  // the first right-hand side rides along
-        MM_LAUNCH(ctx, "chol_init_kernel", chol_init_kernel, dim3(32), dim3(256), 0, info, flags, nflags,
-                  (unsigned long long *)contrib_bwd, (size_t)sides * nblk * (bwb + 1) * NB);
-        const int G = (bwb + 1) + bwb * (bwb - 1) / 2;
-        // two-ended: a third group of workgroups, one per block of M x M (fewer than G: m = bwb), pre-accumulates
-        const int grid = g.b > 0 ? 2 * G + g.m * (g.m + 1) / 2 : G;
-        MM_LAUNCH(ctx, "chol_band_fused_kernel", chol_band_fused_kernel<2>, dim3(grid), dim3(256), FUSED_LDS_BYTES, A, g, Linv,
-                  flags, info, b_fwd, ytmp, contrib, slab_ready, cams_per_slab, n_cams);
+        MM_LAUNCH(ctx, "chol_init_kernel", chol_init_kernel, dim3(64), dim3(256), 0, info, flags, nflags,
+                  (unsigned long long *)contrib_bwd, (size_t)sides * nblk * (bwb + 1) * NB, (unsigned long long *)lpub,
+                  (size_t)nblk * LPUB_BLOCK, (unsigned long long *)Linv, (size_t)nblk);
+        if (ctx->debug_abandon > 0) {      // test hook (mm_ctx_control): behave as if a workgroup had given up waiting
+            --ctx->debug_abandon;
+            const int32_t one = 1;
+            MM_HIP(ctx, hipMemcpyAsync(flags, &one, sizeof(one), hipMemcpyHostToDevice, ctx->stream));
+        }
+        MM_LAUNCH(ctx, "chol_band_fused_kernel", chol_band_fused_kernel<2>, dim3(fused_grid), dim3(256), FUSED_LDS_BYTES, A, g, Linv,
+                  flags, info, b_fwd, ytmp, contrib, lpub, slab_ready, cams_per_slab, n_cams);
         fwd_done = b_fwd != nullptr;
     } else {
         for (int k = 0; k < nblk; ++k) {

@@ -25,6 +25,13 @@ struct mm_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // one-time kernel attributes (dynamic LDS opt-in) are per device: remembered per context, not per process
     bool attr_chol_fused = false, attr_chol_bwd = false;
+    // Single-launch banded factorisation (chol.hip): its workgroups wait for each other, so ALL of them have to be
+    // resident -- one per CU (512 registers per lane).  cu_count = CUs of the device; fused_wgs = workgroups this context
+    // has reserved out of the process-wide budget (mm_fused_budget) for its factorisation in flight, released at the
+    // context's next host synchronisation; chol_avoid_fused: take the launch-per-column path (set by mm_ba_trf after an
+    // abandoned factorisation); chol_last_path: 1 single launch, 0 per column, -1 none yet; debug_abandon: test hook.
+    int cu_count = 0, fused_wgs = 0, chol_last_path = -1, debug_abandon = 0;
+    bool chol_avoid_fused = false;
     // rotation coefficients of the cameras the BA sweeps were last called with (ba.hip: mm_cam_coef_table)
     void *cam_tab = nullptr;
     int cam_tab_cap = 0, cam_tab_F = 0;
@@ -53,6 +60,8 @@ void mm_cam_table_invalidate(mm_ctx *ctx);          // ... the caller says the v
 int mm_ba_residual_publish(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, const double *pts, void *ws,
                            size_t ws_bytes, double *board, int cost_slot, int count, void *host_board, unsigned long long seq);
 
+// chol.hip: give back the workgroups a context has reserved for a single-launch factorisation (call after a host sync)
+void mm_chol_release_budget(mm_ctx *ctx);
 // chol.hip internals used by the overlapped Schur + solve entry point (schur.hip)
 bool mm_chol_fused_eligible(int n, int half_bandwidth);
 int mm_chol_solve_gated(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int half_bandwidth, int32_t *info, void *ws,

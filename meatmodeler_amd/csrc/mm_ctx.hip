@@ -17,12 +17,14 @@ int mm_ctx_create(int device, void *hip_stream, mm_ctx **out) {
         delete c;
         return MM_ERR_HIP;
     }
+    if (hipDeviceGetAttribute(&c->cu_count, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) c->cu_count = 0;
     *out = c;
     return MM_OK;
 }
 
 void mm_ctx_destroy(mm_ctx *ctx) {
     if (!ctx) return;
+    mm_chol_release_budget(ctx);
     for (auto &r : ctx->recs) {
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
@@ -87,7 +89,20 @@ const char *mm_last_error(mm_ctx *ctx) { return ctx ? ctx->err : "null context";
 int mm_ctx_sync(mm_ctx *ctx) {
     if (!ctx) return MM_ERR_ARG;
     MM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    mm_chol_release_budget(ctx);      // nothing of this context is in flight any more
     return MM_OK;
+}
+
+long long mm_ctx_control(mm_ctx *ctx, int what, long long value) {
+    if (!ctx) return MM_ERR_ARG;
+    switch (what) {
+        case MM_CTL_CHOL_FORCE_ABANDON: ctx->debug_abandon = value < 0 ? 0 : (int)value; return MM_OK;
+        case MM_CTL_CHOL_LAST_PATH: return ctx->chol_last_path;
+        case MM_CTL_CHOL_RESERVED: return ctx->fused_wgs;
+        case MM_CTL_CU_COUNT: return ctx->cu_count;
+        case MM_CTL_CHOL_AVOID_FUSED: ctx->chol_avoid_fused = value != 0; return MM_OK;
+        default: return mm_fail(ctx, MM_ERR_ARG, "mm_ctx_control: unknown request %d", what);
+    }
 }
 
 struct mm_timer {

@@ -154,6 +154,17 @@ extern "C" int mm_ba_trf(mm_ctx *ctx, const mm_ba_problem *pb, double *cams, dou
         explicit TableHold(mm_ctx *ctx) : c(ctx) { mm_cam_table_hold(c, true); }
         ~TableHold() { mm_cam_table_hold(c, false); }
     } table_hold(ctx);
+    // an abandoned single-launch factorisation (info = -1: its workgroups were not co-resident) switches this solve to
+    // the launch-per-column factorisation; the context's setting is restored on the way out, its budget share returned
+    struct FusedGuard {
+        mm_ctx *c;
+        bool saved;
+        explicit FusedGuard(mm_ctx *ctx) : c(ctx), saved(ctx->chol_avoid_fused) {}
+        ~FusedGuard() {
+            c->chol_avoid_fused = saved;
+            mm_chol_release_budget(c);
+        }
+    } fused_guard(ctx);
     const int F = pb->F, P = pb->P;
     const int64_t nc = 6 * (int64_t)F, n = nc + 3 * (int64_t)P;
     hipStream_t st = ctx->stream;
@@ -167,6 +178,7 @@ extern "C" int mm_ba_trf(mm_ctx *ctx, const mm_ba_problem *pb, double *cams, dou
     MM_HIP(ctx, hipMemcpyAsync(x, cams, (size_t)nc * sizeof(double), hipMemcpyDeviceToDevice, st));
     if (P) MM_HIP(ctx, hipMemcpyAsync(x + nc, pts, (size_t)3 * P * sizeof(double), hipMemcpyDeviceToDevice, st));
     double host[16];
+    rep->chol_fallbacks = 0;
     static const bool spin = !(getenv("MM_TRF_SPIN") && getenv("MM_TRF_SPIN")[0] == '0');
     if (spin && !ctx->host_board) {
         MM_HIP(ctx, hipHostMalloc(&ctx->host_board, sizeof(HostBoard), hipHostMallocDefault));
@@ -294,7 +306,15 @@ extern "C" int mm_ba_trf(mm_ctx *ctx, const mm_ba_problem *pb, double *cams, dou
                 solved = true;
                 break;
             }
-            if (inf < 0) return mm_fail(ctx, MM_ERR_HIP, "mm_ba_trf: the fused banded factorisation was abandoned (info = -1)");
+            if (inf < 0) {
+                // the single-launch factorisation gave up waiting (another tenant on the GPU, a profiler serialising
+                // kernels): repeat this attempt -- same damping -- with the launch-per-column factorisation and stay there
+                if (ctx->chol_avoid_fused) return mm_fail(ctx, MM_ERR_HIP, "mm_ba_trf: the banded factorisation reported info = -1");
+                ctx->chol_avoid_fused = true;
+                ++rep->chol_fallbacks;
+                --attempt;
+                continue;
+            }
             if (host[13] <= min_damping * (1.0 + 1e-12)) min_damping *= 100.0;   // failed AT the floor: the floor was too low
             // reg_eff *= 100 on the device: damp[1] is a plain double
             double r100 = host[13] * 100.0;

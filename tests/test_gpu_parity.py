@@ -48,7 +48,7 @@ def test_bf_knn2_single_pair_bit_exact(n, seed):
     np.testing.assert_array_equal(pairs[0, :len(po)].cpu().numpy(), po)
 
 
-@pytest.mark.parametrize("variant", ["114", "200", "300"])
+@pytest.mark.parametrize("variant", ["114", "200", "300", "310"])
 def test_bf_knn2_formulations_agree_with_oracle(variant, monkeypatch):
     """The three formulations of the Hamming search in csrc/bf_match.hip -- xor / popcount on the vector unit (114), the
     +1 / -1 GEMM on the int8 matrix instruction (200) and on the FP4 one (300, the default) -- against the C oracle on a
@@ -862,6 +862,80 @@ def test_library_trf_driver_equals_python_driver_bitwise(golden_dir, case, monke
     assert out["python"][1] == out["library"][1]
     if case == "tiny":
         assert a.status == 0 and a.nfev == 7
+
+
+@pytest.mark.parametrize("driver", ["library", "python"])
+def test_trf_survives_an_abandoned_factorisation(golden_dir, driver, monkeypatch):
+    """info = -1 (the single-launch banded factorisation gave up waiting: its workgroups were not co-resident) is not an
+    error any more: the attempt is repeated with the launch-per-column factorisation and the solve continues there.  The
+    abandonment is provoked through the context's test hook; the result equals the undisturbed run to rounding (the two
+    factorisations order their sums differently)."""
+    from meatmodeler_amd._lib import default_context
+    monkeypatch.setenv("MM_TRF_DRIVER", driver)
+    ctx = default_context()
+    d = np.load(os.path.join(golden_dir, "g5_adjust_points_d.npz"))       # 120 cameras: the band path
+    pr = synth.make_ba_problem(*(int(d[k]) for k in ("F", "P", "L")), seed=int(d["seed"]))
+    args = (pr["ext"], pr["K"], pr["pts0"], pr["obs"], pr["fi"], pr["pi"])
+    ref = bundleAdjuster.solvePoints(*args, verbose=0)
+    assert ctx.control(ctx.CTL_CHOL_LAST_PATH) == 1
+    try:
+        ctx.control(ctx.CTL_CHOL_FORCE_ABANDON, 1)
+        res = bundleAdjuster.solvePoints(*args, verbose=0)
+    finally:
+        ctx.control(ctx.CTL_CHOL_FORCE_ABANDON, 0)
+        ctx.control(ctx.CTL_CHOL_AVOID_FUSED, 0)
+    if driver == "library":
+        assert res.chol_fallbacks == 1
+    if driver == "python":
+        ctx.sync()                                          # (the Python-sequenced loop never calls mm_ctx_sync itself)
+    assert ctx.control(ctx.CTL_CHOL_RESERVED) == 0          # the budget share went back with the end of the solve
+    assert (res.nfev, res.status) == (ref.nfev, ref.status)
+    assert abs(res.cost - ref.cost) <= 1e-9 * ref.cost
+    np.testing.assert_allclose(res.x, ref.x, rtol=1e-6, atol=1e-8)
+    # and the next solve is back on the single-launch path
+    bundleAdjuster.solvePoints(*args, verbose=0)
+    assert ctx.control(ctx.CTL_CHOL_LAST_PATH) == 1
+
+
+def test_chol_single_launch_budget_over_contexts():
+    """The workgroups of the single-launch factorisation must all be resident (one per compute unit).  Contexts that
+    solve at the same time share a per-process budget of the device's compute units: a launch that does not fit takes
+    the launch-per-column path (same solution), and a context's share returns at its next synchronisation."""
+    from meatmodeler_amd._lib import Context
+    n, hb = 3000, 528                      # two-ended grid: 2 * 46 + 45 = 137 workgroups
+    rng = np.random.default_rng(8)
+    M = np.tril(np.triu(rng.normal(size=(n, n)), -hb // 2))
+    A = M @ M.T + n * np.eye(n)
+    b = rng.normal(size=n)
+    ref = np.linalg.solve(A, b)
+    streams = [torch.cuda.Stream(device=DEV) for _ in range(3)]
+    ctxs = [Context(DEV, s) for s in streams]
+    cus = ctxs[0].control(ctxs[0].CTL_CU_COUNT)
+    assert cus >= 64
+    fit = cus // 137                       # launches that fit side by side (1 on a 256-CU MI355X)
+    torch.cuda.synchronize()
+    sols, paths = [], []
+    for c, st in zip(ctxs, streams):
+        with torch.cuda.stream(st):
+            Ad, bd = dev(A), dev(b)
+            info = ops.chol_solve_sym(Ad, bd, c, half_bandwidth=hb, both_triangles=True)
+        sols.append((Ad, bd, info))
+        paths.append(c.control(c.CTL_CHOL_LAST_PATH))
+    assert paths == [1] * min(fit, 3) + [0] * max(0, 3 - fit)
+    assert sum(c.control(c.CTL_CHOL_RESERVED) for c in ctxs) == 137 * min(fit, 3)
+    for c in ctxs:
+        c.sync()
+        assert c.control(c.CTL_CHOL_RESERVED) == 0
+    for Ad, bd, info in sols:
+        assert int(info) == 0
+        np.testing.assert_allclose(bd.cpu().numpy(), ref, rtol=1e-9, atol=1e-12)
+    # with the budget free again the last context fits
+    with torch.cuda.stream(streams[2]):
+        Ad, bd = dev(A), dev(b)
+        ops.chol_solve_sym(Ad, bd, ctxs[2], half_bandwidth=hb, both_triangles=True)
+    assert ctxs[2].control(ctxs[2].CTL_CHOL_LAST_PATH) == 1
+    ctxs[2].sync()
+    np.testing.assert_allclose(bd.cpu().numpy(), ref, rtol=1e-9, atol=1e-12)
 
 
 def test_adjust_points_raises_on_non_finite():

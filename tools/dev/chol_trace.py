@@ -26,7 +26,10 @@ assert raw.mm_debug_chol_trace(buf) == 0
 t = np.array(buf[:], dtype=np.int64).reshape(128, 12)[:, :10] * 10e-3   # 100 MHz -> us
 rows = [r for r in range(128) if t[r, 9] > 0]
 t0 = t[rows, 0].min()
-names = ["start", "acc_done", "aflag", "fin_a", "flag0", "fin_b+pub", "syrk+M", "factor", "publish", "row_end"]
+# stamps: 0 row start, 1 tile products of the earlier columns done, 2 last inverse X_33 of the block above seen, 3 last
+# 16 columns of L_{r,r-1} solved, 4 streamed solve + rank-64 update done, 5 block (r, r-1) published, 6 diagonal block
+# staged, 7 factored (its last stage is out), 8 = 7, 9 row end (inverse blocks, forward substitution)
+names = ["start", "acc_done", "x33_seen", "fin3", "solved", "sub_pub", "staged", "factor", "post", "row_end"]
 print("row  " + " ".join(f"{x:>9s}" for x in names) + "   step(publish - prev publish)")
 prev = None
 for r in rows:
