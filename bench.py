@@ -32,6 +32,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s m
 VALU_PEAK_TLOPS = 78.6         # 256 CU x 4 SIMD-32 x 2.4 GHz (157.3 TF FP32 vector / 2)
 MFMA_F64_PEAK_TF = 78.6        # v_mfma_f64_16x16x4: 2048 flop / 64 clk / SIMD
 MFMA_FP4_PEAK_PF = 10.0        # MI355X_MICROARCH.md: FP4 / FP6 ~10 PF dense (block-scaled f8f6f4 MFMA)
+MFMA_FP4_MEASURED_PF = 6.43   # the same instruction on random +1 / -1 operands, every SIMD busy, >= 10 ms (profiles/r03_mfma_rate.txt)
 
 
 def parse():
@@ -71,7 +72,7 @@ def algorithmic_work(name, cfg):
     it = cfg.get("ba_iters", 0)   # Jacobian evaluations
     nfev = cfg.get("ba_nfev", 0)
     kp = cfg.get("kp_total_local", F * N)
-    if name == "bf_knn2_kernel":
+    if name.startswith("bf_knn2_"):
         pairs = cfg["pair_evals_local"]
         # 8 v_xor_b32 + 8 v_bcnt_u32_b32 = 16 lane-ops per descriptor pair is the unit of the roof
         return cfg["pairs_local"] * (32 * 2 * N + 16 * N), pairs * 16.0, 0
@@ -301,7 +302,7 @@ def main():
             roofline["traffic_note"] = ("NOT measured by this run: FETCH_SIZE + WRITE_SIZE per launch read from the committed "
                                         "file profiles/%s (separate rocprofv3 --pmc passes of this same command, "
                                         "tools/gpu_evidence.sh); FETCH not doubled: 8-byte gathers are uncalibrated" % pmc_file)
-    bf = next((k for k in kernels if k["kernel"] == "bf_knn2_kernel"), None)
+    bf = next((k for k in kernels if k["kernel"].startswith("bf_knn2_")), None)
     if bf is not None and "valu_Tlops" in bf:
         bf = dict(bf)
         # the roof SURVEY section 8(d) fixes for the xor / popcount formulation (16 lane-ops per pair at the nominal
@@ -314,9 +315,16 @@ def main():
         bf["mfma_fp4_PFLOPs"] = bf["T_pairs_per_s"] * 512.0 / 1e3
         bf["mfma_fp4_peak_PFLOPs"] = MFMA_FP4_PEAK_PF
         bf["frac_of_fp4_mfma_roof"] = bf["mfma_fp4_PFLOPs"] / MFMA_FP4_PEAK_PF
-        bf["note"] = ("matrix cores (FP4 operands) + 2 VALU instructions per pair; the xor / popcount kernel it replaces ran at "
-                      "2.0-2.1 T pairs/s = 91 % of the VALU issue roof of its instruction mix (profiles/r02_bf_pmc.txt); "
-                      "MM_BF_VARIANT=114 selects it, 200 the int8 MFMA form; all three return identical results")
+        # the 10 PF figure is the spec at 2.4 GHz on operands that do not toggle; on random +1 / -1 operands with every SIMD
+        # busy the same instruction sustains 6.4 PFLOP/s on this chip (1.8 GHz; tools/dev/mfma_rate.hip,
+        # profiles/r03_mfma_rate.txt), and the kernel itself runs at 1.5-1.7 GHz (tools/dev/bf_inkernel_clock.sh)
+        bf["mfma_fp4_measured_roof_PFLOPs"] = MFMA_FP4_MEASURED_PF
+        bf["frac_of_measured_fp4_roof"] = bf["mfma_fp4_PFLOPs"] / MFMA_FP4_MEASURED_PF
+        bf["note"] = ("matrix cores (FP4 operands); the vector unit only keeps a minimum over each lane's 16 accumulators per "
+                      "train tile (13 instructions per 16 descriptor pairs), the second smallest inside the best tile is "
+                      "recomputed once per query by xor / popcount; MM_BF_VARIANT=300 selects the round-2 FP4 kernel (2 "
+                      "instructions per pair), 200 the int8 MFMA form, 114 the xor / popcount kernel (2.0 T pairs/s = 91 % of the "
+                      "VALU issue roof of its instruction mix, profiles/r02_bf_pmc.txt); all return identical results")
         for k_ in ("valu_Tlops",):
             bf.pop(k_, None)
 

@@ -4,9 +4,12 @@
 // processor.featureTracking (reference processor.py:132-137) by the exact search FLANN-LSH approximates.
 //
 // Mapping to the hardware.  The search is compute bound (0.02 B of HBM per descriptor pair), and
-// there are three formulations of the distance in this file, all returning identical results (ties -> lowest train
-// index); MM_BF_VARIANT selects one, the default is the fastest:
-//  300  matrix cores, FP4 operands (bf_knn2_fp4_kernel): 1.25 ms per 500-frame clip = 6.4 T pairs/s    <- default
+// there are four formulations of the distance in this file, all returning identical results (ties -> lowest train
+// index); MM_BF_VARIANT selects one, the default is the fastest (times: tools/bench_bf.py, 499 pairs of 4000 x 4000):
+//  314  matrix cores, FP4 operands, ONE candidate per lane and train tile (bf_knn2_fp4min_kernel: the vector unit only
+//       takes a minimum over the lane's 16 accumulators; 4 waves per SIMD): 0.95 ms = 8.4 T pairs/s       <- default
+//       (310: the same at 3 waves per SIMD with the A operand read one tile ahead: no faster)
+//  300  matrix cores, FP4 operands, packed per-accumulator streams (bf_knn2_fp4_kernel): 1.15-1.2 ms = 6.6-6.9 T pairs/s
 //  200  matrix cores, int8 operands (bf_knn2_mfma_kernel): 1.9 ms = 4.2 T pairs/s
 //  114  xor / popcount on the vector unit (bf_knn2_lds_kernel, below): 3.9-4.2 ms = 2.0 T pairs/s; also what small
 //       train sets (< 64) and train sets of 65536 or more descriptors take
@@ -829,10 +832,14 @@ __global__ __launch_bounds__(BF_THREADS, 3) void bf_knn2_fp4_kernel(
 // and the second term is recomputed once per (lane, query) at the end of the kernel with xor / popcount on the 15 other
 // rows of that one tile (packed descriptors from global memory): ~300 instructions per lane and query against ~6000 saved.
 // Ties go to the lowest train index as everywhere (keys order by (dist, tile, row)).
-constexpr uint32_t F4M_BASE = 0x4B400000u;      // bit pattern of 1.5 * 2^23
 
+// The 13 instructions per (query tile, train tile) in four chunks (5 + 3 + 3 + 2) so that each can be placed behind one
+// matrix instruction of the OTHER query tile.
+struct F4mState {
+    uint32_t m[5], last, n0, n1, key;
+};
 template <bool PARTIAL>
-__device__ __forceinline__ uint32_t f4m_tile_key(const bf_v16f &acc, uint32_t tile32, int h, int dead_from) {
+__device__ __forceinline__ void f4m_chunk0(const bf_v16f &acc, F4mState &st, int h, int dead_from) {
     uint32_t v[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -844,27 +851,42 @@ __device__ __forceinline__ uint32_t f4m_tile_key(const bf_v16f &acc, uint32_t ti
         }
     }
     // minimum of 16 as v_min3_u32 x 8 (all values share sign and exponent: unsigned order = numeric order)
-    const uint32_t m0 = min(min(v[0], v[1]), v[2]), m1 = min(min(v[3], v[4]), v[5]), m2 = min(min(v[6], v[7]), v[8]);
-    const uint32_t m3 = min(min(v[9], v[10]), v[11]), m4 = min(min(v[12], v[13]), v[14]);
-    const uint32_t n0 = min(min(m0, m1), m2), n1 = min(min(m3, m4), v[15]);
-    const uint32_t m = min(n0, n1);
+#pragma unroll
+    for (int g = 0; g < 5; ++g) st.m[g] = min(min(v[3 * g], v[3 * g + 1]), v[3 * g + 2]);
+    st.last = v[15];
+}
+__device__ __forceinline__ void f4m_chunk1(F4mState &st) {
+    st.n0 = min(min(st.m[0], st.m[1]), st.m[2]);
+    st.n1 = min(min(st.m[3], st.m[4]), st.last);
+    st.n0 = min(st.n0, st.n1);
+}
+template <bool PARTIAL>
+__device__ __forceinline__ void f4m_chunk2(F4mState &st, uint32_t tile32) {
     // key = dist << 22 | tile * 32 + row   (mask: mantissa bits 5..21 = dist << 11; bit 22 is the 1.5)
+    const uint32_t m = st.n0;
     uint32_t k = ((m & 0x003FFFE0u) << 11) + tile32;
     k = (m & 31u) | k;
     if constexpr (PARTIAL) k = m == 0xFFFFFFFFu ? BF_NONE : k;
-    return k;
+    st.key = k;
 }
-
 __device__ __forceinline__ void f4m_update(uint32_t k, uint32_t &b0, uint32_t &b1) {      // b0 <= b1
     asm("v_med3_u32 %0, %1, %2, %3" : "=v"(b1) : "v"(b0), "v"(b1), "v"(k));      // = min(max(b0, k), b1) for b0 <= b1
     b0 = min(b0, k);
 }
 
-__global__ __launch_bounds__(BF_THREADS, 3) void bf_knn2_fp4min_kernel(
+#ifdef MM_BF_CLOCK
+// diagnostic build only (tools/dev/bf_inkernel_clock.sh): shader clock the kernel ran at = s_memtime ticks per 100 MHz
+// s_memrealtime tick around each workgroup's life; the product build executes no stamp
+__device__ long long g_bf_clock[2 * 4096];
+#endif
+// PIPE: the A operand of the next train tile is read from LDS behind the last use of the current one (see below); without
+// it a wave reads its operand after the barrier -- fewer registers: four waves per SIMD fit
+template <int WAVES, bool PIPE>
+__global__ __launch_bounds__(BF_THREADS, WAVES) void bf_knn2_fp4min_kernel(
     const uint8_t *__restrict__ q, const int32_t *__restrict__ nq_dev, int nq_cap, size_t q_stride,
     const uint8_t *__restrict__ tx, const uint8_t *__restrict__ tpk, size_t t_stride, const int32_t *__restrict__ nt_dev,
     int nt_cap, int ntp, int32_t *__restrict__ idx, int32_t *__restrict__ dist) {
-    __shared__ __attribute__((aligned(16))) uint8_t tile[2][MF_TT][F4_PITCH];
+    __shared__ __attribute__((aligned(16))) uint8_t tile[3][MF_TT][F4_PITCH];
     const int pair = blockIdx.z;
     const int nq = nq_dev ? min(nq_dev[pair], nq_cap) : nq_cap;
     const int nt = nt_dev ? min(nt_dev[pair], nt_cap) : nt_cap;
@@ -872,7 +894,11 @@ __global__ __launch_bounds__(BF_THREADS, 3) void bf_knn2_fp4min_kernel(
     if (qbase >= nq) return;  // workgroup-uniform
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int c = lane & 31, h = lane >> 5;
-    bf_v8i B[2][4];
+#ifdef MM_BF_CLOCK
+    const long long clk_t0 = __builtin_readcyclecounter();
+    const unsigned long long clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    bf_v4i B4[2][4];
     const uint8_t *qp = q + (size_t)pair * q_stride;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -887,7 +913,7 @@ __global__ __launch_bounds__(BF_THREADS, 3) void bf_knn2_fp4min_kernel(
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bf_v4i e = bf_fp4x32(~(h ? w[2 * j + 1] : w[2 * j]));      // queries enter NEGATED
-            B[u][j] = bf_v8i{e[0], e[1], e[2], e[3], 0, 0, 0, 0};
+            B4[u][j] = e;
         }
     }
     // C operand: 1.5 * 2^23 + 2^18 + row of accumulator i (rows 8 (i / 4) + 4 h + i % 4): never rewritten
@@ -919,93 +945,148 @@ __global__ __launch_bounds__(BF_THREADS, 3) void bf_knn2_fp4min_kernel(
     // go with a phase's results run in the shadow of the NEXT phase's matrix instructions (query tile 1 of tile t-1 beside
     // query tile 0 of tile t: carried across the barrier).  cbsz = blgp = 4: FP4 operands; block scales (E8M0): train
     // operand 137 = 2^10, queries 127 = 1.0.
+    // The A operand of tile t + 1 is read from LDS while tile t's matrix instructions run (three LDS buffers: tile t + 2 is
+    // being committed meanwhile), so that a wave leaves the barrier with its operands in registers.
     bf_v16f acc1_prev;
-    auto tile_step = [&](int tt, auto first_tag) __attribute__((always_inline)) {
+    bf_v4i A4[4];      // (four registers per K-step; the instruction's operand type is eight wide, the upper half unused for FP4)
+    auto read_a = [&](int buf, int j) __attribute__((always_inline)) {
+        A4[j] = *reinterpret_cast<const bf_v4i *>(&tile[buf][c][32 * j + 16 * h]);
+    };
+#define F4M_A(j) (bf_v8i{A4[j][0], A4[j][1], A4[j][2], A4[j][3], 0, 0, 0, 0})
+#define F4M_B(u, j) (bf_v8i{B4[u][j][0], B4[u][j][1], B4[u][j][2], B4[u][j][3], 0, 0, 0, 0})
+    auto tile_step = [&](int tt, auto first_tag, int nxt, bool have_next) __attribute__((always_inline)) {
         constexpr bool HAVE_PREV = !decltype(first_tag)::value;
-        const int buf = tt & 1;
-        bf_v8i A[4];
+        if constexpr (!PIPE) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bf_v4i a = *reinterpret_cast<const bf_v4i *>(&tile[buf][c][32 * j + 16 * h]);
-            A[j] = bf_v8i{a[0], a[1], a[2], a[3], 0, 0, 0, 0};
+            for (int j = 0; j < 4; ++j) read_a((nxt + 2) % 3, j);
         }
-        bf_v16f acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[0], B[0][0], cinit, 4, 4, 0, 137, 0, 127);
-        if constexpr (HAVE_PREV) f4m_update(f4m_tile_key<false>(acc1_prev, (uint32_t)(tt - 1) * MF_TT, h, 0), b0[1], b1[1]);
+        // query tile 0 of this train tile beside the bookkeeping of query tile 1 of the previous one, then query tile 1
+        // beside the bookkeeping of query tile 0: one matrix instruction, one chunk of vector work, and so on
+        F4mState st;
+        bf_v16f acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(F4M_A(0), F4M_B(0, 0), cinit, 4, 4, 0, 137, 0, 127);
+        if constexpr (HAVE_PREV) f4m_chunk0<false>(acc1_prev, st, h, 0);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 1; j < 4; ++j) acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[j], B[0][j], acc0, 4, 4, 0, 137, 0, 127);
-        bf_v16f acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[0], B[1][0], cinit, 4, 4, 0, 137, 0, 127);
-        f4m_update(f4m_tile_key<false>(acc0, (uint32_t)tt * MF_TT, h, 0), b0[0], b1[0]);
+        acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(F4M_A(1), F4M_B(0, 1), acc0, 4, 4, 0, 137, 0, 127);
+        if constexpr (HAVE_PREV) f4m_chunk1(st);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 1; j < 4; ++j) acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[j], B[1][j], acc1, 4, 4, 0, 137, 0, 127);
+        acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(F4M_A(2), F4M_B(0, 2), acc0, 4, 4, 0, 137, 0, 127);
+        if constexpr (HAVE_PREV) f4m_chunk2<false>(st, (uint32_t)(tt - 1) * MF_TT);
+        __builtin_amdgcn_sched_barrier(0);
+        acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(F4M_A(3), F4M_B(0, 3), acc0, 4, 4, 0, 137, 0, 127);
+        if constexpr (HAVE_PREV) f4m_update(st.key, b0[1], b1[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        bf_v16f acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(F4M_A(0), F4M_B(1, 0), cinit, 4, 4, 0, 137, 0, 127);
+        if (PIPE && have_next) read_a(nxt, 0);
+        f4m_chunk0<false>(acc0, st, h, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(F4M_A(1), F4M_B(1, 1), acc1, 4, 4, 0, 137, 0, 127);
+        if (PIPE && have_next) read_a(nxt, 1);
+        f4m_chunk1(st);
+        __builtin_amdgcn_sched_barrier(0);
+        acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(F4M_A(2), F4M_B(1, 2), acc1, 4, 4, 0, 137, 0, 127);
+        if (PIPE && have_next) read_a(nxt, 2);
+        f4m_chunk2<false>(st, (uint32_t)tt * MF_TT);
+        __builtin_amdgcn_sched_barrier(0);
+        acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(F4M_A(3), F4M_B(1, 3), acc1, 4, 4, 0, 137, 0, 127);
+        if (PIPE && have_next) read_a(nxt, 3);
+        f4m_update(st.key, b0[0], b1[0]);
+        __builtin_amdgcn_sched_barrier(0);
         acc1_prev = acc1;
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>;
+    // tile t lives in register set / LDS buffer t % 3
     fetch(0, I0{});
     fetch(1, I1{});
     fetch(2, I2{});
     if (ntiles > 0) commit(0, I0{});
     fetch(3, I0{});
+    if (ntiles > 1) commit(1, I1{});
+    fetch(4, I1{});
     __syncthreads();
+    if constexpr (PIPE) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) read_a(0, j);
+    }
     const int nfull = nt / MF_TT;
-    auto iteration = [&](int tt, auto next_set, auto first_tag) __attribute__((always_inline)) {
-        tile_step(tt, first_tag);
-        if (tt + 1 < ntiles) commit((tt & 1) ^ 1, next_set);
-        fetch(tt + 4, next_set);
+    // iteration tt (tt % 3 == CUR): A(tt) is in registers; read A(tt + 1), compute, commit tile tt + 2, request tile tt + 5
+    auto iteration = [&](int tt, auto cur_tag, auto first_tag) __attribute__((always_inline)) {
+        constexpr int CUR = decltype(cur_tag)::value, NXT = (CUR + 1) % 3, C2 = (CUR + 2) % 3;
+        tile_step(tt, first_tag, NXT, tt + 1 < ntiles);
+        if (tt + 2 < ntiles) commit(C2, std::integral_constant<int, C2>{});
+        fetch(tt + 5, std::integral_constant<int, C2>{});
         __syncthreads();
     };
     int tt = 0;
     if (nfull > 0) {      // peeled: the first tile has no predecessor
-        iteration(0, I1{}, std::true_type{});
+        iteration(0, I0{}, std::true_type{});
         tt = 1;
+        if (tt < nfull) { iteration(tt, I1{}, std::false_type{}); ++tt; }
         if (tt < nfull) { iteration(tt, I2{}, std::false_type{}); ++tt; }
-        if (tt < nfull) { iteration(tt, I0{}, std::false_type{}); ++tt; }
     }
-    for (; tt + 3 <= nfull; tt += 3) {
-        iteration(tt, I1{}, std::false_type{});
-        iteration(tt + 1, I2{}, std::false_type{});
-        iteration(tt + 2, I0{}, std::false_type{});
+    for (; tt + 3 <= nfull; tt += 3) {      // (tt is a multiple of 3 here)
+        iteration(tt, I0{}, std::false_type{});
+        iteration(tt + 1, I1{}, std::false_type{});
+        iteration(tt + 2, I2{}, std::false_type{});
     }
     if (tt < nfull) {
-        iteration(tt, I1{}, std::false_type{});
-        if (tt + 1 < nfull) iteration(tt + 1, I2{}, std::false_type{});
+        iteration(tt, I0{}, std::false_type{});
+        if (tt + 1 < nfull) iteration(tt + 1, I1{}, std::false_type{});
     }
-    if (nfull > 0) f4m_update(f4m_tile_key<false>(acc1_prev, (uint32_t)(nfull - 1) * MF_TT, h, 0), b0[1], b1[1]);
+    auto book = [&](const bf_v16f &acc, uint32_t tile32, int u, auto partial_tag, int dead_from) __attribute__((always_inline)) {
+        constexpr bool PARTIAL = decltype(partial_tag)::value;
+        F4mState st;
+        f4m_chunk0<PARTIAL>(acc, st, h, dead_from);
+        f4m_chunk1(st);
+        f4m_chunk2<PARTIAL>(st, tile32);
+        f4m_update(st.key, b0[u], b1[u]);
+    };
+    if (nfull > 0) book(acc1_prev, (uint32_t)(nfull - 1) * MF_TT, 1, std::false_type{}, 0);
     if (nfull < ntiles) {      // the partial last tile, unpipelined: rows past the last train never win
-        const int buf = nfull & 1;
-        bf_v16f acc0 = cinit, acc1 = cinit;
+        bf_v16f acc0 = cinit, acc1 = cinit;      // (PIPE: the operands of tile nfull were read during the last iteration)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const bf_v4i a = *reinterpret_cast<const bf_v4i *>(&tile[buf][c][32 * j + 16 * h]);
-            const bf_v8i A = bf_v8i{a[0], a[1], a[2], a[3], 0, 0, 0, 0};
-            acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B[0][j], acc0, 4, 4, 0, 137, 0, 127);
-            acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B[1][j], acc1, 4, 4, 0, 137, 0, 127);
+            if constexpr (!PIPE) read_a(nfull % 3, j);
+            acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(F4M_A(j), F4M_B(0, j), acc0, 4, 4, 0, 137, 0, 127);
+            acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(F4M_A(j), F4M_B(1, j), acc1, 4, 4, 0, 137, 0, 127);
         }
         const int dead_from = nt - nfull * MF_TT;
-        f4m_update(f4m_tile_key<true>(acc0, (uint32_t)nfull * MF_TT, h, dead_from), b0[0], b1[0]);
-        f4m_update(f4m_tile_key<true>(acc1, (uint32_t)nfull * MF_TT, h, dead_from), b0[1], b1[1]);
+        book(acc0, (uint32_t)nfull * MF_TT, 0, std::true_type{}, dead_from);
+        book(acc1, (uint32_t)nfull * MF_TT, 1, std::true_type{}, dead_from);
     }
     // the second smallest INSIDE the best tile, by xor / popcount on the lane's 15 other rows of that tile
     const uint8_t *tp = tpk + (size_t)pair * t_stride;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int qi = qbase + 64 * wv + 32 * u + c;
-        if (b0[u] != BF_NONE) {
+        {
+            // (all loads unconditional on clamped rows and issued in four batches of four: a guarded load per row turns into
+            // sixteen dependent trips to memory)
             const uint4 *p = reinterpret_cast<const uint4 *>(qp + (size_t)min(qi, nq - 1) * 32);
             const uint4 lo = p[0], hi = p[1];
             const uint32_t a[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-            const uint32_t best_idx = b0[u] & 0xFFFFu, t0 = best_idx & ~31u;
+            const bool have = b0[u] != BF_NONE;
+            const uint32_t best_idx = have ? (b0[u] & 0xFFFFu) : 0u, t0 = best_idx & ~31u;
+            const uint32_t last = (uint32_t)max(nt - 1, 0);
             uint32_t c2 = BF_NONE;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const uint32_t ti = t0 + (uint32_t)(8 * (i >> 2) + 4 * h + (i & 3));
-                if (ti != best_idx && ti < (uint32_t)nt) {
-                    const uint4 *r = reinterpret_cast<const uint4 *>(tp + (size_t)ti * 32);
-                    const uint32_t d = ham256(a, r[0], r[1]);
-                    c2 = min(c2, (d << 22) | ti);
+            for (int part = 0; part < 4; ++part) {
+                uint4 r0[4], r1[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ii = 4 * part + i;
+                    const uint32_t ti = t0 + (uint32_t)(8 * (ii >> 2) + 4 * h + (ii & 3));
+                    const uint4 *r = reinterpret_cast<const uint4 *>(tp + (size_t)min(ti, last) * 32);
+                    r0[i] = r[0];
+                    r1[i] = r[1];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ii = 4 * part + i;
+                    const uint32_t ti = t0 + (uint32_t)(8 * (ii >> 2) + 4 * h + (ii & 3));
+                    const uint32_t key = (ham256(a, r0[i], r1[i]) << 22) | ti;
+                    c2 = (have && ti != best_idx && ti < (uint32_t)nt) ? min(c2, key) : c2;
                 }
             }
             b1[u] = min(b1[u], c2);
@@ -1022,28 +1103,38 @@ __global__ __launch_bounds__(BF_THREADS, 3) void bf_knn2_fp4min_kernel(
             dist[o + 1] = b1[u] == BF_NONE ? -1 : (int32_t)(b1[u] >> 22);
         }
     }
+#ifdef MM_BF_CLOCK
+    if (threadIdx.x == 0) {
+        const unsigned w = (blockIdx.z * gridDim.x + blockIdx.x) & 4095u;
+        g_bf_clock[2 * w] = __builtin_readcyclecounter() - clk_t0;
+        g_bf_clock[2 * w + 1] = (long long)(__builtin_amdgcn_s_memrealtime() - clk_r0);
+    }
+#endif
 }
 
+#undef F4M_B
+#undef F4M_A
 // queries per lane: 2 amortises the scalar train loads over two descriptor pairs; small launches use 1 to get more waves.
 // MM_BF_VARIANT=<qpl><unroll> (e.g. 24, 28, 44, 14) overrides for tuning runs.
 int bf_variant(int n_pairs, int nq_cap) {
     const char *e = getenv("MM_BF_VARIANT");
     const int forced = e ? atoi(e) : 0;
     if (forced) return forced;
-    return 300;  // 300: matrix cores, FP4 operands (bf_knn2_fp4_kernel); 200: int8 (bf_knn2_mfma_kernel); 114: the best
+    return 314;  // 314 / 310: matrix cores, FP4 operands, one candidate per lane and train tile (bf_knn2_fp4min_kernel, 4 / 3
+                 // waves per SIMD); 300: FP4 with packed per-accumulator streams (bf_knn2_fp4_kernel); 200: int8; 114: the best
 }                // xor / popcount variant (LDS-fed, one query per lane)
 
 // the MFMA formulation needs train indices below 2^16 and pays off from a few train tiles on
 bool bf_use_mfma(int n_pairs, int nq_cap, int nt_cap) {
     const int v = bf_variant(n_pairs, nq_cap);
-    return (v == 200 || v == 300 || v == 310) && nt_cap >= 64 && nt_cap < 65536;
+    return (v == 200 || v == 300 || v == 310 || v == 314) && nt_cap >= 64 && nt_cap < 65536;
 }
 int bf_ntp(int nt_cap) { return (nt_cap + MF_TT - 1) / MF_TT * MF_TT; }
 
 int bf_choose_splits(int n_pairs, int nq_cap, int nt_cap) {
     if (bf_use_mfma(n_pairs, nq_cap, nt_cap)) return 1;
     int var = bf_variant(n_pairs, nq_cap);
-    if (var == 200 || var == 300 || var == 310) var = 114;      // (shapes the matrix-core kernels do not take)
+    if (var == 200 || var >= 300) var = 114;      // (shapes the matrix-core kernels do not take)
     const int BF_QTILE = BF_THREADS * ((var / 10) % 10);
     long waves = (long)n_pairs * ((nq_cap + BF_QTILE - 1) / BF_QTILE) * (BF_THREADS / 64);
     if (waves <= 0) return 1;
@@ -1056,6 +1147,12 @@ int bf_choose_splits(int n_pairs, int nq_cap, int nt_cap) {
 }
 
 }  // namespace
+
+#ifdef MM_BF_CLOCK
+extern "C" int mm_debug_bf_clock(long long *host /*[2*4096]*/) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_bf_clock), sizeof(g_bf_clock));
+}
+#endif
 
 extern "C" {
 
@@ -1091,23 +1188,28 @@ int mm_bf_knn2_batched(mm_ctx *ctx, const uint8_t *q, const int32_t *nq, int nq_
             MM_LAUNCH(ctx, "bf_expand_kernel", bf_expand_fp4_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, t, nt_cap,
                       t_set_stride, ntp, n_pairs, (uint8_t *)ws);
             if (bf_variant(n_pairs, nq_cap) == 310) {
-                MM_LAUNCH(ctx, "bf_knn2_kernel", bf_knn2_fp4min_kernel, grid, dim3(BF_THREADS), 0, q, nq, nq_cap, q_set_stride,
+                MM_LAUNCH(ctx, "bf_knn2_fp4min_kernel", (bf_knn2_fp4min_kernel<3, true>), grid, dim3(BF_THREADS), 0, q, nq, nq_cap, q_set_stride,
                           (const uint8_t *)ws, t, t_set_stride, nt, nt_cap, ntp, idx, dist);
                 return MM_OK;
             }
-            MM_LAUNCH(ctx, "bf_knn2_kernel", bf_knn2_fp4_kernel, grid, dim3(BF_THREADS), 0, q, nq, nq_cap, q_set_stride,
+            if (bf_variant(n_pairs, nq_cap) == 314) {
+                MM_LAUNCH(ctx, "bf_knn2_fp4min_kernel", (bf_knn2_fp4min_kernel<4, false>), grid, dim3(BF_THREADS), 0, q, nq, nq_cap, q_set_stride,
+                          (const uint8_t *)ws, t, t_set_stride, nt, nt_cap, ntp, idx, dist);
+                return MM_OK;
+            }
+            MM_LAUNCH(ctx, "bf_knn2_fp4_kernel", bf_knn2_fp4_kernel, grid, dim3(BF_THREADS), 0, q, nq, nq_cap, q_set_stride,
                       (const uint8_t *)ws, nt, nt_cap, ntp, idx, dist);
             return MM_OK;
         }
         const size_t chunks = (size_t)n_pairs * ntp * 16;
         MM_LAUNCH(ctx, "bf_expand_kernel", bf_expand_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, t, nt_cap,
                   t_set_stride, ntp, n_pairs, (uint8_t *)ws);
-        MM_LAUNCH(ctx, "bf_knn2_kernel", bf_knn2_mfma_kernel, grid, dim3(BF_THREADS), 0, q, nq, nq_cap, q_set_stride,
+        MM_LAUNCH(ctx, "bf_knn2_mfma_kernel", bf_knn2_mfma_kernel, grid, dim3(BF_THREADS), 0, q, nq, nq_cap, q_set_stride,
                   (const uint8_t *)ws, nt, nt_cap, ntp, idx, dist);
         return MM_OK;
     }
     int var = bf_variant(n_pairs, nq_cap);
-    if (var == 200 || var == 300 || var == 310) var = 114;      // (shapes the matrix-core kernels do not take)
+    if (var == 200 || var >= 300) var = 114;      // (shapes the matrix-core kernels do not take)
     const int qtile = BF_THREADS * ((var / 10) % 10);
     dim3 grid((nq_cap + qtile - 1) / qtile, s, n_pairs);
 #define BF_GO(Q, U)                                                                                              \
@@ -1122,15 +1224,15 @@ int mm_bf_knn2_batched(mm_ctx *ctx, const uint8_t *q, const int32_t *nq, int nq_
         case 44: BF_GO(4, 4); break;
         case 48: BF_GO(4, 8); break;
 #define BF_GO_LDS(Q)                                                                                             \
-    MM_LAUNCH(ctx, "bf_knn2_kernel", (bf_knn2_lds_kernel<Q>), grid, dim3(BF_THREADS), 0, q, nq, nq_cap, q_set_stride, t, \
+    MM_LAUNCH(ctx, "bf_knn2_lds_kernel", (bf_knn2_lds_kernel<Q>), grid, dim3(BF_THREADS), 0, q, nq, nq_cap, q_set_stride, t, \
               nt, nt_cap, t_set_stride, s, (uint32_t *)ws, idx, dist)
         case 114: BF_GO_LDS(1); break;
         case 115:
-            MM_LAUNCH(ctx, "bf_knn2_kernel", (bf_knn2_lds_kernel<1, 512>), grid, dim3(BF_THREADS), 0, q, nq, nq_cap, q_set_stride,
+            MM_LAUNCH(ctx, "bf_knn2_lds_kernel", (bf_knn2_lds_kernel<1, 512>), grid, dim3(BF_THREADS), 0, q, nq, nq_cap, q_set_stride,
                       t, nt, nt_cap, t_set_stride, s, (uint32_t *)ws, idx, dist);
             break;
         case 125:
-            MM_LAUNCH(ctx, "bf_knn2_kernel", (bf_knn2_lds_kernel<2, 512>), grid, dim3(BF_THREADS), 0, q, nq, nq_cap, q_set_stride,
+            MM_LAUNCH(ctx, "bf_knn2_lds_kernel", (bf_knn2_lds_kernel<2, 512>), grid, dim3(BF_THREADS), 0, q, nq, nq_cap, q_set_stride,
                       t, nt, nt_cap, t_set_stride, s, (uint32_t *)ws, idx, dist);
             break;
         case 124: BF_GO_LDS(2); break;

@@ -48,7 +48,7 @@ def test_bf_knn2_single_pair_bit_exact(n, seed):
     np.testing.assert_array_equal(pairs[0, :len(po)].cpu().numpy(), po)
 
 
-@pytest.mark.parametrize("variant", ["114", "200", "300", "310"])
+@pytest.mark.parametrize("variant", ["114", "200", "300", "310", "314"])
 def test_bf_knn2_formulations_agree_with_oracle(variant, monkeypatch):
     """The three formulations of the Hamming search in csrc/bf_match.hip -- xor / popcount on the vector unit (114), the
     +1 / -1 GEMM on the int8 matrix instruction (200) and on the FP4 one (300, the default) -- against the C oracle on a

@@ -35,6 +35,31 @@ __global__ void rate_fp4(long long *out, int iters) {
     if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
     if (c0[0] + c1[1] + c2[2] + c3[3] == 12345.f) out[1000] = 1;
 }
+// the same instruction on operands with the statistics of the matching kernel: random +1 / -1 nibbles (0x2 / 0xA), fresh
+// per iteration (rotated), block scale 2^10 on one side; reports the shader clock it ran at (s_memtime vs the 100 MHz
+// s_memrealtime): under toggling operands the chip clocks lower than on constants, and THAT rate is the roof of the kernel
+__global__ void rate_fp4_rand(long long *out, int iters, unsigned seed) {
+    unsigned x = seed ^ (threadIdx.x * 2654435761u) ^ (blockIdx.x * 40503u);
+    auto nib = [&]() { x = x * 1664525u + 1013904223u; unsigned r = 0; for (int k = 0; k < 8; ++k) r |= (((x >> (k + 8)) & 1u) ? 0xAu : 0x2u) << (4 * k); return (int)r; };
+    v8i a = {nib(), nib(), nib(), nib(), 0, 0, 0, 0}, b = {nib(), nib(), nib(), nib(), 0, 0, 0, 0};
+    v16f c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+    const long long t0 = __builtin_readcyclecounter();
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) {
+        c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c0, 4, 4, 0, 137, 0, 127);
+        a[0] = __builtin_amdgcn_alignbit(a[0], a[1], 4);
+        c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b, a, c1, 4, 4, 0, 137, 0, 127);
+        b[1] = __builtin_amdgcn_alignbit(b[1], b[2], 8);
+        c2 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c2, 4, 4, 0, 137, 0, 127);
+        a[2] = __builtin_amdgcn_alignbit(a[2], a[3], 12);
+        c3 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b, a, c3, 4, 4, 0, 137, 0, 127);
+        b[3] = __builtin_amdgcn_alignbit(b[3], b[0], 16);
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { out[2 * blockIdx.x] = t1 - t0; out[2 * blockIdx.x + 1] = (long long)(r1 - r0); }
+    if (c0[0] + c1[1] + c2[2] + c3[3] == 12345.f) out[4000] = 1;
+}
 int main() {
     long long *d, h[4];
     hipMalloc(&d, 1001 * 8);
@@ -57,6 +82,20 @@ int main() {
         float ms; hipEventElapsedTime(&ms, e0, e1);
         const double ops = 1024.0 * iters * 4 * 2.0 * 32 * 32 * (which == 0 ? 32 : 64);
         printf("%s all SIMDs: %.3f ms -> %.2f P(FL)OP/s, %.1f ns per MFMA per SIMD\n", which == 0 ? "i8 " : "fp4", ms, ops / ms / 1e12, ms * 1e6 / (iters * 4));
+    }
+    {   // >= 10 ms on random operands, every SIMD busy
+        long long *d2; hipMalloc(&d2, 4001 * 8);
+        const int it2 = 200000;
+        hipLaunchKernelGGL(rate_fp4_rand, dim3(1024), dim3(64), 0, 0, d2, 1000, 7u);
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(rate_fp4_rand, dim3(1024), dim3(64), 0, 0, d2, it2, 7u);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        long long hh[2048]; hipMemcpy(hh, d2, sizeof(hh), hipMemcpyDeviceToHost);
+        double clk = 0; for (int i = 0; i < 1024; ++i) clk += (double)hh[2 * i] / (double)hh[2 * i + 1] * 0.1; clk /= 1024;
+        const double ops = 1024.0 * it2 * 4 * 2.0 * 32 * 32 * 64;
+        printf("fp4 all SIMDs, random +-1 operands: %.3f ms -> %.2f PFLOP/s, %.1f ns per MFMA per SIMD, shader clock %.2f GHz, %.1f cycles per MFMA\n",
+               ms, ops / ms / 1e12, ms * 1e6 / (it2 * 4.0), clk, ms * 1e6 / (it2 * 4.0) * clk);
     }
     return 0;
 }
