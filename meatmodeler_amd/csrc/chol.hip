@@ -55,20 +55,12 @@ __device__ __forceinline__ int thread_id() {
     return t;
 }
 
-__device__ __forceinline__ double readlane_f64(double x, int src_lane /*wave-uniform*/) {
-    const unsigned long long u = __double_as_longlong(x);
-    const unsigned lo = __builtin_amdgcn_readlane((int)(u & 0xffffffffu), src_lane);
-    const unsigned hi = __builtin_amdgcn_readlane((int)(u >> 32), src_lane);
-    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
-}
-
 // ---- (1) diagonal block ------------------------------------------------------------------------------------------------
 // Panel pb (columns c0 = 16 pb ..) of the 64 x 64 block in LDS.  update: wave w brings rows 16w..16w+15 of the panel
 // up to date from the finished columns with f64 MFMA (K = c0).  factor (ONE wave): the 64 x 16 panel in registers,
-// lane = row; pivots and panel columns travel by v_readlane.  A lone wave is issue-latency bound, so the point is to
-// minimise instructions per FMA: fully unrolled, static register indices, 1/sqrt by v_rsq_f64 + two Newton steps (one
-// transcendental and ~8 FMAs per pivot instead of a sqrt and a division); the reciprocals 1/L_jj are kept in R for
-// the inverse.
+// lane = row.  A lone wave is issue bound (an f64 instruction every 8 cycles), so the point is to minimise instructions
+// per FMA: fully unrolled, static register indices, 1/sqrt by v_rsq_f64 + two Newton steps (one transcendental and ~8
+// FMAs per pivot instead of a sqrt and a division); the reciprocals 1/L_jj are kept in R for the inverse.
 template <int PB>
 __device__ __forceinline__ void panel16_update(double (*M)[NB + 1]) {
     constexpr int c0 = PB * 16;
@@ -88,122 +80,81 @@ __device__ __forceinline__ void panel16_update(double (*M)[NB + 1]) {
     __syncthreads();
 }
 
-// a[j] -= x * src[lane SRC + j], j < N <= 4: the broadcasts go through fixed SGPR pairs inside ONE asm statement.
-// (Left to the scheduler, the 2 x 120 v_readlane of a panel are hoisted ahead of their FMAs and the scalar registers
-// spill.)  gfx950 hazards the assembler does not see inside asm: a VALU reading an SGPR written by v_readlane needs
-// 2 wait states, v_readlane reading a VGPR written by the previous VALU needs 1 -- covered by the instruction order
-// for N >= 3 and by s_nop otherwise; FRESH = the source was produced by the instruction right before.
-template <int SRC, int N, bool FRESH>
-__device__ __forceinline__ void fnma_bcast(double &a0, double &a1, double &a2, double &a3, double src, double x) {
-    if constexpr (FRESH) asm volatile("s_nop 1" : "+v"(src));  // tied to src: stays between its producer and the readlanes
-    const unsigned long long u = __double_as_longlong(src);
-    const unsigned lo = (unsigned)u, hi = (unsigned)(u >> 32);
-    if constexpr (N == 4)
-        asm volatile(
-            "v_readlane_b32 s88, %4, %7\n\tv_readlane_b32 s89, %5, %7\n\t"
-            "v_readlane_b32 s90, %4, %7+1\n\tv_readlane_b32 s91, %5, %7+1\n\t"
-            "v_readlane_b32 s92, %4, %7+2\n\tv_readlane_b32 s93, %5, %7+2\n\t"
-            "v_readlane_b32 s94, %4, %7+3\n\tv_readlane_b32 s95, %5, %7+3\n\t"
-            "v_fma_f64 %0, -%6, s[88:89], %0\n\tv_fma_f64 %1, -%6, s[90:91], %1\n\t"
-            "v_fma_f64 %2, -%6, s[92:93], %2\n\tv_fma_f64 %3, -%6, s[94:95], %3"
-            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)
-            : "v"(lo), "v"(hi), "v"(x), "n"(SRC)
-            : "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95");
-    if constexpr (N == 3)
-        asm volatile(
-            "v_readlane_b32 s88, %3, %6\n\tv_readlane_b32 s89, %4, %6\n\t"
-            "v_readlane_b32 s90, %3, %6+1\n\tv_readlane_b32 s91, %4, %6+1\n\t"
-            "v_readlane_b32 s92, %3, %6+2\n\tv_readlane_b32 s93, %4, %6+2\n\t"
-            "v_fma_f64 %0, -%5, s[88:89], %0\n\tv_fma_f64 %1, -%5, s[90:91], %1\n\t"
-            "v_fma_f64 %2, -%5, s[92:93], %2"
-            : "+v"(a0), "+v"(a1), "+v"(a2)
-            : "v"(lo), "v"(hi), "v"(x), "n"(SRC)
-            : "s88", "s89", "s90", "s91", "s92", "s93");
-    if constexpr (N == 2)
-        asm volatile(
-            "v_readlane_b32 s88, %2, %5\n\tv_readlane_b32 s89, %3, %5\n\t"
-            "v_readlane_b32 s90, %2, %5+1\n\tv_readlane_b32 s91, %3, %5+1\n\t"
-            "s_nop 1\n\t"
-            "v_fma_f64 %0, -%4, s[88:89], %0\n\tv_fma_f64 %1, -%4, s[90:91], %1\n\t"
-            "s_nop 0"
-            : "+v"(a0), "+v"(a1)
-            : "v"(lo), "v"(hi), "v"(x), "n"(SRC)
-            : "s88", "s89", "s90", "s91");
-    if constexpr (N == 1)
-        asm volatile(
-            "v_readlane_b32 s88, %1, %4\n\tv_readlane_b32 s89, %2, %4\n\t"
-            "s_nop 1\n\t"
-            "v_fma_f64 %0, -%3, s[88:89], %0\n\t"
-            "s_nop 0"
-            : "+v"(a0)
-            : "v"(lo), "v"(hi), "v"(x), "n"(SRC)
-            : "s88", "s89");
+// ---- the panel itself: DPP row broadcasts ---------------------------------------------------------------------------------
+// (Round 2 used 2 v_readlane_b32 + 1 v_fma_f64 with an SGPR operand per rank-1 update: see the history of this file.)
+// f64 vector instructions issue every 8 cycles from a lone wave, a v_readlane_b32 every 4: 2 v_readlane + 1 v_fma per
+// rank-1 update is 16 cycles, and so are TWO v_fmac_f64_dpp -- one for the lane's own row, one for a SHADOW copy of the
+// 16 x 16 diagonal block that every 16-lane DPP row keeps (row t of the block in lane t of each DPP row), so that
+// row_newbcast:j delivers L[c0 + j][q] to all 64 lanes without touching the scalar unit:
+//     a[j]  -= bcast_j(slq) * lq        (own row)          sh[j] -= bcast_j(slq) * slq       (shadow row)
+// That alone is a draw; the gain is what falls away around it: no SGPR traffic (no hazard nops, no pivot read-ahead), 13
+// instead of 20 instructions of per-column overhead.  Measured (tools/dev/panel_insitu.hip): 1.65 us per 64 x 16 panel
+// against 2.3.  (Tried: identity rows in the idle lanes above the panel, which the elimination turns into L_dd^-T for
+// free -- 0.3 us for the extra selects plus 0.2 us for the masked LDS stores per panel; the separate 16 x 16 inversion
+// below, with the same broadcasts, is 0.5 us and runs on another wave for three of the four panels.)
+template <int J>
+__device__ __forceinline__ void fmac_bcast(double &acc, double bsrc, double x) {   // acc -= bcast_J(bsrc) * x
+    asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bsrc), "v"(x), "n"(J));
 }
-
-// updates of columns Q + 1 + G .. of the panel by column Q (value lq), four at a time
-template <int C0, int Q, int G>
-__device__ __forceinline__ void panel16_update_cols(double (&a)[16], double lq) {
-    constexpr int first = Q + 1 + G;
-    constexpr int left = 16 - first;
-    if constexpr (left > 0) {
-        constexpr int n = left >= 4 ? 4 : left;
-        constexpr int i1 = first + 1 < 16 ? first + 1 : 15, i2 = first + 2 < 16 ? first + 2 : 15,
-                      i3 = first + 3 < 16 ? first + 3 : 15;
-        fnma_bcast<C0 + first, n, G == 0>(a[first], a[i1], a[i2], a[i3], lq, lq);
-        panel16_update_cols<C0, Q, G + 4>(a, lq);
+template <int J>
+__device__ __forceinline__ double mov_bcast(double src) {   // (s_nop: a DPP read of a VGPR written by the previous VALU needs 2 wait states)
+    double r;
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(src), "n"(J));
+    return r;
+}
+template <int Q, int J>
+__device__ __forceinline__ void dpp_update_cols(double (&a)[16], double (&sh)[16], double slq, double lq) {
+    if constexpr (J < 16) {
+        fmac_bcast<J>(sh[J], slq, slq);
+        fmac_bcast<J>(a[J], slq, lq);
+        dpp_update_cols<Q, J + 1>(a, sh, slq, lq);
     }
 }
-
-template <int C0, int Q>
-__device__ __forceinline__ void panel16_column(double (&a)[16], double &piv, double &myr, int lane) {
-    // 1 / sqrt(piv): v_rsq_f64 + two Newton steps
-    double r = __builtin_amdgcn_rsq(piv);
+template <int Q>
+__device__ __forceinline__ void dpp_column(double (&a)[16], double (&sh)[16], double &rvec, int t) {
+    const double piv = mov_bcast<Q>(sh[Q]);
+    double r = __builtin_amdgcn_rsq(piv);      // 1 / sqrt(piv): v_rsq_f64 + two Newton steps
     r = r * (1.5 - 0.5 * piv * r * r);
     r = r * (1.5 - 0.5 * piv * r * r);
-    if constexpr (Q < 15) {
-        // the next pivot on the side: what lane C0+Q+1 is about to compute for its diagonal entry, bit for bit,
-        // without waiting for the column below to travel through the lanes
-        const double l = readlane_f64(a[Q], C0 + Q + 1) * r;
-        piv = __builtin_fma(-l, l, readlane_f64(a[Q + 1], C0 + Q + 1));
-    }
-    const double lq = a[Q] * r;  // rows above the diagonal carry zeros (or garbage that never reaches the lower part)
-    a[Q] = lq;
-    myr = lane == C0 + Q ? r : myr;
-    panel16_update_cols<C0, Q, 0>(a, lq);
+    rvec = t == Q ? r : rvec;
+    sh[Q] *= r;
+    a[Q] *= r;
+    asm volatile("s_nop 1" : "+v"(sh[Q]), "+v"(a[Q]));
+    dpp_update_cols<Q, Q + 1>(a, sh, sh[Q], a[Q]);
 }
-
-// A non-positive pivot is not handled on the sequential path: rsq turns it into NaN, which spreads to every later
-// column, and block_first_bad() finds the first damaged diagonal entry afterwards.
+// Panel PB of the 64 x 64 block in M (columns c0 = 16 PB ..), ONE wave; R receives the reciprocal pivots.
 template <int PB>
-__device__ __forceinline__ void panel16_factor(double (*M)[NB + 1], double *R) {
+__device__ __forceinline__ void panel16_factor_dpp(double (*M)[NB + 1], double (*X)[NB + 1], double *R) {
     constexpr int c0 = PB * 16;
-    const int lane = lane_id();
-    double a[16];
+    const int lane = lane_id(), t = lane & 15;
+    double a[16], sh[16], rvec = 0.0;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-        const double v = M[lane][c0 + q];
+        const double v = M[lane][c0 + q], d = M[c0 + t][c0 + q];
         a[q] = lane >= c0 + q ? v : 0.0;
+        sh[q] = t >= q ? d : 0.0;
     }
-    double piv = readlane_f64(a[0], c0), myr = 0.0;
-    panel16_column<c0, 0>(a, piv, myr, lane);
-    panel16_column<c0, 1>(a, piv, myr, lane);
-    panel16_column<c0, 2>(a, piv, myr, lane);
-    panel16_column<c0, 3>(a, piv, myr, lane);
-    panel16_column<c0, 4>(a, piv, myr, lane);
-    panel16_column<c0, 5>(a, piv, myr, lane);
-    panel16_column<c0, 6>(a, piv, myr, lane);
-    panel16_column<c0, 7>(a, piv, myr, lane);
-    panel16_column<c0, 8>(a, piv, myr, lane);
-    panel16_column<c0, 9>(a, piv, myr, lane);
-    panel16_column<c0, 10>(a, piv, myr, lane);
-    panel16_column<c0, 11>(a, piv, myr, lane);
-    panel16_column<c0, 12>(a, piv, myr, lane);
-    panel16_column<c0, 13>(a, piv, myr, lane);
-    panel16_column<c0, 14>(a, piv, myr, lane);
-    panel16_column<c0, 15>(a, piv, myr, lane);
+    dpp_column<0>(a, sh, rvec, t);
+    dpp_column<1>(a, sh, rvec, t);
+    dpp_column<2>(a, sh, rvec, t);
+    dpp_column<3>(a, sh, rvec, t);
+    dpp_column<4>(a, sh, rvec, t);
+    dpp_column<5>(a, sh, rvec, t);
+    dpp_column<6>(a, sh, rvec, t);
+    dpp_column<7>(a, sh, rvec, t);
+    dpp_column<8>(a, sh, rvec, t);
+    dpp_column<9>(a, sh, rvec, t);
+    dpp_column<10>(a, sh, rvec, t);
+    dpp_column<11>(a, sh, rvec, t);
+    dpp_column<12>(a, sh, rvec, t);
+    dpp_column<13>(a, sh, rvec, t);
+    dpp_column<14>(a, sh, rvec, t);
+    dpp_column<15>(a, sh, rvec, t);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) M[lane][c0 + q] = lane >= c0 + q ? a[q] : 0.0;
-    if (lane >= c0 && lane < c0 + 16) R[lane] = myr;
+    for (int q = 0; q < 16; ++q) {
+        M[lane][c0 + q] = lane >= c0 + q ? a[q] : 0.0;
+    }
+    if (lane < 16) R[c0 + lane] = rvec;
 }
 
 // first column (1-based, offset by k0) whose diagonal entry of L is not a positive number, 0 if none; call with one
@@ -220,55 +171,45 @@ __device__ __forceinline__ int block_first_bad(const double (*M)[NB + 1], int k0
 //   X_ij = -X_ii * sum_{k=j}^{i-1} L_ik X_kj
 // Block row i only needs L rows <= 16 i + 15 and X rows < 16 i, so it runs on an idle wave while wave 0 factors the
 // next panel; only the last row is left for the end.
-// x[i] -= L[i][K] * x[K] for the rows i > K of one 16 x 16 block; lane i holds L[i][K] in lcol
-template <int K, int G>
-__device__ __forceinline__ void inv_update_rows(double (&x)[16], double lcol, double xk) {
-    constexpr int first = K + 1 + G;
-    constexpr int left = 16 - first;
-    if constexpr (left > 0) {
-        constexpr int n = left >= 4 ? 4 : left;
-        constexpr int i1 = first + 1 < 16 ? first + 1 : 15, i2 = first + 2 < 16 ? first + 2 : 15,
-                      i3 = first + 3 < 16 ? first + 3 : 15;
-        fnma_bcast<first, n, false>(x[first], x[i1], x[i2], x[i3], lcol, xk);
-        inv_update_rows<K, G + 4>(x, lcol, xk);
+template <int K, int I>
+__device__ __forceinline__ void inv16_rows(double (&x)[16], double lk, double xk) {   // x[i] -= L[i][K] x[K], i > K
+    if constexpr (I < 16) {
+        fmac_bcast<I>(x[I], lk, xk);      // lane i of the DPP row holds L[i][K] in lk
+        inv16_rows<K, I + 1>(x, lk, xk);
     }
 }
-
 template <int K>
-__device__ __forceinline__ void inv_diag16_step(double (&x)[16], const double (&Lrow)[16], double Rv) {
-    x[K] *= readlane_f64(Rv, K);
-    inv_update_rows<K, 0>(x, Lrow[K], x[K]);
+__device__ __forceinline__ void inv16_step(double (&x)[16], const double (&Lrow)[16], double Rv) {
+    x[K] *= mov_bcast<K>(Rv);
+    inv16_rows<K, K + 1>(x, Lrow[K], x[K]);
 }
-
+// Column `lane & 15` of the inverse of diagonal 16 x 16 block bi, right-looking forward substitution; the block sits in
+// registers (lane t of every DPP row keeps row t) and L[i][K] reaches the FMAs as a row broadcast: 120 v_fmac_f64_dpp.
 __device__ __forceinline__ void inv_diag16(const double (*M)[NB + 1], double (*X)[NB + 1], const double *R, int bi) {
-    // Column `lane` of the inverse of one diagonal 16 x 16 block, right-looking forward substitution.  The block sits
-    // in registers (lane i keeps row i) and its entries reach the FMAs as scalars through v_readlane, like the panel
-    // factorisation: no LDS access and no accumulation chain inside the 16 dependent steps.  (Reading L[i][k] from
-    // LDS as needed, the compiler serialised ~120 load-wait-FMA triples: 2.5 us instead of ~1.)
-    const int lane = lane_id();
+    const int lane = lane_id(), t = lane & 15;
     const int o = 16 * bi;
     double Lrow[16], x[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) Lrow[q] = M[o + (lane & 15)][o + q];
-    const double Rv = R[o + (lane & 15)];
+    for (int q = 0; q < 16; ++q) Lrow[q] = M[o + t][o + q];
+    const double Rv = R[o + t];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) x[i] = (i == lane) ? 1.0 : 0.0;
-    inv_diag16_step<0>(x, Lrow, Rv);
-    inv_diag16_step<1>(x, Lrow, Rv);
-    inv_diag16_step<2>(x, Lrow, Rv);
-    inv_diag16_step<3>(x, Lrow, Rv);
-    inv_diag16_step<4>(x, Lrow, Rv);
-    inv_diag16_step<5>(x, Lrow, Rv);
-    inv_diag16_step<6>(x, Lrow, Rv);
-    inv_diag16_step<7>(x, Lrow, Rv);
-    inv_diag16_step<8>(x, Lrow, Rv);
-    inv_diag16_step<9>(x, Lrow, Rv);
-    inv_diag16_step<10>(x, Lrow, Rv);
-    inv_diag16_step<11>(x, Lrow, Rv);
-    inv_diag16_step<12>(x, Lrow, Rv);
-    inv_diag16_step<13>(x, Lrow, Rv);
-    inv_diag16_step<14>(x, Lrow, Rv);
-    inv_diag16_step<15>(x, Lrow, Rv);
+    for (int i = 0; i < 16; ++i) x[i] = (i == t) ? 1.0 : 0.0;
+    inv16_step<0>(x, Lrow, Rv);
+    inv16_step<1>(x, Lrow, Rv);
+    inv16_step<2>(x, Lrow, Rv);
+    inv16_step<3>(x, Lrow, Rv);
+    inv16_step<4>(x, Lrow, Rv);
+    inv16_step<5>(x, Lrow, Rv);
+    inv16_step<6>(x, Lrow, Rv);
+    inv16_step<7>(x, Lrow, Rv);
+    inv16_step<8>(x, Lrow, Rv);
+    inv16_step<9>(x, Lrow, Rv);
+    inv16_step<10>(x, Lrow, Rv);
+    inv16_step<11>(x, Lrow, Rv);
+    inv16_step<12>(x, Lrow, Rv);
+    inv16_step<13>(x, Lrow, Rv);
+    inv16_step<14>(x, Lrow, Rv);
+    inv16_step<15>(x, Lrow, Rv);
     if (lane < 16) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) X[o + i][o + lane] = x[i];   // zero above the diagonal by construction
@@ -304,6 +245,15 @@ __device__ __forceinline__ void inv_offdiag16(const double (*M)[NB + 1], double 
     wave_lds_sync();
 }
 
+#ifdef MM_CHOL_TRACE
+__device__ unsigned long long g_chol_trace[128][16];
+#define MM_TRACE(r, e) do { if (side == 0 && threadIdx.x == 0 && (r) < 128) g_chol_trace[r][e] = wall_clock64(); } while (0)
+#define MM_TRACE_ROW(r, e) do { if (threadIdx.x == 0 && (r) >= 0 && (r) < 128) g_chol_trace[r][e] = wall_clock64(); } while (0)
+#else
+#define MM_TRACE(r, e) do { } while (0)
+#define MM_TRACE_ROW(r, e) do { } while (0)
+#endif
+
 // L (in place, lower triangle of M), the reciprocal pivots R and the four 16 x 16 diagonal blocks of X = L^-1 (the
 // rest of X zeroed); 256 threads.  The diagonal inverses ride on an idle wave while wave 0 factors the next panel.
 // `pub` streams the block out while it is being factored (the fused kernel): pub.l(k), called by wave 2 as soon as
@@ -315,42 +265,48 @@ struct NoPub {
 };
 template <class Pub = NoPub>
 __device__ __forceinline__ void factor_block_lds(double (*M)[NB + 1], double (*X)[NB + 1], double *R, int k0, int &bad,
-                                                 Pub pub = Pub()) {
+                                                 Pub pub = Pub(), int trace_row = -1) {
     const int w = wave_id();
     if (w == 0) {
-        panel16_factor<0>(M, R);
+        panel16_factor_dpp<0>(M, X, R);
     } else {
-        for (int e = threadIdx.x - 64; e < NB * NB; e += 192) X[e / NB][e % NB] = 0.0;
+        for (int e = thread_id() - 64; e < NB * NB; e += 192) X[e / NB][e % NB] = 0.0;
     }
     __syncthreads();
+    MM_TRACE_ROW(trace_row, 10);
     panel16_update<1>(M);
-    if (w == 2) pub.l(0);   // (after the update: wave 2 is idle from here, and its store acknowledgements stay off wave 0's path)
-    if (w == 0) panel16_factor<1>(M, R);
+    MM_TRACE_ROW(trace_row, 11);
+    if (w == 2) pub.l(0);   // (after the update: wave 2 is idle from here, and its stores stay off wave 0's path)
+    if (w == 0) panel16_factor_dpp<1>(M, X, R);
     if (w == 1) {
         inv_diag16(M, X, R, 0);
         pub.x(0);
     }
     __syncthreads();
+    MM_TRACE_ROW(trace_row, 12);
     panel16_update<2>(M);
     if (w == 2) pub.l(1);
-    if (w == 0) panel16_factor<2>(M, R);
+    if (w == 0) panel16_factor_dpp<2>(M, X, R);
     if (w == 1) {
         inv_diag16(M, X, R, 1);
         pub.x(1);
     }
     __syncthreads();
+    MM_TRACE_ROW(trace_row, 13);
     panel16_update<3>(M);
+    MM_TRACE_ROW(trace_row, 14);
     if (w == 2) pub.l(2);
-    if (w == 0) panel16_factor<3>(M, R);
+    if (w == 0) {
+        panel16_factor_dpp<3>(M, X, R);
+        wave_lds_sync();
+        inv_diag16(M, X, R, 3);      // the one inverse on the chain: half a microsecond
+        pub.x(3);
+    }
     if (w == 1) {
         inv_diag16(M, X, R, 2);
         pub.x(2);
     }
     __syncthreads();
-    if (w == 0) {
-        inv_diag16(M, X, R, 3);
-        pub.x(3);
-    }
     if (w == 1) bad = block_first_bad(M, k0);
     __syncthreads();
 }
@@ -609,6 +565,14 @@ __device__ __forceinline__ void st_shared(double *p, double v) {
         *p = v;
 }
 
+// Two doubles in ONE 16-byte write-through store (p 16-byte aligned).  An 8-byte sc1 store is one fabric write per LANE:
+// publishing a 64 x 16 panel that way took longer than factoring it (guide, visibility table: "scalar sc1 stores").
+typedef double double2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st_shared16(double *p, double v0, double v1) {
+    const double2_t v = {v0, v1};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+
 // 64 x 64 tile of a published block -> LDS (zero outside the valid range); 16 coalesced 8-byte loads per thread, all
 // in flight
 template <int MODE>
@@ -750,22 +714,24 @@ __device__ __forceinline__ void trsm_finish(double (*As)[LDT], const double (*Xd
     }
     wave_lds_sync();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = row0 + lk + 4 * i, col = 16 * J + lr;
-        As[row][col] = pj[i];
-        if (t.rv(row) && t.cv(col)) st_shared<MODE>(t.at(row, col), pj[i]);
-    }
+    for (int i = 0; i < 4; ++i) As[row0 + lk + 4 * i][16 * J + lr] = pj[i];
     wave_lds_sync();
+    // to global memory from the LDS copy: two neighbouring columns per lane = one 16-byte write-through store (the
+    // accumulator layout has them in neighbouring LANES).  Reversed coordinates (side 1): the pair sits the other way round.
+    const int lane = lr + 16 * lk;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int e = lane + 64 * q, row = row0 + (e >> 3), col = 16 * J + 2 * (e & 7);
+        const double v0 = As[row][col], v1 = As[row][col + 1];
+        if (t.rv(row) && t.cv(col)) {
+            if (t.sgn > 0)
+                st_shared16(t.at(row, col), v0, v1);
+            else
+                st_shared16(t.at(row, col + 1), v1, v0);
+        }
+    }
 }
 
-#ifdef MM_CHOL_TRACE
-__device__ unsigned long long g_chol_trace[128][12];
-#define MM_TRACE(r, e) do { if (side == 0 && threadIdx.x == 0 && (r) < 128) g_chol_trace[r][e] = wall_clock64(); } while (0)
-#define MM_TRACE_ROW(r, e) do { if (threadIdx.x == 0 && (r) >= 0 && (r) < 128) g_chol_trace[r][e] = wall_clock64(); } while (0)
-#else
-#define MM_TRACE(r, e) do { } while (0)
-#define MM_TRACE_ROW(r, e) do { } while (0)
-#endif
 
 // one stage of the streamed solve (this wave's 16 rows); false: the wait was abandoned.
 // No flag: the producer's pieces land in buffers that start out as a NaN sentinel (chol_init_kernel) -- X_kk in its place
@@ -878,24 +844,20 @@ struct StagePub {
     const double (*X)[NB + 1];
     TileRef dt;
     double *Lr, *lpub;
-    __device__ __forceinline__ void l(int k) const {   // blocks (j, k), j > k: 16 (3 - k) rows x 16 columns
+    __device__ __forceinline__ void l(int k) const {   // blocks (j, k), j > k: 16 (3 - k) rows x 16 columns, 16 bytes per lane
         const int lane = lane_id();
 #pragma unroll
-        for (int q = 0; q < 12; ++q) {
-            const int e = lane + 64 * q, rr = 16 * (k + 1) + (e >> 4), cc = 16 * k + (e & 15);
-            if (q < 4 * (3 - k)) {
-                const double v = M[rr][cc];
-                __hip_atomic_store(lpub + 256 * lpub_first(k) + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (dt.rv(rr) && dt.cv(cc)) st_shared<MODE>(dt.at(rr, cc), v);      // (the copy the later kernels read)
-            }
+        for (int q = 0; q < 6; ++q) {
+            const int e = 2 * (lane + 64 * q), rr = 16 * (k + 1) + (e >> 4), cc = 16 * k + (e & 15);
+            if (q < 2 * (3 - k)) st_shared16(lpub + 256 * lpub_first(k) + e, M[rr][cc], M[rr][cc + 1]);
         }
     }
     __device__ __forceinline__ void x(int k) const {
         const int lane = lane_id();
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = lane + 64 * q, rr = 16 * k + (e >> 4), cc = 16 * k + (e & 15);
-            __hip_atomic_store(Lr + rr * NB + cc, X[rr][cc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int q = 0; q < 2; ++q) {
+            const int e = 2 * (lane + 64 * q), rr = 16 * k + (e >> 4), cc = 16 * k + (e & 15);
+            st_shared16(Lr + rr * NB + cc, X[rr][cc], X[rr][cc + 1]);
         }
     }
 };
@@ -1151,15 +1113,14 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, TwGeom 
         double *Lr = linv(side, r);
         MM_TRACE(r, 6);
         // the block streams out while it is factored: column panel k's sub-diagonal blocks, then X_kk (see trsm_stage)
-        factor_block_lds(M, X, R, 0, bad, StagePub<MODE>{M, X, dt, Lr, lpubp(side, r)});
+        factor_block_lds(M, X, R, 0, bad, StagePub<MODE>{M, X, dt, Lr, lpubp(side, r)}, side == 0 ? r : -1);
         MM_TRACE(r, 7);
         if (bad && threadIdx.x == 64) {  // `bad` = 1-based position inside the block; report the natural column
             const long col = vec_index(g, side, r, bad - 1);
             report_bad(info, (int)(col >= 0 && col < n ? col + 1 : n));
         }
-        MM_TRACE(r, 8);
-        for (int q = 0; q < 4; ++q) {  // diagonal 16 x 16 blocks of L_rr: only the later kernels read them
-            const int e = thread_id() + 256 * q, blk = e >> 8, rr = 16 * blk + ((e >> 4) & 15), cc = 16 * blk + (e & 15);
+        for (int e = thread_id(); e < NB * NB; e += 256) {  // L_rr itself: only the later kernels read it (plain stores)
+            const int rr = e / NB, cc = e % NB;
             if (dt.rv(rr) && dt.cv(cc) && cc <= rr) *dt.at(rr, cc) = M[rr][cc];
         }
         // the rest of L_rr^-1 (for the substitution kernels) is nobody's critical path
@@ -1209,7 +1170,7 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, TwGeom 
 }
 
 #ifdef MM_CHOL_TRACE
-extern "C" int mm_debug_chol_trace(unsigned long long *host /*[128*12]*/) {
+extern "C" int mm_debug_chol_trace(unsigned long long *host /*[128*16]*/) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_chol_trace), sizeof(g_chol_trace));
 }
 #endif

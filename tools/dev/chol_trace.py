@@ -21,23 +21,32 @@ for rep in range(3):
 x = v.cpu().numpy()
 print("info", int(info), "residual", np.abs(A @ x - b).max())
 raw = C.CDLL(LIB_PATH)
-buf = (C.c_ulonglong * (128 * 12))()
+buf = (C.c_ulonglong * (128 * 16))()
 assert raw.mm_debug_chol_trace(buf) == 0
-t = np.array(buf[:], dtype=np.int64).reshape(128, 12)[:, :10] * 10e-3   # 100 MHz -> us
+full = np.array(buf[:], dtype=np.int64).reshape(128, 16) * 10e-3   # 100 MHz -> us
+t = full[:, :10]
 rows = [r for r in range(128) if t[r, 9] > 0]
 t0 = t[rows, 0].min()
 # stamps: 0 row start, 1 tile products of the earlier columns done, 2 last inverse X_33 of the block above seen, 3 last
 # 16 columns of L_{r,r-1} solved, 4 streamed solve + rank-64 update done, 5 block (r, r-1) published, 6 diagonal block
 # staged, 7 factored (its last stage is out), 8 = 7, 9 row end (inverse blocks, forward substitution)
 names = ["start", "acc_done", "x33_seen", "fin3", "solved", "sub_pub", "staged", "factor", "post", "row_end"]
-print("row  " + " ".join(f"{x:>9s}" for x in names) + "   step(publish - prev publish)")
+print("row  " + " ".join(f"{x:>9s}" for x in names) + "   step(factor done - prev)")
 prev = None
 for r in rows:
     rel = t[r] - t0
-    step = "" if prev is None else f"{t[r, 8] - prev:8.2f}"
+    step = "" if prev is None else f"{t[r, 7] - prev:8.2f}"
     print(f"{r:3d}  " + " ".join(f"{x:9.2f}" for x in rel) + "   " + step)
-    prev = t[r, 8]
-d = np.diff(t[rows][:, 8])
+    prev = t[r, 7]
+d = np.diff(t[rows][:, 7])
 print("median step", np.median(d))
 seg = t[rows][:, 1:] - t[rows][:, :-1]
 print("median per-phase (us):", dict(zip(names[1:], np.round(np.median(seg[1:], 0), 2))))
+
+# inside the 64 x 64 factorisation: 10 first panel done, 11 panel 1 brought up to date, 12 panel 1 done, 13 panel 2 done,
+# 14 panel 3 brought up to date; 7 = all done
+fr = full[rows]
+inner = np.stack([fr[:, 10] - fr[:, 6], fr[:, 11] - fr[:, 10], fr[:, 12] - fr[:, 11], fr[:, 13] - fr[:, 12], fr[:, 14] - fr[:, 13],
+                  fr[:, 7] - fr[:, 14]], 1)
+print("factor phases (us, median): panel0 %.2f | update1 %.2f | panel1 %.2f | update2+panel2 %.2f | update3 %.2f | panel3 + tail %.2f"
+      % tuple(np.median(inner[1:], 0)))

@@ -46,6 +46,94 @@ __device__ __forceinline__ void column(double (&a)[16], double (&sh)[16], double
     upd<Q, Q + 1>(a, sh, sh[Q], a[Q]);
 }
 
+// LDL^T form of the same panel: the chain per column is  pivot broadcast -> v_rcp_f64 + 2 Newton steps (2 FMAs each) -> one
+// multiply -> first update -> next broadcast  (8 dependent instructions instead of 12: no square root on the chain); the
+// columns stay unscaled and are multiplied by 1 / sqrt(d_q) once at the end (one v_rsq_f64 for all 16 pivots at once).
+template <int Q, int J>
+__device__ __forceinline__ void upd_ldl(double (&a)[16], double (&sh)[16], double w) {
+    if constexpr (J < 16) {
+        fmac_bcast<J>(sh[J], w, sh[Q]);
+        fmac_bcast<J>(a[J], w, a[Q]);
+        upd_ldl<Q, J + 1>(a, sh, w);
+    }
+}
+template <int Q>
+__device__ __forceinline__ void column_ldl(double (&a)[16], double (&sh)[16], double &dvec, int t) {
+    const double d = mov_bcast<Q>(sh[Q]);
+    double y = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-d, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    dvec = t == Q ? d : dvec;
+    double w = sh[Q] * y;
+    asm volatile("s_nop 1" : "+v"(w));   // DPP read of a VGPR written by the previous VALU: 2 wait states
+    upd_ldl<Q, Q + 1>(a, sh, w);
+}
+template <int Q>
+__device__ __forceinline__ void scale_col(double (&a)[16], double rvec) {
+    a[Q] *= mov_bcast<Q>(rvec);
+}
+
+__global__ void panel_ldl_kernel(const double *A, const double *D, int c0, double *Lout, double *Xt, double *R, unsigned long long *ticks,
+                                 int reps) {
+    const int lane = threadIdx.x, t = lane & 15;
+    double a[16], sh[16], dvec = 1.0, rvec = 0.0;
+    unsigned long long t0 = 0, t1 = 0;
+    for (int rep = 0; rep < reps; ++rep) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            a[q] = lane >= c0 ? (lane >= c0 + q ? A[lane * 16 + q] : 0.0) : (lane < 16 && c0 >= 16 ? (q == lane ? 1.0 : 0.0) : 0.0);
+            sh[q] = t >= q ? D[t * 16 + q] : 0.0;
+        }
+        if (rep == 1) t0 = wall_clock64();
+        column_ldl<0>(a, sh, dvec, t);
+        column_ldl<1>(a, sh, dvec, t);
+        column_ldl<2>(a, sh, dvec, t);
+        column_ldl<3>(a, sh, dvec, t);
+        column_ldl<4>(a, sh, dvec, t);
+        column_ldl<5>(a, sh, dvec, t);
+        column_ldl<6>(a, sh, dvec, t);
+        column_ldl<7>(a, sh, dvec, t);
+        column_ldl<8>(a, sh, dvec, t);
+        column_ldl<9>(a, sh, dvec, t);
+        column_ldl<10>(a, sh, dvec, t);
+        column_ldl<11>(a, sh, dvec, t);
+        column_ldl<12>(a, sh, dvec, t);
+        column_ldl<13>(a, sh, dvec, t);
+        column_ldl<14>(a, sh, dvec, t);
+        column_ldl<15>(a, sh, dvec, t);
+        rvec = __builtin_amdgcn_rsq(dvec);
+        rvec = rvec * (1.5 - 0.5 * dvec * rvec * rvec);
+        rvec = rvec * (1.5 - 0.5 * dvec * rvec * rvec);
+        scale_col<0>(a, rvec);
+        scale_col<1>(a, rvec);
+        scale_col<2>(a, rvec);
+        scale_col<3>(a, rvec);
+        scale_col<4>(a, rvec);
+        scale_col<5>(a, rvec);
+        scale_col<6>(a, rvec);
+        scale_col<7>(a, rvec);
+        scale_col<8>(a, rvec);
+        scale_col<9>(a, rvec);
+        scale_col<10>(a, rvec);
+        scale_col<11>(a, rvec);
+        scale_col<12>(a, rvec);
+        scale_col<13>(a, rvec);
+        scale_col<14>(a, rvec);
+        scale_col<15>(a, rvec);
+        asm volatile("" ::"v"(a[15]), "v"(sh[15]));
+    }
+    t1 = wall_clock64();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        Lout[lane * 16 + q] = a[q];
+        if (lane < 16) Xt[lane * 16 + q] = a[q];
+    }
+    if (lane < 16) R[lane] = rvec;
+    if (lane == 0) ticks[0] = t1 - t0;
+}
+
 // A [64][16] panel (row-major, rows >= c0 meaningful), D [16][16] diagonal block; out: L panel [64][16], Xt [16][16] (lane t,
 // column q = X[q][t]) from the identity rows in lanes 0..15 (c0 >= 16)
 __global__ void panel_kernel(const double *A, const double *D, int c0, double *Lout, double *Xt, double *R, unsigned long long *ticks,
@@ -124,7 +212,12 @@ int main() {
     hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice);
     hipMemcpy(dD, D.data(), D.size() * 8, hipMemcpyHostToDevice);
     const int reps = 101;
-    hipLaunchKernelGGL(panel_kernel, dim3(1), dim3(64), 0, 0, dA, dD, c0, dL, dX, dR, dT, reps);
+    int rc_all = 0;
+    for (int variant = 0; variant < 2; ++variant) {
+    if (variant == 0)
+        hipLaunchKernelGGL(panel_kernel, dim3(1), dim3(64), 0, 0, dA, dD, c0, dL, dX, dR, dT, reps);
+    else
+        hipLaunchKernelGGL(panel_ldl_kernel, dim3(1), dim3(64), 0, 0, dA, dD, c0, dL, dX, dR, dT, reps);
     if (hipDeviceSynchronize() != hipSuccess) {
         printf("kernel failed\n");
         return 1;
@@ -145,7 +238,9 @@ int main() {
             for (int q = 0; q <= i; ++q) s += Lr[(c0 + i) * 16 + q] * X[t * 16 + q];
             errx = fmax(errx, fabs(s - (i == t ? 1.0 : 0.0)));
         }
-    printf("panel_dpp: max |L - ref| = %.3e, max |L X - I| = %.3e, %.3f us per 64x16 panel (100 MHz clock, %d reps)\n", err, errx,
-           ticks * 0.01 / (reps - 1), reps - 1);
-    return err < 1e-12 && errx < 1e-12 ? 0 : 2;
+    printf("panel_dpp (%s): max |L - ref| = %.3e, max |L X - I| = %.3e, %.3f us per 64x16 panel (100 MHz clock, %d reps)\n",
+           variant == 0 ? "L L^T, rsq on the chain" : "L D L^T, rcp on the chain, scaled at the end", err, errx, ticks * 0.01 / (reps - 1), reps - 1);
+    if (!(err < 1e-12 && errx < 1e-12)) rc_all = 2;
+    }
+    return rc_all;
 }
