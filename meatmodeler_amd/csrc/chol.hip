@@ -19,6 +19,7 @@
 // D reg i of lane l -> D[(l>>4) + 4 i][l&15].
 #include "mm_common.h"
 #include <atomic>
+#include <type_traits>
 #include <cstdlib>
 
 namespace {
@@ -246,8 +247,8 @@ __device__ __forceinline__ void inv_offdiag16(const double (*M)[NB + 1], double 
 }
 
 #ifdef MM_CHOL_TRACE
-__device__ unsigned long long g_chol_trace[128][16];
-#define MM_TRACE(r, e) do { if (side == 0 && threadIdx.x == 0 && (r) < 128) g_chol_trace[r][e] = wall_clock64(); } while (0)
+__device__ unsigned long long g_chol_trace[128][32];
+#define MM_TRACE(r, e) do { if (side < 2 && threadIdx.x == 0 && (r) < 64) g_chol_trace[64 * side + (r)][e] = wall_clock64(); } while (0)
 #define MM_TRACE_ROW(r, e) do { if (threadIdx.x == 0 && (r) >= 0 && (r) < 128) g_chol_trace[r][e] = wall_clock64(); } while (0)
 #else
 #define MM_TRACE(r, e) do { } while (0)
@@ -262,6 +263,9 @@ __device__ unsigned long long g_chol_trace[128][16];
 struct NoPub {
     __device__ void l(int) const {}
     __device__ void x(int) const {}
+    __device__ void bulk(int) const {}
+    __device__ void drain() const {}
+    __device__ void raise_sub_flag() const {}
 };
 template <class Pub = NoPub>
 __device__ __forceinline__ void factor_block_lds(double (*M)[NB + 1], double (*X)[NB + 1], double *R, int k0, int &bad,
@@ -277,6 +281,10 @@ __device__ __forceinline__ void factor_block_lds(double (*M)[NB + 1], double (*X
     panel16_update<1>(M);
     MM_TRACE_ROW(trace_row, 11);
     if (w == 2) pub.l(0);   // (after the update: wave 2 is idle from here, and its stores stay off wave 0's path)
+    if (w == 3) {
+        pub.bulk(0);
+        pub.bulk(1);
+    }
     if (w == 0) panel16_factor_dpp<1>(M, X, R);
     if (w == 1) {
         inv_diag16(M, X, R, 0);
@@ -286,6 +294,7 @@ __device__ __forceinline__ void factor_block_lds(double (*M)[NB + 1], double (*X
     MM_TRACE_ROW(trace_row, 12);
     panel16_update<2>(M);
     if (w == 2) pub.l(1);
+    if (w == 3) pub.bulk(2);
     if (w == 0) panel16_factor_dpp<2>(M, X, R);
     if (w == 1) {
         inv_diag16(M, X, R, 1);
@@ -295,6 +304,10 @@ __device__ __forceinline__ void factor_block_lds(double (*M)[NB + 1], double (*X
     MM_TRACE_ROW(trace_row, 13);
     panel16_update<3>(M);
     MM_TRACE_ROW(trace_row, 14);
+    if (w == 3) {      // (only wave 3 has stored the copy: its own drain suffices)
+        pub.drain();
+        pub.raise_sub_flag();
+    }
     if (w == 2) pub.l(2);
     if (w == 0) {
         panel16_factor_dpp<3>(M, X, R);
@@ -500,7 +513,7 @@ __global__ __launch_bounds__(256) void chol_update_kernel(double *__restrict__ A
 // identity rows -- the same trick as the partial last block of the one-ended scheme.
 constexpr long SPIN_LIMIT = 1L << 23;
 constexpr int FUSED_MAX_BWB = 15;  // 16 + 105 = 121 resident workgroups per side at most
-constexpr size_t FUSED_LDS_BYTES = (size_t)(2 * NB * LDT + 4 * 16 * 17 + 3 * NB) * sizeof(double);
+constexpr size_t FUSED_LDS_BYTES = (size_t)(4 * NB * LDT + 4 * 16 * 17 + 3 * NB) * sizeof(double);   // 146 KB of the CU's 160
 
 struct TwGeom {
     int n, nblk, bwb;
@@ -588,6 +601,41 @@ __device__ __forceinline__ void load_tile_shared(double (*T)[LDT], const TileRef
     for (int q = 0; q < 16; ++q) {
         const int e = thread_id() + 256 * q;
         T[e / NB][e % NB] = v[q];
+    }
+}
+
+// LDS tile -> its place in A, 16-byte write-through stores (8 per thread); reversed coordinates: pairs the other way round
+__device__ __forceinline__ void store_tile_shared16(const double (*T)[LDT], const TileRef &t) {
+    const int tid = thread_id();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int e = tid + 256 * q, row = e >> 5, col = 2 * (e & 31);
+        if (t.rv(row) && t.cv(col)) {
+            if (t.sgn > 0)
+                st_shared16(t.at(row, col), T[row][col], T[row][col + 1]);
+            else
+                st_shared16(t.at(row, col + 1), T[row][col + 1], T[row][col]);
+        }
+    }
+}
+
+// the same in two halves: request into registers (several tiles may be in flight), commit later (tile_commit)
+template <int MODE>
+__device__ __forceinline__ void tile_prefetch_shared(double (&pre)[16], const TileRef &t) {
+    const int tid = thread_id();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int e = tid + 256 * q;
+        const int r = e / NB, c = e % NB;
+        pre[q] = (t.rv(r) && t.cv(c)) ? ld_shared<MODE>(t.at(r, c)) : 0.0;
+    }
+}
+
+__device__ __forceinline__ void tile_commit(double (*T)[LDT], const double (&pre)[16]) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int e = thread_id() + 256 * q;
+        T[e / NB][e % NB] = pre[q];
     }
 }
 
@@ -704,7 +752,7 @@ __device__ __forceinline__ void trsm_update(double (*As)[LDT], const double (*Bs
 // P_j = W_j X_jj^T: block j of As in place, and to global memory
 template <int MODE, int J>
 __device__ __forceinline__ void trsm_finish(double (*As)[LDT], const double (*Xd)[16][17], const TileRef &t, int row0,
-                                            int lr, int lk) {
+                                            int lr, int lk, double *spub_blk) {
     double4_t pj = {0, 0, 0, 0};
 #pragma unroll
     for (int ss = 0; ss < 4; ++ss) {
@@ -723,7 +771,13 @@ __device__ __forceinline__ void trsm_finish(double (*As)[LDT], const double (*Xd
     for (int q = 0; q < 2; ++q) {
         const int e = lane + 64 * q, row = row0 + (e >> 3), col = 16 * J + 2 * (e & 7);
         const double v0 = As[row][col], v1 = As[row][col + 1];
-        if (t.rv(row) && t.cv(col)) {
+        // Blocks that sit on the critical chain (block (r, r - 1) of a row head, the offset-2 block below it) go into the
+        // polled hand-over buffer, in this side's own orientation, padding rows included: the next row head multiplies with
+        // them panel by panel.  A write-through store takes microseconds to land and they queue behind each other, so
+        // NOTHING else is stored here for such a block: its copy in A follows after the solve (store_tile_shared16).
+        if (spub_blk) {
+            st_shared16(spub_blk + row * NB + col, v0, v1);
+        } else if (t.rv(row) && t.cv(col)) {
             if (t.sgn > 0)
                 st_shared16(t.at(row, col), v0, v1);
             else
@@ -733,7 +787,7 @@ __device__ __forceinline__ void trsm_finish(double (*As)[LDT], const double (*Xd
 }
 
 
-// one stage of the streamed solve (this wave's 16 rows); false: the wait was abandoned.
+// The streamed solve, stage by stage (this wave's 16 rows).
 // No flag: the producer's pieces land in buffers that start out as a NaN sentinel (chol_init_kernel) -- X_kk in its place
 // inside L_cc^-1, the blocks L_jk in the hand-over buffer `lpub` -- and every lane polls the very values it needs, so a
 // hand-over costs one trip to memory instead of store-acknowledge + flag + load (the backward kernel's trick).
@@ -741,54 +795,105 @@ constexpr unsigned long long STAGE_SENTINEL = ~0ull;
 constexpr int LPUB_BLOCK = 6 * 256;      // doubles per diagonal block: (1,0) (2,0) (3,0) | (2,1) (3,1) | (3,2), 16 x 16 row-major
 __device__ __forceinline__ constexpr int lpub_first(int k) { return k == 0 ? 0 : (k == 1 ? 3 : 5); }
 
-template <int MODE, int K>
-__device__ __forceinline__ bool trsm_stage(double (*As)[LDT], double (*Bs)[LDT], double (*Xd)[16][17], const double *lpub_c,
-                                           const double *Linv_c, int32_t *abort_flag, const TileRef &t, int trace_row) {
-    const int lane = lane_id(), row0 = 16 * wave_id();
-    const int lr = lane & 15, lk = lane >> 4;
-    constexpr int NL = K < 3 ? 4 * (3 - K) : 0;
-    double lv[NL > 0 ? NL : 1], xv[4];
-    bool ok = false;
+// Poll one word per lane (lanes may watch different words; `watch` = lanes that count) until none is the sentinel, with FOUR
+// polls in flight: a poll that has to return before the next one is issued samples the word once per trip to memory
+// (1-2 us under load), and half of that on average is pure detection latency on the critical chain.  Bounded; false: abandoned.
+__device__ __forceinline__ bool poll_words_pipelined(const double *p, unsigned long long watch, int32_t *abort_flag) {
+    auto ld = [&]() { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto there = [&](double v) {
+        return !(__builtin_amdgcn_ballot_w64((unsigned long long)__double_as_longlong(v) == STAGE_SENTINEL) & watch);
+    };
+    double c0 = ld();
+    __builtin_amdgcn_s_sleep(2);
+    double c1 = ld();
+    __builtin_amdgcn_s_sleep(2);
+    double c2 = ld();
+    __builtin_amdgcn_s_sleep(2);
+    double c3 = ld();
     for (long it = 0; it < SPIN_LIMIT; ++it) {
-        bool missing = false;
-#pragma unroll
-        for (int q = 0; q < NL; ++q) {
-            lv[q] = __hip_atomic_load(lpub_c + 256 * lpub_first(K) + lane + 64 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            missing |= (unsigned long long)__double_as_longlong(lv[q]) == STAGE_SENTINEL;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = lane + 64 * q;
-            xv[q] = __hip_atomic_load(Linv_c + (size_t)(16 * K + (e >> 4)) * NB + 16 * K + (e & 15), __ATOMIC_RELAXED,
-                                      __HIP_MEMORY_SCOPE_AGENT);
-            missing |= (unsigned long long)__double_as_longlong(xv[q]) == STAGE_SENTINEL;
-        }
-        if (!__builtin_amdgcn_ballot_w64(missing)) {
-            ok = true;
-            break;
-        }
-        if ((it & 63) == 63 && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-        __builtin_amdgcn_s_sleep(1);
+        if (there(c0)) return true;
+        c0 = ld();
+        if (there(c1)) return true;
+        c1 = ld();
+        if (there(c2)) return true;
+        c2 = ld();
+        if (there(c3)) return true;
+        c3 = ld();
+        if ((it & 63) == 63 && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
     }
-    if (!ok) __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (K == 3) MM_TRACE_ROW(trace_row, 2);
+    __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return false;
+}
+
+// registers of one stage: the blocks L_jK (j > K) this wave multiplies with, and X_KK
+template <int K>
+struct StageRegs {
+    static constexpr int NL = K < 3 ? 4 * (3 - K) : 0;
+    double lv[NL > 0 ? NL : 1], xv[4];
+};
+// one attempt: issue the loads of stage K (every lane the very values it will use)
+template <int K>
+__device__ __forceinline__ void stage_issue(StageRegs<K> &g, const double *lpub_c, const double *Linv_c, int lane) {
 #pragma unroll
-    for (int q = 0; q < NL; ++q) {
+    for (int q = 0; q < StageRegs<K>::NL; ++q)
+        g.lv[q] = __hip_atomic_load(lpub_c + 256 * lpub_first(K) + lane + 64 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
         const int e = lane + 64 * q;
-        Bs[16 * (K + 1) + (e >> 4)][16 * K + (e & 15)] = lv[q];
+        g.xv[q] = __hip_atomic_load(Linv_c + (size_t)(16 * K + (e >> 4)) * NB + 16 * K + (e & 15), __ATOMIC_RELAXED,
+                                    __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+template <int K>
+__device__ __forceinline__ bool stage_complete(const StageRegs<K> &g) {      // wave-uniform
+    bool missing = false;
+#pragma unroll
+    for (int q = 0; q < StageRegs<K>::NL; ++q) missing |= (unsigned long long)__double_as_longlong(g.lv[q]) == STAGE_SENTINEL;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) missing |= (unsigned long long)__double_as_longlong(g.xv[q]) == STAGE_SENTINEL;
+    return !__builtin_amdgcn_ballot_w64(missing);
+}
+// Wait until stage K is there (bounded); false: abandoned.  Polling the whole stage (16 loads per lane, four waves per
+// consumer, ten consumers per diagonal block) floods the memory queues the producer's stores travel through: while
+// something is missing only TWO words are polled -- the last element each of the producer's two publishing waves
+// stores for this stage (the corner of block (3, K), X_KK[15][15]) -- and the stage is loaded and checked once they
+// are there (the check stays: stores of one wave may land in any order).
+template <int K>
+__device__ __forceinline__ bool stage_wait(StageRegs<K> &g, const double *lpub_c, const double *Linv_c, int lane,
+                                           int32_t *abort_flag) {
+    if (stage_complete<K>(g)) return true;
+    // two words tell that the stage is (about to be) there: the last element each of the producer's two publishing waves
+    // stores for it -- the corner of block (3, K) and X_KK[15][15]; even lanes watch the one, odd lanes the other
+    const double *canary_x = Linv_c + (size_t)(16 * K + 15) * NB + 16 * K + 15;
+    const double *canary_l = K < 3 ? lpub_c + 256 * (lpub_first(K) + (2 - K)) + 255 : canary_x;
+    for (int attempt = 0; attempt < 64; ++attempt) {
+        if (!poll_words_pipelined((lane & 1) ? canary_l : canary_x, 3ull, abort_flag)) return false;
+        stage_issue<K>(g, lpub_c, Linv_c, lane);
+        if (stage_complete<K>(g)) return true;      // (almost always: the check stays because stores of one wave may land in any order)
+    }
+    __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return false;
+}
+// stage K of the solve on this wave's 16 rows, its operands in registers
+template <int MODE, int K>
+__device__ __forceinline__ void stage_compute(const StageRegs<K> &g, double (*As)[LDT], double (*Bs)[LDT], double (*Xd)[16][17],
+                                              const TileRef &t, double *spub_blk, int lane, int row0) {
+    const int lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int q = 0; q < StageRegs<K>::NL; ++q) {
+        const int e = lane + 64 * q;
+        Bs[16 * (K + 1) + (e >> 4)][16 * K + (e & 15)] = g.lv[q];
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int e = lane + 64 * q;
-        Xd[K][e >> 4][e & 15] = xv[q];
+        Xd[K][e >> 4][e & 15] = g.xv[q];
     }
     wave_lds_sync();
-    trsm_finish<MODE, K>(As, Xd, t, row0, lr, lk);
-    if (K == 3) MM_TRACE_ROW(trace_row, 3);
+    trsm_finish<MODE, K>(As, Xd, t, row0, lr, lk, spub_blk);
     if constexpr (K < 1) trsm_update<1, K, K + 1>(As, Bs, row0, lr, lk);
     if constexpr (K < 2) trsm_update<2, K, K + 1>(As, Bs, row0, lr, lk);
     if constexpr (K < 3) trsm_update<3, K, K + 1>(As, Bs, row0, lr, lk);
-    return ok;
 }
 
 // acc += P_K P_K^T (columns 16K .. 16K+15 of As, all 64 rows: call after a workgroup barrier), tile_gemm_nt layout
@@ -809,31 +914,156 @@ __device__ __forceinline__ void syrk_slice(const double (*As)[LDT], double4_t (&
     }
 }
 
-// The whole streamed solve of one off-diagonal block; V must be staged in As behind a workgroup barrier.  SYRK: also
-// acc += P P^T (the owner of the diagonal block of the same row).  Returns false (uniformly) if a wait was abandoned.
+// The whole streamed solve of one off-diagonal block; V must be staged in As behind a workgroup barrier.  The loads of
+// stage K + 1 are in flight while stage K computes (one attempt; whatever is still the sentinel is polled afterwards).
+// SYRK (the owner of the diagonal block of the same row): also acc += P P^T -- the first three 16-column slices while the
+// last stage is awaited, so that only 16 MFMAs of it follow the last stage.  spub_blk: see trsm_finish.  Returns false
+// (uniformly) if a wait was abandoned.
 template <int MODE, bool SYRK>
 __device__ __forceinline__ bool finish_off_block_streamed(double (*As)[LDT], double (*Bs)[LDT], double (*Xd)[16][17],
                                                           const double *lpub_c, const double *Linv_c, int32_t *abort_flag,
-                                                          const TileRef &t, double4_t (&acc)[2][2], int trace_row = -1) {
-    bool ok = trsm_stage<MODE, 0>(As, Bs, Xd, lpub_c, Linv_c, abort_flag, t, trace_row);
+                                                          const TileRef &t, double4_t (&acc)[2][2], double *spub_blk,
+                                                          int trace_row = -1) {
+    const int lane = lane_id(), row0 = 16 * wave_id();
+    StageRegs<0> g0;
+    StageRegs<1> g1;
+    StageRegs<2> g2;
+    StageRegs<3> g3;
+    stage_issue<0>(g0, lpub_c, Linv_c, lane);
+    bool ok = stage_wait<0>(g0, lpub_c, Linv_c, lane, abort_flag);
+    stage_issue<1>(g1, lpub_c, Linv_c, lane);
+    stage_compute<MODE, 0>(g0, As, Bs, Xd, t, spub_blk, lane, row0);
+    ok = stage_wait<1>(g1, lpub_c, Linv_c, lane, abort_flag) && ok;
+    stage_issue<2>(g2, lpub_c, Linv_c, lane);
+    stage_compute<MODE, 1>(g1, As, Bs, Xd, t, spub_blk, lane, row0);
+    ok = stage_wait<2>(g2, lpub_c, Linv_c, lane, abort_flag) && ok;
+    stage_issue<3>(g3, lpub_c, Linv_c, lane);
+    stage_compute<MODE, 2>(g2, As, Bs, Xd, t, spub_blk, lane, row0);
     if constexpr (SYRK) {
-        __syncthreads();
+        __syncthreads();      // P_0 .. P_2 of all four waves
         syrk_slice<0>(As, acc);
-    }
-    ok = trsm_stage<MODE, 1>(As, Bs, Xd, lpub_c, Linv_c, abort_flag, t, trace_row) && ok;
-    if constexpr (SYRK) {
-        __syncthreads();
         syrk_slice<1>(As, acc);
-    }
-    ok = trsm_stage<MODE, 2>(As, Bs, Xd, lpub_c, Linv_c, abort_flag, t, trace_row) && ok;
-    if constexpr (SYRK) {
-        __syncthreads();
         syrk_slice<2>(As, acc);
     }
-    ok = trsm_stage<MODE, 3>(As, Bs, Xd, lpub_c, Linv_c, abort_flag, t, trace_row) && ok;
+    ok = stage_wait<3>(g3, lpub_c, Linv_c, lane, abort_flag) && ok;
+    MM_TRACE_ROW(trace_row, 2);
+    stage_compute<MODE, 3>(g3, As, Bs, Xd, t, spub_blk, lane, row0);
+    MM_TRACE_ROW(trace_row, 3);
     const bool all_ok = !__syncthreads_or(!ok);
     if constexpr (SYRK) syrk_slice<3>(As, acc);
     return all_ok;
+}
+
+// Polled loads from the sub-diagonal hand-over buffer (block (r, r - 1) of row head r, written 16 columns at a time by
+// trsm_finish): a whole 64 x 64 tile, or one 16-column panel of it, into an LDS tile; 256 threads, bounded.  Returns false
+// (uniformly) if the wait was abandoned.
+__device__ __forceinline__ bool load_tile_polled(double (*T)[LDT], const double *blk, int32_t *abort_flag) {
+    const int tid = thread_id();
+    double v[16];
+    bool ok = false;
+    for (long it = 0; it < SPIN_LIMIT; ++it) {
+        bool missing = false;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            v[q] = __hip_atomic_load(blk + tid + 256 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            missing |= (unsigned long long)__double_as_longlong(v[q]) == STAGE_SENTINEL;
+        }
+        if (!__builtin_amdgcn_ballot_w64(missing)) {
+            ok = true;
+            break;
+        }
+        if ((it & 63) == 63 && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    if (!ok) __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int e = tid + 256 * q;
+        T[e / NB][e % NB] = v[q];
+    }
+    return !__syncthreads_or(!ok);
+}
+// One 16-column panel of TWO blocks at once (blk_b may be null), pipelined: the loads of panel K + 1 are in flight while the
+// products with panel K run.  issue: one attempt; wait: if something is still the sentinel, wave 0 polls the four (eight)
+// words each writing wave stores LAST for this panel (row 16 w + 15, column 16 K + 15) while the others sit at a
+// barrier -- polling whole panels with 256 threads floods the queues the producers' stores travel through -- then the
+// panel is loaded again and checked (the check stays: stores of one wave may land in any order); commit: to LDS.
+struct PanelPair {
+    double va[4], vb[4];
+};
+template <int K>
+__device__ __forceinline__ void panels_issue(PanelPair &g, const double *blk_a, const double *blk_b, int /*tid*/) {
+    const int tid = thread_id();      // (opaque: keeps the offsets next to the loads, see lane_id())
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = tid + 256 * q, off = (e >> 4) * NB + 16 * K + (e & 15);
+        g.va[q] = __hip_atomic_load(blk_a + off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        g.vb[q] = blk_b ? __hip_atomic_load(blk_b + off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    }
+}
+template <int K>
+__device__ __forceinline__ bool panels_wait(PanelPair &g, const double *blk_a, const double *blk_b, int tid, int32_t *abort_flag,
+                                            int trace_row = -1) {
+#ifdef MM_CHOL_TRACE
+    bool seen_a = false, seen_b = false;
+#endif
+    for (long round = 0; round < SPIN_LIMIT; ++round) {
+#ifdef MM_CHOL_TRACE
+        if (K == 3 && trace_row >= 0) {
+            bool ma = false, mb = false;
+            for (int q = 0; q < 4; ++q) {
+                ma |= (unsigned long long)__double_as_longlong(g.va[q]) == STAGE_SENTINEL;
+                mb |= (unsigned long long)__double_as_longlong(g.vb[q]) == STAGE_SENTINEL;
+            }
+            if (!__syncthreads_or(ma) && !seen_a) { seen_a = true; MM_TRACE_ROW(trace_row, 22); }
+            if (!__syncthreads_or(mb) && !seen_b) { seen_b = true; MM_TRACE_ROW(trace_row, 23); }
+        }
+#endif
+        bool missing = false;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            missing |= (unsigned long long)__double_as_longlong(g.va[q]) == STAGE_SENTINEL ||
+                       (unsigned long long)__double_as_longlong(g.vb[q]) == STAGE_SENTINEL;
+        if (!__syncthreads_or(missing)) return true;
+        bool dead = false;
+        if (wave_id() == 0) {
+            const int lane = lane_id();
+            const double *cp = ((lane & 4) && blk_b ? blk_b : blk_a) + (size_t)(16 * (lane & 3) + 15) * NB + 16 * K + 15;
+            dead = !poll_words_pipelined(cp, blk_b ? 0xFFull : 0x0Full, abort_flag);
+        }
+        if (__syncthreads_or(dead)) break;
+        panels_issue<K>(g, blk_a, blk_b, tid);
+    }
+    __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return false;
+}
+template <int K>
+__device__ __forceinline__ void panels_commit(const PanelPair &g, double (*Ta)[LDT], double (*Tb)[LDT], bool have_b, int /*tid*/) {
+    const int tid = thread_id();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = tid + 256 * q;
+        Ta[e >> 4][16 * K + (e & 15)] = g.va[q];
+        if (have_b) Tb[e >> 4][16 * K + (e & 15)] = g.vb[q];
+    }
+    __syncthreads();
+}
+// acc += As[:, 16K .. 16K+15] * Bs[:, 16K .. 16K+15]^T (one 16-column slice of tile_gemm_nt)
+template <int K>
+__device__ __forceinline__ void gemm_slice(const double (*As)[LDT], const double (*Bs)[LDT], double4_t (&acc)[2][2]) {
+    const int lane = lane_id(), w = wave_id();
+    const int r0 = (w >> 1) * 32, c0 = (w & 1) * 32;
+    const int lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int ks = 4 * K; ks < 4 * K + 4; ++ks) {
+        const int k = ks * 4 + lk;
+        double a0 = As[r0 + lr][k], a1 = As[r0 + 16 + lr][k];
+        double b0 = Bs[c0 + lr][k], b1 = Bs[c0 + 16 + lr][k];
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
 }
 
 // producer side of the streamed hand-over (factor_block_lds calls l(k) on wave 2, x(k) on the wave that inverted
@@ -844,6 +1074,30 @@ struct StagePub {
     const double (*X)[NB + 1];
     TileRef dt;
     double *Lr, *lpub;
+    int32_t *sub_flag;      // flag of block (r, r - 1), raised once every wave's stores of it have landed (may be null)
+    const double (*Ss)[LDT];   // L_{r,r-1} in LDS, st its place in A
+    TileRef st;
+    // wave 3 (idle throughout) beside the first three panels, a third each: the copy of L_{r,r-1} in A (what the
+    // pre-accumulators and the later kernels read), 16-byte write-through stores, eleven per lane and panel
+    __device__ __forceinline__ void bulk(int part) const {
+        if (!sub_flag) return;
+        const int lane = lane_id();
+        for (int q = 11 * part; q < 11 * part + 11 && q < 32; ++q) {
+            const int e = lane + 64 * q, row = e >> 5, col = 2 * (e & 31);
+            if (st.rv(row) && st.cv(col)) {
+                if (st.sgn > 0)
+                    st_shared16(st.at(row, col), Ss[row][col], Ss[row][col + 1]);
+                else
+                    st_shared16(st.at(row, col + 1), Ss[row][col + 1], Ss[row][col]);
+            }
+        }
+    }
+    __device__ __forceinline__ void drain() const {      // every wave, two panels later: its stores are long acknowledged
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __device__ __forceinline__ void raise_sub_flag() const {      // one wave, one barrier after drain()
+        if (sub_flag && lane_id() == 0) __hip_atomic_store(sub_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     __device__ __forceinline__ void l(int k) const {   // blocks (j, k), j > k: 16 (3 - k) rows x 16 columns, 16 bytes per lane
         const int lane = lane_id();
 #pragma unroll
@@ -882,8 +1136,8 @@ template <int MODE>
 __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, TwGeom g, double *Linv,
                                                               int32_t *__restrict__ flags, int32_t *__restrict__ info,
                                                               const double *b_fwd, double *y,
-                                                              double *contrib, double *lpub, const int32_t *slab_ready,
-                                                              int cams_per_slab, int n_cams) {
+                                                              double *contrib, double *lpub, double *spub,
+                                                              const int32_t *slab_ready, int cams_per_slab, int n_cams) {
     // these waves form a latency chain; when the reduced system is being built by a concurrent launch they share their
     // SIMDs with its waves, so ask the instruction arbiter to prefer them
     __builtin_amdgcn_s_setprio(3);
@@ -895,6 +1149,9 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, TwGeom 
     double (*T)[16][17] = reinterpret_cast<double (*)[16][17]>(smem + 2 * NB * LDT);
     double *R = smem + 2 * NB * LDT + 4 * 16 * 17;
     double *ys = R + NB, *rhs = R + 2 * NB;
+    // a row head parks its own two tiles of A here (fetched while it waits for the last column; 64 registers otherwise)
+    double (*Ds)[LDT] = reinterpret_cast<double (*)[LDT]>(smem + 2 * NB * LDT + 4 * 16 * 17 + 3 * NB);
+    double (*Ss)[LDT] = reinterpret_cast<double (*)[LDT]>(smem + 3 * NB * LDT + 4 * 16 * 17 + 3 * NB);
     __shared__ int s_ok;
     const int bwb = g.bwb, W = bwb + 1, nblk = g.nblk, n = g.n;
     const int G = W + bwb * (bwb - 1) / 2;  // workgroups per side
@@ -914,6 +1171,11 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, TwGeom 
     auto cslot = [&](int s, int r, int d) { return contrib + (((size_t)s * nblk + r) * W + d) * NB; };
     auto linv = [&](int s, int blk) { return Linv + (size_t)nat(s, blk) * NB * NB; };
     auto lpubp = [&](int s, int blk) { return lpub + (size_t)nat(s, blk) * LPUB_BLOCK; };
+    // polled copies of the blocks (blk, blk - 1) and (blk, blk - 2) of the rows that HAVE a row head on their side (blk <
+    // ncols: natural indices are disjoint between the sides then; the rows of M in side 1's numbering have none, their
+    // blocks go through A and flags only)
+    auto spubp = [&](int s, int blk) { return spub + (size_t)nat(s, blk) * NB * NB; };
+    auto spub2p = [&](int s, int blk) { return spub + ((size_t)nblk + nat(s, blk)) * NB * NB; };
     // Entries of A (and of the right-hand side) may still be under construction by a concurrent launch on another
     // stream (the reduced camera system, built in camera slabs).  The entries (i, j) and (j, i), i >= j, are written
     // together with camera row i / 6: a tile is complete when the slabs of its LARGER natural block index are
@@ -923,7 +1185,7 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, TwGeom 
         const int s_lo = (NB * q / 6) / cams_per_slab, s_hi = min(n_cams - 1, (NB * q + NB - 1) / 6) / cams_per_slab;
         return wg_wait<MODE>(slab_ready + s_lo, s_hi != s_lo ? slab_ready + s_hi : nullptr, abort_flag, &s_ok);
     };
-    double4_t acc[2][2], a0[2][2];
+    double4_t acc[2][2];
     if (side == 2) {
         // Pre-accumulator of one block (r, c) of M x M.  What the columns of T and of the other end contribute to it
         // is known long before the elimination reaches M, but its owner on side 0 walks its blocks in column order and
@@ -988,10 +1250,16 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, TwGeom 
             // a block of M x M: the columns of T and of the other end have been taken care of by its pre-accumulator
             const bool in_m = tw && side == 0 && c >= g.a;
             for (int k = max(in_m ? g.a : 0, r - bwb); k < c; ++k) {
-                if (!wg_wait<MODE>(flag(fb, r, r - k), flag(fb, c, c - k), abort_flag, &s_ok)) MM_FUSED_ABANDON;
+                // (c, k): for k = c - 1 the block of row head c -- its flag is raised late, off that workgroup's critical
+                // path; the data itself is polled
+                if (!wg_wait<MODE>(flag(fb, r, r - k), c - k > 1 ? flag(fb, c, c - k) : nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
                 load_tile_shared<MODE>(As, tile_ref(A, g, side, r, k));
-                load_tile_shared<MODE>(Bs, tile_ref(A, g, side, c, k));
-                __syncthreads();
+                if (c - k > 1) {
+                    load_tile_shared<MODE>(Bs, tile_ref(A, g, side, c, k));
+                    __syncthreads();
+                } else if (!load_tile_polled(Bs, spubp(side, c), abort_flag)) {
+                    MM_FUSED_ABANDON;
+                }
                 tile_gemm_nt(As, Bs, acc);
             }
             // the block's own entries are fetched as late as possible (their latency hides behind the wait for L_cc):
@@ -1004,7 +1272,11 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, TwGeom 
             __syncthreads();   // the last tile product has read As / Bs
             MM_ACC_FOREACH(As[row][col] = ((t.rv(row) && t.cv(col)) ? ld_shared<MODE>(t.at(row, col)) : 0.0) - acc[a][b][i];)
             __syncthreads();
-            if (!finish_off_block_streamed<MODE, false>(As, Bs, T, lpubp(side, c), linv(side, c), abort_flag, t, acc)) MM_FUSED_ABANDON;
+            // (d = 2: the block also goes out panel by panel for the head of its row, whose last column it is)
+            if (!finish_off_block_streamed<MODE, false>(As, Bs, T, lpubp(side, c), linv(side, c), abort_flag, t, acc,
+                                                        d == 2 && r < ncols ? spub2p(side, r) : nullptr))
+                MM_FUSED_ABANDON;
+            if (d == 2 && r < ncols) store_tile_shared16(As, t);      // (its copy in A: see trsm_finish)
             wg_publish<MODE>(flag(fb, r, d));
             if (b_fwd) {  // L_rc y_c for the forward substitution (the block is still in As)
                 if (!wg_wait<MODE>(yflag(fb, c), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
@@ -1022,7 +1294,7 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, TwGeom 
         }
         return;
     }
-    double4_t acc1[2][2], a1[2][2];
+    double4_t acc1[2][2];
     for (int r = j; r < nrows; r += period) {
         const bool diag_here = r < ncols;          // side 1 past its last column: only the block (b, b - 1) is left
         if (!diag_here && r != ncols) continue;
@@ -1036,40 +1308,90 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, TwGeom 
         // rows of M (two-ended, side 0): the diagonal block -- and the block left of it when that is in M too -- come
         // pre-accumulated over the columns of T and of the other end; only the columns of M are left to add
         const bool diag_pre = tw && side == 0 && r >= g.a, sub_pre = diag_pre && r - 1 >= g.a;
-        // The block's own entries (a0: diagonal tile, a1: the tile left of it) are fetched right before the LAST column's
-        // waits -- late enough for a matrix that is still being produced by a concurrent launch, early enough that their
-        // latency hides behind those waits.  What follows the last column sits on the critical chain
-        //   L_{r-1,r-2} -> this row's product with it -> streamed solve behind the factorisation of L_{r-1,r-1},
-        // so the products are ordered by what they wait for: the row's own block first (its square goes to the diagonal
-        // accumulator), the block of the row above last.
+        // The row's own two tiles of A (Ds: diagonal tile, Ss: the tile left of it) are parked in LDS before the products
+        // start -- nothing depends on them until the streamed solve, and two tile loads at the end of the row would sit on
+        // the critical chain  L_{r-1,r-2} -> product with it -> streamed solve behind the factorisation of L_{r-1,r-1}.
+        // (The first two rows of M wait for their pre-accumulators, which finish late: they fetch before the last column.)
         bool fetched = false, fetch_ok = true;
-        auto fetch_own = [&]() {
+        auto fetch_own = [&]() __attribute__((always_inline)) {
             fetched = true;
             if (diag_pre && !wg_wait<MODE>(pflag(r - g.a, r - g.a), sub_pre ? pflag(r - g.a, r - 1 - g.a) : nullptr, abort_flag, &s_ok)) fetch_ok = false;
             if (fetch_ok && diag_here && !rows_ready(nat(side, r))) fetch_ok = false;
             if (fetch_ok && side == 1 && has_sub && !rows_ready(nat(1, r - 1))) fetch_ok = false;
             if (!fetch_ok) return;
-            if (diag_here)
-                MM_ACC_FOREACH(a0[a][b][i] = (dt.rv(row) && dt.cv(col) && col <= row) ? ld_shared<MODE>(dt.at(row, col)) : 0.0;)
-            if (has_sub) MM_ACC_FOREACH(a1[a][b][i] = (st.rv(row) && st.cv(col)) ? ld_shared<MODE>(st.at(row, col)) : 0.0;)
+            if (diag_here) load_tile_shared<MODE>(Ds, dt);      // (the upper triangle is masked where the tile is used)
+            if (has_sub) load_tile_shared<MODE>(Ss, st);
         };
+        if (!diag_pre || r >= g.a + 2) {
+            fetch_own();
+            if (!fetch_ok) MM_FUSED_ABANDON;
+        }
         for (int k = max(0, r - bwb); k + 1 < r; ++k) {
             const bool do_diag = diag_here && !(diag_pre && k < g.a), do_sub = !(sub_pre && k < g.a);
-            if (k + 2 == r) {
+            if (k + 2 == r && !fetched) {
                 fetch_own();
                 if (!fetch_ok) MM_FUSED_ABANDON;
             }
             if (!do_diag && !do_sub) continue;
-            if (!wg_wait<MODE>(flag(fb, r, r - k), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
-            load_tile_shared<MODE>(As, tile_ref(A, g, side, r, k));
+            if (k + 2 == r && diag_here) {
+                // The last column.  Both blocks of it -- the row's own L_{r,r-2} (owner: offset 2) and L_{r-1,r-2} (the row
+                // head above) -- are being solved for right now, 16 columns at a time behind the factorisation of
+                // L_{r-2,r-2}: their products are taken panel by panel as the panels appear in the polled buffers, and
+                // this workgroup is ready for ITS streamed solve two microseconds after that factorisation ends.
+                const double *own = spub2p(side, r), *above = do_sub ? spubp(side, r - 1) : nullptr;
+                __syncthreads();      // the previous column's products have read As / Bs
+                MM_TRACE(r, 8);
+                // (one straight-line body per combination of the two products: accumulators updated under run-time
+                // conditions end up shuffled between register files and scratch)
+                bool col_ok = true;
+                auto last_column = [&](auto diag_tag, auto sub_tag) __attribute__((always_inline)) {
+                    constexpr bool DIAG = decltype(diag_tag)::value, SUB = decltype(sub_tag)::value;
+                    const int tid = thread_id();
+                    PanelPair p0, p1;
+                    panels_issue<0>(p0, own, above, tid);
+                    col_ok = panels_wait<0>(p0, own, above, tid, abort_flag);
+                    MM_TRACE(r, 15);
+                    panels_issue<1>(p1, own, above, tid);
+                    panels_commit<0>(p0, As, Bs, SUB, tid);
+                    if constexpr (DIAG) gemm_slice<0>(As, As, acc);
+                    if constexpr (SUB) gemm_slice<0>(As, Bs, acc1);
+                    col_ok = panels_wait<1>(p1, own, above, tid, abort_flag) && col_ok;
+                    panels_issue<2>(p0, own, above, tid);
+                    panels_commit<1>(p1, As, Bs, SUB, tid);
+                    if constexpr (DIAG) gemm_slice<1>(As, As, acc);
+                    if constexpr (SUB) gemm_slice<1>(As, Bs, acc1);
+                    col_ok = panels_wait<2>(p0, own, above, tid, abort_flag) && col_ok;
+                    panels_issue<3>(p1, own, above, tid);
+                    panels_commit<2>(p0, As, Bs, SUB, tid);
+                    if constexpr (DIAG) gemm_slice<2>(As, As, acc);
+                    if constexpr (SUB) gemm_slice<2>(As, Bs, acc1);
+                    col_ok = panels_wait<3>(p1, own, above, tid, abort_flag, side == 0 ? r : -1) && col_ok;
+                    MM_TRACE(r, 5);
+                    panels_commit<3>(p1, As, Bs, SUB, tid);
+                    if constexpr (DIAG) gemm_slice<3>(As, As, acc);
+                    if constexpr (SUB) gemm_slice<3>(As, Bs, acc1);
+                };
+                if (do_diag && do_sub)
+                    last_column(std::true_type{}, std::true_type{});
+                else if (do_diag)
+                    last_column(std::true_type{}, std::false_type{});
+                else
+                    last_column(std::false_type{}, std::true_type{});
+                if (!col_ok) MM_FUSED_ABANDON;
+                continue;
+            }
+            // both blocks of the column are waited for and fetched together (one trip to memory, one barrier)
+            if (!wg_wait<MODE>(flag(fb, r, r - k), do_sub ? flag(fb, r - 1, r - 1 - k) : nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
+            {
+                double pa[16], pb[16];
+                tile_prefetch_shared<MODE>(pa, tile_ref(A, g, side, r, k));
+                if (do_sub) tile_prefetch_shared<MODE>(pb, tile_ref(A, g, side, r - 1, k));
+                tile_commit(As, pa);
+                if (do_sub) tile_commit(Bs, pb);
+            }
             __syncthreads();
             if (do_diag) tile_gemm_nt(As, As, acc);
-            if (do_sub) {
-                if (!wg_wait<MODE>(flag(fb, r - 1, r - 1 - k), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
-                load_tile_shared<MODE>(Bs, tile_ref(A, g, side, r - 1, k));
-                __syncthreads();
-                tile_gemm_nt(As, Bs, acc1);
-            }
+            if (do_sub) tile_gemm_nt(As, Bs, acc1);
         }
         if (!fetched) {
             fetch_own();
@@ -1078,19 +1400,30 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, TwGeom 
         if (has_sub) {
             MM_TRACE(r, 1);
             __syncthreads();   // the last tile product has read As / Bs
-            MM_ACC_FOREACH(As[row][col] = a1[a][b][i] - acc1[a][b][i];)
+            // The solve runs IN the parked tile Ss (V = A_{r,r-1} - sum, in place): L_{r,r-1} then outlives the diagonal
+            // block's factorisation, which takes As / Bs -- it is copied to A beside that factorisation by the idle waves
+            // (StagePub::bulk) and multiplies y_{r-1} at the end of the row without being read back.
+            MM_ACC_FOREACH(Ss[row][col] -= acc1[a][b][i];)
             __syncthreads();
             // the solve streams behind the factorisation of L_{r-1,r-1}; acc += L_{r,r-1} L_{r,r-1}^T rides along
-            const bool ok = diag_here ? finish_off_block_streamed<MODE, true>(As, Bs, T, lpubp(side, r - 1), linv(side, r - 1), abort_flag,
-                                                                              st, acc, side == 0 ? r : -1)
-                                      : finish_off_block_streamed<MODE, false>(As, Bs, T, lpubp(side, r - 1), linv(side, r - 1),
-                                                                               abort_flag, st, acc);
+            const bool ok = diag_here ? finish_off_block_streamed<MODE, true>(Ss, Bs, T, lpubp(side, r - 1), linv(side, r - 1), abort_flag,
+                                                                              st, acc, spubp(side, r), side == 0 ? r : -1)
+                                      : finish_off_block_streamed<MODE, false>(Ss, Bs, T, lpubp(side, r - 1), linv(side, r - 1),
+                                                                               abort_flag, st, acc, nullptr);
             if (!ok) MM_FUSED_ABANDON;
             MM_TRACE(r, 4);
-            wg_publish<MODE>(flag(fb, r, 1));  // (its barrier also orders the LDS copy of the block)
-            MM_TRACE(r, 5);
+            // The block is out panel by panel in the polled buffer for those who sit on the chain (the next row head, the
+            // owners of the blocks below); its copy in A and the FLAG that goes with it -- for the pre-accumulators --
+            // follow beside the factorisation below.  One exception: the first row of M.  Its block (a, a - 1) is the last
+            // thing the pre-accumulators of the column (., a) wait for, and the next row heads wait for THEM: published at
+            // once (a few microseconds on the chain, once per factorisation).
+            if (diag_pre && r == g.a) {
+                store_tile_shared16(Ss, st);
+                wg_publish<MODE>(flag(fb, r, 1));
+            }
         }
         if (!diag_here) {  // side 1, block (b, b - 1): its row belongs to M, side 0 finishes it
+            wg_publish<MODE>(flag(fb, r, 1));
             if (b_fwd) {
                 if (!wg_wait<MODE>(yflag(fb, r - 1), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
                 if (threadIdx.x < NB) {
@@ -1098,7 +1431,7 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, TwGeom 
                     ys[threadIdx.x] = (vi >= 0 && vi < n) ? ld_shared<MODE>(y + vi) : 0.0;
                 }
                 __syncthreads();
-                const double tv = tile_matvec<LDT>(As, ys);
+                const double tv = tile_matvec<LDT>(Ss, ys);
                 if ((threadIdx.x & 3) == 0) st_shared<MODE>(cslot(side, r, 1) + (NB - 1 - (threadIdx.x >> 2)), tv);
                 wg_publish<MODE>(cflag(fb, r, 1));
             }
@@ -1106,14 +1439,15 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, TwGeom 
             continue;
         }
         __syncthreads();  // As / Bs are reused as M / X from here
-        MM_ACC_FOREACH(M[row][col] = (dt.rv(row) && dt.cv(col) && col <= row) ? a0[a][b][i] - acc[a][b][i]
+        MM_ACC_FOREACH(M[row][col] = (dt.rv(row) && dt.cv(col) && col <= row) ? Ds[row][col] - acc[a][b][i]
                                                                              : ((!dt.rv(row) && row == col) ? 1.0 : 0.0);)
         __syncthreads();
         int bad = 0;
         double *Lr = linv(side, r);
         MM_TRACE(r, 6);
         // the block streams out while it is factored: column panel k's sub-diagonal blocks, then X_kk (see trsm_stage)
-        factor_block_lds(M, X, R, 0, bad, StagePub<MODE>{M, X, dt, Lr, lpubp(side, r)}, side == 0 ? r : -1);
+        factor_block_lds(M, X, R, 0, bad, StagePub<MODE>{M, X, dt, Lr, lpubp(side, r), has_sub && !(diag_pre && r == g.a) ? flag(fb, r, 1) : nullptr, Ss, st},
+                         side == 0 ? r : -1);
         MM_TRACE(r, 7);
         if (bad && threadIdx.x == 64) {  // `bad` = 1-based position inside the block; report the natural column
             const long col = vec_index(g, side, r, bad - 1);
@@ -1134,15 +1468,14 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, TwGeom 
                 const long vi = vec_index(g, side, r, threadIdx.x);
                 rhs[threadIdx.x] = (vi >= 0 && vi < n) ? ld_shared<MODE>(b_fwd + vi) : 0.0;
             }
-            if (has_sub) {  // this workgroup owns (r, r-1); its LDS copy is gone (M), read the block back
+            if (has_sub) {  // this workgroup owns (r, r-1): still in Ss
                 if (!wg_wait<MODE>(yflag(fb, r - 1), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
-                load_tile_shared<MODE>(As, st);
                 if (threadIdx.x < NB) {
                     const long vi = vec_index(g, side, r - 1, threadIdx.x);
                     ys[threadIdx.x] = (vi >= 0 && vi < n) ? ld_shared<MODE>(y + vi) : 0.0;
                 }
                 __syncthreads();
-                const double tv = tile_matvec<LDT>(As, ys);
+                const double tv = tile_matvec<LDT>(Ss, ys);
                 if ((threadIdx.x & 3) == 0) rhs[threadIdx.x >> 2] -= tv;
             }
             for (int dd = 2; dd <= bwb && dd <= r; ++dd) {
@@ -1170,7 +1503,7 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, TwGeom 
 }
 
 #ifdef MM_CHOL_TRACE
-extern "C" int mm_debug_chol_trace(unsigned long long *host /*[128*16]*/) {
+extern "C" int mm_debug_chol_trace(unsigned long long *host /*[128*32]*/) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_chol_trace), sizeof(g_chol_trace));
 }
 #endif
@@ -1198,13 +1531,6 @@ __device__ __forceinline__ void tile_prefetch(double (&pre)[16], const TileRef &
 __device__ __forceinline__ void tile_prefetch_dense(double (&pre)[16], const double *__restrict__ src) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) pre[q] = src[threadIdx.x + 256 * q];
-}
-__device__ __forceinline__ void tile_commit(double (*T)[LDT], const double (&pre)[16]) {
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int e = threadIdx.x + 256 * q;
-        T[e / NB][e % NB] = pre[q];
-    }
 }
 // out[c] = sum_r T[r][c] v[r] for c = threadIdx.x & 63 (valid in the first 64 threads after the call); 256 threads
 __device__ __forceinline__ double tile_matvec_t(const double (*T)[LDT], const double *v, double (*part)[NB]) {
@@ -1369,6 +1695,7 @@ __global__ __launch_bounds__(256) void chol_init_kernel(int32_t *__restrict__ in
                                                         unsigned long long *__restrict__ sentinel_buf, size_t nsent,
                                                         unsigned long long *__restrict__ lpub, size_t nlpub,
                                                         unsigned long long *__restrict__ Linv, size_t nblk) {
+    // (lpub covers both hand-over buffers: the streamed pieces of the diagonal blocks and the sub-diagonal blocks)
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
     if (i == 0) info[0] = 0;
     for (size_t k = i; k < nflags; k += stride) flags[k] = 0;
@@ -1473,7 +1800,7 @@ size_t mm_chol_workspace_bytes(int n) {
     return mm_align_up(nblk * NB * NB * sizeof(double), 256) + mm_align_up((size_t)(n + NB) * sizeof(double), 256) +
            mm_align_up((2 * (2 * nblk * (FUSED_MAX_BWB + 1) + 2 * nblk) + 64 + FUSED_MAX_BWB * FUSED_MAX_BWB) * sizeof(int32_t), 256) +
            2 * mm_align_up(2 * nblk * (FUSED_MAX_BWB + 1) * NB * sizeof(double), 256) +  // forward + backward contributions
-           mm_align_up(nblk * LPUB_BLOCK * sizeof(double), 256);                          // hand-over buffer of the streamed blocks
+           mm_align_up(nblk * (LPUB_BLOCK + 2 * NB * NB) * sizeof(double), 256);          // hand-over buffers of the streamed blocks
 }
 
 int mm_chol_solve(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int half_bandwidth, int32_t *info, void *ws,
@@ -1598,16 +1925,17 @@ int mm_chol_solve_gated(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int 
         }
         const size_t nflags = 1 + 2 * (2 * (size_t)nblk * (bwb + 1) + 2 * nblk) + (size_t)g.m * g.m;
         const double *b_fwd = nrhs >= 1 ? b : nullptr;  // the first right-hand side rides along
-        MM_LAUNCH(ctx, "chol_init_kernel", chol_init_kernel, dim3(64), dim3(256), 0, info, flags, nflags,
+        double *spub = lpub + (size_t)nblk * LPUB_BLOCK;
+        MM_LAUNCH(ctx, "chol_init_kernel", chol_init_kernel, dim3(128), dim3(256), 0, info, flags, nflags,
                   (unsigned long long *)contrib_bwd, (size_t)sides * nblk * (bwb + 1) * NB, (unsigned long long *)lpub,
-                  (size_t)nblk * LPUB_BLOCK, (unsigned long long *)Linv, (size_t)nblk);
+                  (size_t)nblk * (LPUB_BLOCK + 2 * NB * NB), (unsigned long long *)Linv, (size_t)nblk);
         if (ctx->debug_abandon > 0) {      // test hook (mm_ctx_control): behave as if a workgroup had given up waiting
             --ctx->debug_abandon;
             const int32_t one = 1;
             MM_HIP(ctx, hipMemcpyAsync(flags, &one, sizeof(one), hipMemcpyHostToDevice, ctx->stream));
         }
         MM_LAUNCH(ctx, "chol_band_fused_kernel", chol_band_fused_kernel<2>, dim3(fused_grid), dim3(256), FUSED_LDS_BYTES, A, g, Linv,
-                  flags, info, b_fwd, ytmp, contrib, lpub, slab_ready, cams_per_slab, n_cams);
+                  flags, info, b_fwd, ytmp, contrib, lpub, spub, slab_ready, cams_per_slab, n_cams);
         fwd_done = b_fwd != nullptr;
     } else {
         for (int k = 0; k < nblk; ++k) {
