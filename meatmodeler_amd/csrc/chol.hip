@@ -1226,7 +1226,12 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, TwGeom 
                 tile_gemm_nt(As, As, acc);
         }
         if (!rows_ready(r)) MM_FUSED_ABANDON;
-        MM_ACC_FOREACH(if (t.rv(row) && t.cv(col)) st_shared<MODE>(t.at(row, col), ld_shared<MODE>(t.at(row, col)) - acc[a][b][i]);)
+        // A_rc - sum goes back through LDS: 16-byte write-through stores (an 8-byte one is a fabric write per lane, and the
+        // first rows of M wait for exactly this publication)
+        __syncthreads();
+        MM_ACC_FOREACH(As[row][col] = ((t.rv(row) && t.cv(col)) ? ld_shared<MODE>(t.at(row, col)) : 0.0) - acc[a][b][i];)
+        __syncthreads();
+        store_tile_shared16(As, t);
         wg_publish<MODE>(pflag(i, jj));
         return;
     }
@@ -1328,7 +1333,7 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, TwGeom 
         }
         for (int k = max(0, r - bwb); k + 1 < r; ++k) {
             const bool do_diag = diag_here && !(diag_pre && k < g.a), do_sub = !(sub_pre && k < g.a);
-            if (k + 2 == r && !fetched) {
+            if (k + 2 == r && !fetched && !diag_here) {      // (the streamed last column below fetches AFTER its products)
                 fetch_own();
                 if (!fetch_ok) MM_FUSED_ABANDON;
             }
@@ -1378,6 +1383,10 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, TwGeom 
                 else
                     last_column(std::false_type{}, std::true_type{});
                 if (!col_ok) MM_FUSED_ABANDON;
+                if (!fetched) {      // the first two rows of M: their pre-accumulators finish last of all
+                    fetch_own();
+                    if (!fetch_ok) MM_FUSED_ABANDON;
+                }
                 continue;
             }
             // both blocks of the column are waited for and fetched together (one trip to memory, one barrier)
