@@ -147,6 +147,18 @@ size_t mm_link_workspace_bytes(int n_frames, int cap);
 int mm_link_tracks_device(mm_ctx *ctx, int n_frames, int cap, const int32_t *kp_count, const float *kp_xy,
                           const int32_t *match_count, const int32_t *matches, void *ws, size_t ws_bytes,
                           int32_t *track_ptr, int32_t *obs_frame, int32_t *obs_kp, int64_t *counts /*dev[3]*/);
+/* managePoints ON THE DEVICE (processor.py:264-291): the flat observation arrays of a selection of tracks, point-major,
+ * insertion order inside a track -- what adjustPoints takes (bundleAdjuster.py:160-166).  All pointers are DEVICE pointers.
+ *   selection: sel == NULL: the n_sel tracks t_lo .. t_lo + n_sel - 1 (everything, or one rank's shard);
+ *              sel [n_sel] i32: these tracks in this order (a sliding window), with out_ptr [n_sel + 1] i64 = the exclusive
+ *              scan of their lengths from mm_flatten_offsets (out_ptr[n_sel] = number of observations: read it back to size
+ *              the outputs);
+ *   coords [n_obs, 2] f64 = kp_xy[obs_frame, obs_kp] (kp_xy [F, cap, 2] f32); frame_indices [n_obs] i32 = obs_frame -
+ *   frame_offset; point_indices [n_obs] i32 = position of the observation's track in the selection. */
+int mm_flatten_offsets(mm_ctx *ctx, const int32_t *track_ptr, const int32_t *sel, int64_t n_sel, int64_t *out_ptr);
+int mm_flatten_tracks(mm_ctx *ctx, const int32_t *track_ptr, const int32_t *obs_frame, const int32_t *obs_kp, const float *kp_xy,
+                      int cap, const int32_t *sel /*|NULL*/, int t_lo, int64_t n_sel, const int64_t *out_ptr /*|NULL*/, int64_t n_obs,
+                      int frame_offset, double *coords, int32_t *frame_indices, int32_t *point_indices);
 /* Host: co-observation pairs (o, o2) of one point with camera(o2) <= camera(o), grouped by block segment
  * camera(o) * (span + 1) + camera(o) - camera(o2) in a fixed canonical order.  seg_ptr [F*(span+1)+1].  Call with
  * pair_o == NULL to get the pair count.  Returns the count or a negative error (MM_ERR_ARG if span is too small). */

@@ -80,6 +80,8 @@ SIGNATURES = {
                                         C.c_int64, c_i64p, c_i32p, c_i32p, c_i64p]),
     "mm_link_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "mm_link_tracks_device": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_size_t, vp, vp, vp, vp]),
+    "mm_flatten_offsets": (C.c_int, [vp, vp, vp, C.c_int64, vp]),
+    "mm_flatten_tracks": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, vp, C.c_int, C.c_int64, vp, C.c_int64, C.c_int, vp, vp, vp]),
     "mm_ba_build_pairs": (C.c_int64, [C.c_int, C.c_int, C.c_int64, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, C.c_int,
                                       c_i64p, c_i32p, c_i32p, C.c_int64]),
     "mm_ba_build_index": (C.c_int, [C.c_int, C.c_int, C.c_int64, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p]),

@@ -165,6 +165,41 @@ def link_tracks_device(kp_count, kp_xy, match_count, matches, ctx=None):
     return track_ptr[:nt + 1], obs_frame[:no], obs_kp[:no], bool(bad)
 
 
+def flatten_tracks(track_ptr, obs_frame, obs_kp, kp_xy, sel=None, t_lo=0, n_sel=None, frame_offset=0, ctx=None):
+    """managePoints on the device (mm_flatten_tracks; reference processor.py:264-291): the flat observation arrays of a
+    selection of tracks.  track_ptr [T+1] i32, obs_frame / obs_kp [O] i32, kp_xy [F,cap,2] f32 (device tensors).
+    sel = None: the tracks t_lo .. t_lo + n_sel - 1 (default: all); sel [n] integer tensor: these tracks, in this order.
+    -> (coords [n_obs,2] f64, frame_indices [n_obs] i32 (minus frame_offset), point_indices [n_obs] i32) device tensors."""
+    ctx = ctx or default_context()
+    d = kp_xy.device
+    cap = kp_xy.shape[1]
+    tp = track_ptr.to(torch.int32).contiguous()
+    T = tp.numel() - 1
+    out_ptr = None
+    if sel is None:
+        n_sel = T - t_lo if n_sel is None else int(n_sel)
+        if n_sel < 0 or t_lo < 0 or t_lo + n_sel > T:
+            raise ValueError("flatten_tracks: range outside the track list")
+        n_obs = int((tp[t_lo + n_sel] - tp[t_lo]).item()) if n_sel else 0      # (one read-back sizes the outputs)
+        sel_t = None
+    else:
+        sel_t = sel.to(torch.int32).contiguous()
+        n_sel = sel_t.numel()
+        out_ptr = torch.empty(n_sel + 1, dtype=torch.int64, device=d)
+        ctx.check(lib.mm_flatten_offsets(ctx.h, ptr(tp), ptr(sel_t) if n_sel else None, n_sel, ptr(out_ptr)), "mm_flatten_offsets")
+        n_obs = int(out_ptr[n_sel].item())
+    coords = torch.empty((n_obs, 2), dtype=torch.float64, device=d)
+    fi = torch.empty(n_obs, dtype=torch.int32, device=d)
+    pi = torch.empty(n_obs, dtype=torch.int32, device=d)
+    if n_obs:
+        ctx.check(lib.mm_flatten_tracks(ctx.h, ptr(tp), ptr(obs_frame.to(torch.int32).contiguous()), ptr(obs_kp.to(torch.int32).contiguous()),
+                                        ptr(kp_xy.contiguous()), cap,
+                                        ptr(sel_t) if sel_t is not None else None, int(t_lo), n_sel,
+                                        ptr(out_ptr) if out_ptr is not None else None, n_obs, int(frame_offset), ptr(coords),
+                                        ptr(fi), ptr(pi)), "mm_flatten_tracks")
+    return coords, fi, pi
+
+
 # ------------------------------------------------------------------------------------------------ bundle adjustment
 
 def ba_build_index(F, P, fi, pi):

@@ -202,14 +202,9 @@ class ClipPipeline:
                 lens = lens[p_lo:p_hi]
                 P = p_hi - p_lo
             sharded = world > 1 and P_all >= 4 * world
-            O = int(lens.sum().item())
-            # observation indices of the selected tracks, point-major (managePoints order)
-            starts = tp64[sel]
-            offs = torch.cumsum(lens, 0) - lens
-            oi = torch.repeat_interleave(starts - offs, lens, output_size=O) + torch.arange(O, device=d)
-            fi = (of_[oi] - lo).to(torch.int32)
-            pi = torch.repeat_interleave(torch.arange(P, dtype=torch.int32, device=d), lens, output_size=O)
-            coords = xy[of_[oi].long(), ok[oi].long()].to(torch.float64)
+            # the selected tracks' observations, point-major (managePoints order; mm_flatten_tracks)
+            coords, fi, pi = ops.flatten_tracks(tp, of_, ok, xy, sel=sel, frame_offset=lo, ctx=self.ctx)
+            O = int(fi.numel())
             pb = ops.BADevice(K, fi, pi, coords, hi - lo, P, d, self.ctx)
             res = SchurTRF(pb, allreduce=allreduce if sharded else None).solve(
                 cams[lo:hi].contiguous(), pts[sel].contiguous(), ftol=ftol, verbose=verbose if rank == 0 else 0)
@@ -231,7 +226,7 @@ class ClipPipeline:
             timers["ba_windows"] = timers.get("ba_windows", 0.0) + (time.perf_counter() - t0) * 1e3
         return dict(cams=cams, points=pts, windows=stats)
 
-    def _window_problem(self, out, first_f, last_f, lens_all, tp64, lo, hi, F):
+    def _window_problem(self, out, first_f, last_f, lens_all, tp64, lo, hi, F, ctx=None):
         """Selection + managePoints-order flattening of one window on the device -> (sel, fi, pi, coords, P, O)."""
         d = self.device
         of_, ok, xy = out["obs_frame_dev"], out["obs_kp_dev"], out["xy_dev"]
@@ -239,15 +234,9 @@ class ClipPipeline:
         P = int(sel.numel())
         if P == 0:
             return sel, None, None, None, 0, 0
-        lens = lens_all[sel]
-        O = int(lens.sum().item())
-        starts = tp64[sel]
-        offs = torch.cumsum(lens, 0) - lens
-        oi = torch.repeat_interleave(starts - offs, lens, output_size=O) + torch.arange(O, device=d)
-        fi = (of_[oi] - lo).to(torch.int32)
-        pi = torch.repeat_interleave(torch.arange(P, dtype=torch.int32, device=d), lens, output_size=O)
-        coords = xy[of_[oi].long(), ok[oi].long()].to(torch.float64)
-        return sel, fi, pi, coords, P, O
+        # (mm_flatten_offsets + mm_flatten_tracks: the window's tracks, frame indices relative to the window)
+        coords, fi, pi = ops.flatten_tracks(out["track_ptr_dev"], of_, ok, xy, sel=sel, frame_offset=lo, ctx=ctx or self.ctx)
+        return sel, fi, pi, coords, P, int(fi.numel())
 
     def _adjust_windows_wavefront(self, out, K, extrinsics, window, stride, ftol, verbose, timers, allreduce, world, rank,
                                   streams=1):
@@ -290,7 +279,7 @@ class ClipPipeline:
 
         def solve_window(k, ctx, cams, pts, cams_upd, cam_mask, pts_upd, pt_mask):
             lo, hi = wins[k]
-            sel, fi, pi, coords, P, O = self._window_problem(out, first_f, last_f, lens_all, tp64, lo, hi, F)
+            sel, fi, pi, coords, P, O = self._window_problem(out, first_f, last_f, lens_all, tp64, lo, hi, F, ctx)
             if P == 0:
                 return
             pb = ops.BADevice(K, fi, pi, coords, hi - lo, P, d, ctx)
@@ -427,11 +416,8 @@ class ClipPipeline:
             lo, hi, o_lo, o_hi = parallel.partition_tracks(track_ptr, rank, world)
         else:
             lo, hi, o_lo, o_hi = 0, P, 0, O
-        of_d = obs_frame[o_lo:o_hi].contiguous()
-        ok_d = obs_kp[o_lo:o_hi]
-        lens = (track_ptr[lo + 1:hi + 1] - track_ptr[lo:hi]).long()
-        pi_d = torch.repeat_interleave(torch.arange(hi - lo, dtype=torch.int32, device=d), lens, output_size=o_hi - o_lo)
-        coords_d = xy_dev[of_d.long(), ok_d.long()].to(torch.float64)
+        # (mm_flatten_tracks: this rank's tracks lo .. hi - 1)
+        coords_d, of_d, pi_d = ops.flatten_tracks(track_ptr, obs_frame, obs_kp, xy_dev, t_lo=lo, n_sel=hi - lo, ctx=self.ctx)
         pb = ops.BADevice(K, of_d, pi_d, coords_d, F, hi - lo, d, self.ctx)
         pts0 = X[lo:hi].contiguous()
         solver = SchurTRF(pb, allreduce=parallel.AllReduce() if world > 1 else None)

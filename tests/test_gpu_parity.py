@@ -1243,6 +1243,111 @@ def test_wavefront_windows_in_flight_on_several_streams_equal_one_at_a_time():
     assert torch.equal(one["cams"], four["cams"]) and torch.equal(one["points"], four["points"])
 
 
+def test_flatten_tracks_device_equals_manage_points(golden_dir):
+    """mm_flatten_offsets / mm_flatten_tracks (managePoints behind the C ABI, reference processor.py:264-291): the flat
+    observation arrays of all tracks equal the reference's golden G7 output and the NumPy flattening; a contiguous range
+    (one rank's shard) and an index list with a frame offset (a sliding window) equal plain NumPy selections."""
+    sc = json.load(open(os.path.join(golden_dir, "g7_point_tracking.json")))[0]
+    kp = {int(k): v for k, v in sc["kp"].items()}
+    matches = {int(k): v for k, v in sc["matches"].items()}
+    F = len(kp)
+    cap = max(max(len(v) for v in kp.values()), max(len(v) for v in matches.values()))
+    kp_xy = np.zeros((F, cap, 2), np.float32)
+    kp_count = np.zeros(F, np.int32)
+    mm = np.zeros((F - 1, cap, 2), np.int32)
+    mc = np.zeros(F - 1, np.int32)
+    for f, v in kp.items():
+        kp_xy[f, :len(v)] = v
+        kp_count[f] = len(v)
+    for f, v in matches.items():
+        mm[f, :len(v)] = v
+        mc[f] = len(v)
+    tp, of, ok, bad = ops.link_tracks_device(dev(kp_count), dev(kp_xy), dev(mc), dev(mm))
+    coords, fi, pi = ops.flatten_tracks(tp, of, ok, dev(kp_xy))
+    mg = sc["manage"]
+    assert coords.cpu().numpy().tolist() == mg["coordinates"]
+    assert fi.cpu().numpy().tolist() == mg["frame_indices"] and pi.cpu().numpy().tolist() == mg["point_indices"]
+    # a larger random problem: ranges and index lists against NumPy
+    rng = np.random.default_rng(12)
+    T, Fr, capr = 5000, 40, 300
+    lens = rng.integers(2, 9, T)
+    tpn = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    ofn = np.concatenate([np.sort(rng.choice(Fr, l, replace=False)) for l in lens]).astype(np.int32)
+    okn = rng.integers(0, capr, tpn[-1]).astype(np.int32)
+    xyn = rng.normal(size=(Fr, capr, 2)).astype(np.float32)
+
+    def ref(sel, off):
+        c, f_, p_ = [], [], []
+        for j, t in enumerate(sel):
+            for o in range(tpn[t], tpn[t + 1]):
+                c.append(xyn[ofn[o], okn[o]].astype(np.float64))
+                f_.append(ofn[o] - off)
+                p_.append(j)
+        return np.array(c).reshape(-1, 2), np.array(f_, np.int32), np.array(p_, np.int32)
+    d_tp, d_of, d_ok, d_xy = dev(tpn), dev(ofn), dev(okn), dev(xyn)
+    cases = [dict(), dict(t_lo=1234, n_sel=2100), dict(sel=dev(np.sort(rng.choice(T, 1500, replace=False)).astype(np.int64)), frame_offset=7),
+             dict(sel=dev(np.array([4999, 0, 17], np.int64))), dict(t_lo=10, n_sel=0)]
+    for kw in cases:
+        c, f_, p_ = ops.flatten_tracks(d_tp, d_of, d_ok, d_xy, **kw)
+        if "sel" in kw:
+            sel = kw["sel"].cpu().numpy()
+        else:
+            lo = kw.get("t_lo", 0)
+            sel = np.arange(lo, lo + kw.get("n_sel", T - lo))
+        rc, rf, rp = ref(sel, kw.get("frame_offset", 0))
+        assert np.array_equal(c.cpu().numpy().reshape(-1, 2), rc) and np.array_equal(f_.cpu().numpy(), rf)
+        assert np.array_equal(p_.cpu().numpy(), rp)
+
+
+def test_c5_shape_4k_windows_on_one_gpu():
+    """BASELINE config 5's shape on one GPU: 3840 x 2160 frames, 8000 key points per frame, sliding-window bundle
+    adjustment with the wavefront schedule on 8 HIP streams (60 frames instead of 2000: the per-frame and per-window work
+    is the full-size one).  Every window terminates on a tolerance (status > 0); with disjoint windows (stride = window)
+    every window's reported cost is the oracle's cost function at the cameras / points it left behind (and no higher than
+    where it started); with the usual half-overlapping windows eight windows in flight equal one at a time."""
+    from meatmodeler_amd.bundleAdjuster import frameParameters
+    F, W = 60, 20
+    frames, ext, K = synth.render_orbit_frames_torch(F, 3840, 2160, DEV, arc_deg=0.36 * F, tex_size=4096)
+    pipe = ClipPipeline(2160, 3840, 8000, batch=12)
+    out = pipe.run(frames, K, ext, ba=False)
+    del frames
+    n_kp = out["det"]["n"].cpu().numpy()
+    assert n_kp.min() > 6000 and out["n_tracks"] > 50000
+    ClipPipeline.tracks_to_host(out)
+    tp, of, ok = out["track_ptr"], out["obs_frame"], out["obs_kp"]
+    xy = out["xy_dev"].cpu().numpy()
+    first, last = of[tp[:-1]], of[tp[1:] - 1]
+    cams0 = frameParameters(np.asarray(ext)[:, :3, :]).reshape(F, 6)
+    pts0 = out["points0"].cpu().numpy()
+
+    def window_problem(lo, hi):
+        sel = np.nonzero(ClipPipeline.window_selection(first, last, lo, hi, F))[0]
+        lens = tp[sel + 1] - tp[sel]
+        oi = np.concatenate([np.arange(tp[t], tp[t + 1]) for t in sel])
+        return sel, of[oi] - lo, np.repeat(np.arange(len(sel)), lens), xy[of[oi], ok[oi]].astype(np.float64)
+
+    def cost(cams, pts, lo, hi, sel, fi, pi, coords):
+        x = np.hstack([cams[lo:hi].ravel(), pts[sel].ravel()])
+        return 0.5 * np.sum(bo.point_fun(x, K, hi - lo, len(sel), fi, pi, coords) ** 2)
+    res = pipe.adjust_windows(out, K, ext, window=W, stride=W, order="wavefront", streams=8)
+    cams, pts = res["cams"].cpu().numpy(), res["points"].cpu().numpy()
+    assert len(res["windows"]) == 3
+    for st in res["windows"]:
+        assert st["status"] > 0 and st["points"] > 5000
+        sel, fi, pi, coords = window_problem(st["lo"], st["hi"])
+        assert (len(sel), len(fi)) == (st["points"], st["observations"])
+        c = cost(cams, pts, st["lo"], st["hi"], sel, fi, pi, coords)
+        assert abs(c - st["cost"]) <= 1e-7 * max(c, 1.0)
+        assert c <= cost(cams0, pts0, st["lo"], st["hi"], sel, fi, pi, coords)
+    # the usual half-overlapping windows: two colours; eight windows in flight give the result of one at a time, bit for bit
+    res2 = pipe.adjust_windows(out, K, ext, window=W, stride=W // 2, order="wavefront", streams=8)
+    assert len(res2["windows"]) == 5 and max(w["colour"] for w in res2["windows"]) == 1
+    assert all(st["status"] > 0 and np.isfinite(st["cost"]) for st in res2["windows"])
+    res1 = pipe.adjust_windows(out, K, ext, window=W, stride=W // 2, order="wavefront", streams=1)
+    assert res1["windows"] == res2["windows"]
+    assert torch.equal(res1["cams"], res2["cams"]) and torch.equal(res1["points"], res2["points"])
+
+
 def test_clip_pipeline_c2_shape_match_and_triangulate():
     """BASELINE config "1080p, 2000 key points, BF match + 2-view triangulation" on a short clip: the batched pipeline's
     matches of two frame pairs equal the oracle's (detect -> describe -> kNN-2 -> ratio, bit exact at 1080p), every
