@@ -318,11 +318,37 @@ typedef struct mm_trf_report {
     double cost0, cost, optimality, min_damping /* as raised during the solve */;
     int32_t nfev, njev, status, iterations, log_rows;
     int32_t chol_fallbacks;   /* times the solve switched to the launch-per-column factorisation (info = -1 seen): 0 or 1 */
+    int32_t collectives;      /* mm_ba_trf_dist: all-reduce calls made (7 per trust-region iteration + 3 at the start) */
+    int32_t reserved;
 } mm_trf_report;
 size_t mm_ba_trf_workspace_bytes(const mm_ba_problem *pb);
 int mm_ba_trf(mm_ctx *ctx, const mm_ba_problem *pb, double *cams /*dev, in/out*/, double *pts /*dev, in/out*/,
               const mm_trf_params *prm, mm_trf_report *report /*host*/, mm_trf_row *log /*host|NULL*/, int log_cap,
               void *ws /*dev, 256-byte aligned*/, size_t ws_bytes);
+/* The same loop SHARDED over the GPUs of a node (one process per GPU): `pb` holds this rank's points
+ * with all their observations (point indices local), the cameras are replicated, `pts` is the rank's shard.  Every sum
+ * over observations / points is completed by the caller's all-reduce -- the library does not link a communication
+ * library: `allreduce(user, buf, count)` must sum `count` doubles at the DEVICE pointer `buf` (inside the workspace) over
+ * the ranks, in place, ordered after the work already on the context's stream and before what follows (RCCL:
+ * ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, comm, stream); torch.distributed: all_reduce on a tensor view of the
+ * workspace), and return 0.  Per trust-region iteration: {B, g_c} | {|g_h|^2, |g|_inf, |J d g_h|^2} | {band of S, v} |
+ * {<q1, gn_h>, |gn_h|^2} | {|w|^2} | {the five step inner products, <u1, J s2>, |J s2|^2} | {trial cost, "a rank's
+ * factorisation was abandoned"} -- seven collectives, six of them one 64-double vector (the chain of dependent scalars of
+ * SciPy's 2-D subspace step does not get shorter than the four groups it has).
+ *   half_bandwidth: of the reduced camera system, from the GLOBAL camera span (6 * max over ranks of cam_span + 5);
+ *   band_exchange != 0: every rank's S is confined to that band (all shards have a pair list): n (hb + 1) + n doubles are
+ *     exchanged instead of n^2 + n.  Both must be the same on every rank (decide them from all-reduced quantities).
+ * All ranks see identical scalars and take identical decisions; the replicated cameras come out bit-identical. */
+typedef int (*mm_allreduce_fn)(void *user, double *buf /*dev*/, int64_t count);
+typedef struct mm_dist {
+    int32_t rank, world;   /* world <= 16 */
+    int32_t half_bandwidth, band_exchange;
+    mm_allreduce_fn allreduce;
+    void *user;
+} mm_dist;
+size_t mm_ba_trf_dist_workspace_bytes(const mm_ba_problem *pb, int half_bandwidth);
+int mm_ba_trf_dist(mm_ctx *ctx, const mm_ba_problem *pb, double *cams, double *pts, const mm_trf_params *prm,
+                   mm_trf_report *report, mm_trf_row *log, int log_cap, void *ws, size_t ws_bytes, const mm_dist *dist);
 /* SPD solve A x = b by blocked Cholesky (f64 MFMA trailing updates).  A [n,n] row-major, lower triangle is
  * overwritten by L; b [nrhs,n] is overwritten by x.  half_bandwidth: A[i][j] == 0 whenever i - j > half_bandwidth
  * (pass n for a dense matrix); the factorisation and the substitutions skip blocks outside the band.

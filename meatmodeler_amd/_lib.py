@@ -46,10 +46,18 @@ class TrfRow(C.Structure):
                 ("step_norm", C.c_double), ("optimality", C.c_double)]
 
 
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, vp, vp, C.c_int64)
+
+
+class Dist(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("half_bandwidth", C.c_int32), ("band_exchange", C.c_int32),
+                ("allreduce", ALLREDUCE_FN), ("user", vp)]
+
+
 class TrfReport(C.Structure):
     _fields_ = [("cost0", C.c_double), ("cost", C.c_double), ("optimality", C.c_double), ("min_damping", C.c_double),
                 ("nfev", C.c_int32), ("njev", C.c_int32), ("status", C.c_int32), ("iterations", C.c_int32),
-                ("log_rows", C.c_int32), ("chol_fallbacks", C.c_int32)]
+                ("log_rows", C.c_int32), ("chol_fallbacks", C.c_int32), ("collectives", C.c_int32), ("reserved", C.c_int32)]
 
 
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header.
@@ -124,6 +132,9 @@ SIGNATURES = {
     "mm_ba_trf_workspace_bytes": (C.c_size_t, [C.POINTER(BAProblem)]),
     "mm_ba_trf": (C.c_int, [vp, C.POINTER(BAProblem), vp, vp, C.POINTER(TrfParams), C.POINTER(TrfReport),
                             C.POINTER(TrfRow), C.c_int, vp, C.c_size_t]),
+    "mm_ba_trf_dist_workspace_bytes": (C.c_size_t, [C.POINTER(BAProblem), C.c_int]),
+    "mm_ba_trf_dist": (C.c_int, [vp, C.POINTER(BAProblem), vp, vp, C.POINTER(TrfParams), C.POINTER(TrfReport),
+                                 C.POINTER(TrfRow), C.c_int, vp, C.c_size_t, C.POINTER(Dist)]),
 }
 
 

@@ -359,6 +359,10 @@ class SchurTRF:
         band_exchange = (self.allreduce is not None and hasattr(pb, "band_view")
                          and span_all <= getattr(pb, "max_band_span", 192) and half_bw < nc)
         nfev, njev = 1, 1
+        if (self.driver == "library" and self.allreduce is not None and hasattr(pb, "trf_solve_dist")
+                and getattr(self.allreduce, "world_size", 1) <= 16):
+            # sharded: the same library loop, with this process group's all-reduce as its callback (mm_ba_trf_dist)
+            return self._solve_library(x, ftol, xtol, gtol, max_nfev, verbose, dist=(half_bw, band_exchange))
         if self._native and hasattr(pb, "trf_step2d") and hasattr(pb, "schur_solve") and hasattr(pb, "jvp_dots"):
             return self._solve_device(x, g, cost, half_bw, band_exchange, ftol, xtol, gtol, max_nfev, verbose)
         B, C = self._normal(x, g)
@@ -537,13 +541,18 @@ class SchurTRF:
                         iterations=iteration, host_segments_ms={k: 1e3 * v for k, v in seg.items()})
 
 
-def _solve_library(self, x, ftol, xtol, gtol, max_nfev, verbose):
-    """One GPU: the whole loop of `_solve_device` inside the library (mm_ba_trf, csrc/trf.hip)."""
+def _solve_library(self, x, ftol, xtol, gtol, max_nfev, verbose, dist=None):
+    """The whole loop of `_solve_device` inside the library: mm_ba_trf on one GPU, mm_ba_trf_dist (dist = (half bandwidth,
+    band exchange), both decided from all-reduced quantities) when the points are sharded over ranks (csrc/trf.hip)."""
     nc = self.nc
     cams, pts = x[:nc], x[nc:]
     t0 = time.perf_counter()
-    rep, rows = self.pb.trf_solve(cams, pts, ftol, xtol, gtol, max_nfev, self.min_damping,
-                                  log_cap=4096 if verbose == 2 else 0)
+    if dist is None:
+        rep, rows = self.pb.trf_solve(cams, pts, ftol, xtol, gtol, max_nfev, self.min_damping,
+                                      log_cap=4096 if verbose == 2 else 0)
+    else:
+        rep, rows = self.pb.trf_solve_dist(cams, pts, ftol, xtol, gtol, self.allreduce, dist[0], dist[1], max_nfev,
+                                           self.min_damping, log_cap=4096 if verbose == 2 else 0)
     self.min_damping = rep.min_damping
     if verbose == 2:
         _print_header()
@@ -554,6 +563,7 @@ def _solve_library(self, x, ftol, xtol, gtol, max_nfev, verbose):
     return BAResult(cams=self._cams(x).clone(), pts=self._pts(x).clone(), cost=rep.cost, optimality=rep.optimality,
                     nfev=rep.nfev, njev=rep.njev, status=rep.status, message=_MESSAGES[rep.status],
                     success=rep.status > 0, iterations=rep.iterations, chol_fallbacks=rep.chol_fallbacks,
+                    collectives=rep.collectives,
                     host_segments_ms={"library": 1e3 * (time.perf_counter() - t0)})
 
 

@@ -11,6 +11,8 @@
 // allocation, no second stream unless the overlapped build is requested.
 #include "mm_common.h"
 #include <chrono>
+#include <initializer_list>
+#include <utility>
 #include <cmath>
 #include <cstdlib>
 
@@ -38,6 +40,100 @@ __global__ __launch_bounds__(64) void board_publish_kernel(const double *__restr
     if (threadIdx.x == 0) __hip_atomic_store(&hb->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// ---- the sharded loop (mm_ba_trf_dist): points partitioned over ranks, cameras replicated --------------------------------
+// Every sum over observations / points is a partial sum on a rank.  The scalars among them travel in ONE 64-double
+// exchange vector per synchronisation point (all-reduce = sum): a packing kernel collects the ranks' contributions, the
+// unpacking kernel writes the totals where the next kernel reads them (the "total" column of the result rows), so that
+// all ranks feed identical scalars to identical kernels and take identical decisions.
+//   kind 0: a result row of a pass over the PARAMETER vector {camera part, point part, total}: the camera part is
+//           replicated (and its reduction tree depends on the local vector length: only rank 0's copy enters the sum);
+//   kind 1: a result row of inner products of RESIDUAL-space vectors: the local total enters;
+//   kind 2: a maximum {camera part, point part, total}: every rank puts its point part into its own slot (a sum over
+//           ranks then gathers them) and the maximum is taken after the exchange;
+//   kind 3: a plain scalar;  kind 4: "info < 0 on this rank" -> 1 in the rank's slot, the sum of the slots comes back.
+constexpr int EX_MAX_ITEMS = 12, EX_SCALARS = 64, EX_MAX_WORLD = 16;
+struct ExItems {
+    double *p[EX_MAX_ITEMS];
+    int kind[EX_MAX_ITEMS];
+    int n, rank, world;
+    const int32_t *info;
+};
+__global__ __launch_bounds__(64) void ex_pack_kernel(ExItems it, double *__restrict__ ex) {
+    const int t = threadIdx.x;
+    double v = 0.0;
+    if (t < it.n) {
+        const double *r = it.p[t];
+        const int k = it.kind[t];
+        if (k == 0) v = it.rank == 0 ? r[0] + r[1] : r[1];
+        else if (k == 1) v = r[2];
+        else if (k == 3) v = r[0];
+    }
+    ex[t] = v;
+    __syncthreads();
+    // slot items: 16 slots each behind the plain items, in item order
+    if (t == 0) {
+        int slot = 16;
+        for (int i = 0; i < it.n; ++i) {
+            if (it.kind[i] == 2) { ex[slot + it.rank] = it.p[i][1]; slot += EX_MAX_WORLD; }
+            if (it.kind[i] == 4) { ex[slot + it.rank] = it.info[0] < 0 ? 1.0 : 0.0; slot += EX_MAX_WORLD; }
+        }
+    }
+}
+__global__ __launch_bounds__(64) void ex_unpack_kernel(ExItems it, const double *__restrict__ ex) {
+    const int t = threadIdx.x;
+    if (t < it.n) {
+        double *r = it.p[t];
+        const int k = it.kind[t];
+        if (k == 0 || k == 1) r[2] = ex[t];
+        else if (k == 3) r[0] = ex[t];
+    }
+    if (t == 0) {
+        int slot = 16;
+        for (int i = 0; i < it.n; ++i) {
+            if (it.kind[i] == 2) {
+                double m = it.p[i][0];
+                for (int q = 0; q < it.world; ++q) m = fmax(m, ex[slot + q]);
+                it.p[i][2] = m;
+                slot += EX_MAX_WORLD;
+            }
+            if (it.kind[i] == 4) {
+                double sum = 0.0;
+                for (int q = 0; q < it.world; ++q) sum += ex[slot + q];
+                it.p[i][0] = sum;
+                slot += EX_MAX_WORLD;
+            }
+        }
+    }
+}
+// the lower band of S as a contiguous [n, hb + 1] array: entry [j, k] = S[j + k][j] (zero past the last row)
+__global__ __launch_bounds__(256) void band_pack_kernel(const double *__restrict__ S, int64_t n, int hb, double *__restrict__ band) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x, total = n * (hb + 1);
+    if (i >= total) return;
+    const int64_t j = i / (hb + 1), k = i % (hb + 1);
+    band[i] = j + k < n ? S[(j + k) * n + j] : 0.0;
+}
+// ... and back, with the duplicates removed: every rank added the full blockdiag(Bd) to its S and the full g_c to its v
+__global__ __launch_bounds__(256) void band_unpack_kernel(double *__restrict__ S, int64_t n, int hb, const double *__restrict__ band,
+                                                          const double *__restrict__ Bd, double dup) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x, total = n * (hb + 1);
+    if (i >= total) return;
+    const int64_t j = i / (hb + 1), k = i % (hb + 1), row = j + k;
+    if (row >= n) return;
+    double v = band[i];
+    if (row / 6 == j / 6) v -= dup * Bd[(j / 6) * 36 + (row % 6) * 6 + j % 6];
+    S[row * n + j] = v;
+}
+__global__ __launch_bounds__(256) void dedup_dense_kernel(double *__restrict__ S, int64_t n, const double *__restrict__ Bd, double dup) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;      // one thread per entry of blockdiag(Bd): F * 36
+    if (i >= n * 6) return;
+    const int64_t f = i / 36, a = (i % 36) / 6, b = i % 6;
+    S[(6 * f + a) * n + 6 * f + b] -= dup * Bd[i];
+}
+__global__ __launch_bounds__(256) void axpy_kernel(double *__restrict__ y, const double *__restrict__ x, double a, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] += a * x[i];
+}
+
 struct Carve {
     char *p;
     size_t used = 0;
@@ -57,10 +153,12 @@ struct TrfWs {
     int32_t *info;
     void *ws_res, *ws_md, *ws_jvp, *ws_schur, *ws_chol, *ws_back;
     size_t ws_res_b, ws_md_b, ws_jvp_b, ws_schur_b, ws_chol_b, ws_back_b;
+    double *exs, *ex;      // sharded loop: the 64-double scalar exchange vector, the bulk exchange buffer (B | g_c, band | v)
+    size_t ex_count;
     size_t total;
 };
 
-TrfWs carve_trf(const mm_ba_problem *pb, void *base) {
+TrfWs carve_trf(const mm_ba_problem *pb, void *base, int64_t ex_half_bw = -1) {
     TrfWs t;
     Carve c(base);
     const size_t F = pb->F, P = pb->P, O = (size_t)pb->O, n = 6 * F + 3 * P, nc = 6 * F;
@@ -100,6 +198,16 @@ TrfWs carve_trf(const mm_ba_problem *pb, void *base) {
     t.ws_chol = c.take<char>(t.ws_chol_b);
     t.ws_back_b = mm_ba_backsub_workspace_bytes(pb);
     t.ws_back = c.take<char>(t.ws_back_b);
+    t.exs = nullptr;
+    t.ex = nullptr;
+    t.ex_count = 0;
+    if (ex_half_bw >= 0) {      // (mm_ba_trf_dist)
+        const size_t hb = (size_t)(ex_half_bw < (int64_t)nc - 1 ? ex_half_bw : (nc ? nc - 1 : 0));
+        t.ex_count = nc * (hb + 1) + nc;
+        if (t.ex_count < F * 42) t.ex_count = F * 42;
+        t.exs = c.take<double>(EX_SCALARS);
+        t.ex = c.take<double>(t.ex_count + 2);
+    }
     t.total = c.used;
     return t;
 }
@@ -139,14 +247,23 @@ extern "C" size_t mm_ba_trf_workspace_bytes(const mm_ba_problem *pb) {
         if (rc_) return rc_;  \
     } while (0)
 
-extern "C" int mm_ba_trf(mm_ctx *ctx, const mm_ba_problem *pb, double *cams, double *pts, const mm_trf_params *prm,
-                         mm_trf_report *rep, mm_trf_row *log, int log_cap, void *ws, size_t ws_bytes) {
+extern "C" size_t mm_ba_trf_dist_workspace_bytes(const mm_ba_problem *pb, int half_bandwidth) {
+    if (!pb || pb->F < 0 || pb->P < 0 || pb->O < 0 || half_bandwidth < 0) return 0;
+    return carve_trf(pb, nullptr, half_bandwidth).total;
+}
+
+static int trf_run(mm_ctx *ctx, const mm_ba_problem *pb, double *cams, double *pts, const mm_trf_params *prm, mm_trf_report *rep,
+                   mm_trf_row *log, int log_cap, void *ws, size_t ws_bytes, const mm_dist *dist) {
     if (!ctx) return MM_ERR_ARG;
     if (!pb || !cams || !pts || !prm || !rep || pb->F <= 0 || pb->P < 0 || pb->O < 0 || !pb->K || log_cap < 0 || (log_cap > 0 && !log))
         return mm_fail(ctx, MM_ERR_ARG, "mm_ba_trf: bad argument");
-    if (!ws || ws_bytes < mm_ba_trf_workspace_bytes(pb) || ((uintptr_t)ws & 255))
+    if (dist && (dist->world < 1 || dist->world > EX_MAX_WORLD || dist->rank < 0 || dist->rank >= dist->world || !dist->allreduce ||
+                 dist->half_bandwidth < 0))
+        return mm_fail(ctx, MM_ERR_ARG, "mm_ba_trf_dist: bad communicator description (1 <= world <= %d)", EX_MAX_WORLD);
+    const size_t need = dist ? mm_ba_trf_dist_workspace_bytes(pb, dist->half_bandwidth) : mm_ba_trf_workspace_bytes(pb);
+    if (!ws || ws_bytes < need || ((uintptr_t)ws & 255))
         return mm_fail(ctx, MM_ERR_WORKSPACE, "mm_ba_trf: workspace too small or misaligned");
-    const TrfWs t = carve_trf(pb, ws);
+    const TrfWs t = carve_trf(pb, ws, dist ? dist->half_bandwidth : -1);
     // the sweeps share one table of per-camera rotation coefficients: this loop knows when the camera vector behind a
     // pointer changes (only the trial point is ever rewritten), so the table is rebuilt once per trial point
     struct TableHold {
@@ -179,6 +296,41 @@ extern "C" int mm_ba_trf(mm_ctx *ctx, const mm_ba_problem *pb, double *cams, dou
     if (P) MM_HIP(ctx, hipMemcpyAsync(x + nc, pts, (size_t)3 * P * sizeof(double), hipMemcpyDeviceToDevice, st));
     double host[16];
     rep->chol_fallbacks = 0;
+    rep->collectives = 0;
+    // ---- sharded: the exchange points (see ExItems) ----
+    auto ar = [&](double *buf, int64_t count) -> int {
+        ++rep->collectives;
+        const int rc = dist->allreduce(dist->user, buf, count);
+        return rc ? mm_fail(ctx, MM_ERR_HIP, "mm_ba_trf_dist: the all-reduce callback failed (%d)", rc) : MM_OK;
+    };
+    auto exchange = [&](std::initializer_list<std::pair<double *, int>> items) -> int {
+        if (!dist) return MM_OK;
+        ExItems it = {};
+        it.rank = dist->rank;
+        it.world = dist->world;
+        it.info = t.info;
+        for (auto &pr : items) {
+            it.p[it.n] = pr.first;
+            it.kind[it.n] = pr.second;
+            ++it.n;
+        }
+        hipLaunchKernelGGL(ex_pack_kernel, dim3(1), dim3(64), 0, st, it, t.exs);
+        TRF_CALL(ar(t.exs, EX_SCALARS));
+        hipLaunchKernelGGL(ex_unpack_kernel, dim3(1), dim3(64), 0, st, it, (const double *)t.exs);
+        MM_LAUNCH_CHECK(ctx, "ex_unpack_kernel");
+        return MM_OK;
+    };
+    // block normal equations at v: B and g_c are sums over ALL observations
+    auto normal_eq = [&](double *v) -> int {
+        TRF_CALL(mm_ba_normal_eq(ctx, pb, cams_of(v), pts_of(v), t.B, cams_of(t.g), t.C, pts_of(t.g)));
+        if (!dist) return MM_OK;
+        MM_HIP(ctx, hipMemcpyAsync(t.ex, t.B, (size_t)F * 36 * sizeof(double), hipMemcpyDeviceToDevice, st));
+        MM_HIP(ctx, hipMemcpyAsync(t.ex + (size_t)F * 36, cams_of(t.g), (size_t)nc * sizeof(double), hipMemcpyDeviceToDevice, st));
+        TRF_CALL(ar(t.ex, (int64_t)F * 42));
+        MM_HIP(ctx, hipMemcpyAsync(t.B, t.ex, (size_t)F * 36 * sizeof(double), hipMemcpyDeviceToDevice, st));
+        MM_HIP(ctx, hipMemcpyAsync(cams_of(t.g), t.ex + (size_t)F * 36, (size_t)nc * sizeof(double), hipMemcpyDeviceToDevice, st));
+        return MM_OK;
+    };
     static const bool spin = !(getenv("MM_TRF_SPIN") && getenv("MM_TRF_SPIN")[0] == '0');
     if (spin && !ctx->host_board) {
         MM_HIP(ctx, hipHostMalloc(&ctx->host_board, sizeof(HostBoard), hipHostMallocDefault));
@@ -215,6 +367,7 @@ extern "C" int mm_ba_trf(mm_ctx *ctx, const mm_ba_problem *pb, double *cams, dou
     };
     // initial cost
     TRF_CALL(mm_ba_residual(ctx, pb, cams_of(x), pts_of(x), nullptr, t.cost2, t.ws_res, t.ws_res_b));
+    TRF_CALL(exchange({{t.cost2, 3}}));
     TRF_CALL(read_board(t.cost2, 1));
     double cost = 0.5 * host[0];
     rep->cost0 = cost;
@@ -222,14 +375,15 @@ extern "C" int mm_ba_trf(mm_ctx *ctx, const mm_ba_problem *pb, double *cams, dou
         rep->status = -2;
         return mm_fail(ctx, MM_ERR_NUMERIC, "mm_ba_trf: residuals are not finite in the initial point");
     }
-    const int half_bw = 6 * pb->cam_span + 5;
+    const int half_bw = dist ? dist->half_bandwidth : 6 * pb->cam_span + 5;
     int nfev = 1, njev = 1;
-    TRF_CALL(mm_ba_normal_eq(ctx, pb, cams_of(x), pts_of(x), t.B, cams_of(t.g), t.C, pts_of(t.g)));
+    TRF_CALL(normal_eq(x));
     TRF_CALL(mm_ba_scale_update(ctx, F, P, t.B, t.C, t.si, 1));
     {   // Delta0 = |x * scale_inv|  (trf.py:428)
         hipLaunchKernelGGL(vec_mul_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double *)x, (const double *)t.si, t.w, n);
         const double *pa[1] = {t.w}, *pbv[1] = {t.w};
         TRF_CALL(mm_multi_dot(ctx, 1, pa, pbv, n, nc, t.rowsx, t.ws_md, t.ws_md_b));
+        TRF_CALL(exchange({{t.rowsx, 0}}));
         TRF_CALL(read_board(t.rowsx, 3));
     }
     double Delta = std::sqrt(host[2]);
@@ -251,6 +405,7 @@ extern "C" int mm_ba_trf(mm_ctx *ctx, const mm_ba_problem *pb, double *cams, dou
             TRF_CALL(mm_trf_fused(ctx, 0, in, outv, nullptr, 0, 0, n, nc, t.r0, t.ws_md, t.ws_md_b));
         }
         TRF_CALL(mm_ba_jvp_dots(ctx, pb, cams_of(x), pts_of(x), cams_of(t.ghs), pts_of(t.ghs), t.u1, nullptr, t.d11, t.ws_jvp, t.ws_jvp_b));
+        TRF_CALL(exchange({{t.r0, 0}, {t.r0 + 3, 2}, {t.d11, 1}, {t.d11 + 3, 1}}));      // |g_h|^2, |g|_inf, |J d g_h|^2
         if (termination != -100 || nfev == max_nfev) {
             TRF_CALL(read_board(t.r0, 6));
             g_norm = host[5];
@@ -267,31 +422,65 @@ extern "C" int mm_ba_trf(mm_ctx *ctx, const mm_ba_problem *pb, double *cams, dou
             const double *sc[1] = {t.board};
             TRF_CALL(mm_trf_fused(ctx, 5, in, outv, sc, 0, 0, n, nc, nullptr, t.ws_md, t.ws_md_b));
             mm_cam_table_invalidate(ctx);      // x_new has new contents
-            if (spin) {      // the residual's final sum and the hand-over to the host mailbox are one launch
+            if (spin && !dist) {      // the residual's final sum and the hand-over to the host mailbox are one launch
                 const unsigned long long seq = ++ctx->host_board_seq;
                 TRF_CALL(mm_ba_residual_publish(ctx, pb, cams_of(x_new), pts_of(x_new), t.ws_res, t.ws_res_b, t.board, 14, 16,
                                                 ctx->host_board, seq));
                 return wait_board(seq, 16);   // ---- the host sync of a trial step ----
             }
             TRF_CALL(mm_ba_residual(ctx, pb, cams_of(x_new), pts_of(x_new), nullptr, t.board + 14, t.ws_res, t.ws_res_b));
+            // sharded: the trial cost is a sum over all ranks; and whether ANY rank's factorisation was abandoned (a
+            // rank-local event) comes back in board[15], so that all ranks fall back together
+            TRF_CALL(exchange({{t.board + 14, 3}, {t.board + 15, 4}}));
             return read_board(t.board, 16);
         };
         for (int attempt = 0; attempt < 6 && !solved; ++attempt) {
             TRF_CALL(mm_ba_damp(ctx, F, P, t.B, t.C, t.si, reg_eff, t.Bd, t.Cd));
-            TRF_CALL(mm_ba_schur_solve(ctx, pb, cams_of(x), pts_of(x), t.Bd, t.Cd, cams_of(t.g), pts_of(t.g), t.S, t.v, t.Cinv, half_bw,
-                                       t.info, t.ws_schur, t.ws_schur_b, t.ws_chol, t.ws_chol_b, 0, 0, nullptr, nullptr));
+            if (!dist) {
+                TRF_CALL(mm_ba_schur_solve(ctx, pb, cams_of(x), pts_of(x), t.Bd, t.Cd, cams_of(t.g), pts_of(t.g), t.S, t.v, t.Cinv, half_bw,
+                                           t.info, t.ws_schur, t.ws_schur_b, t.ws_chol, t.ws_chol_b, 0, 0, nullptr, nullptr));
+            } else {
+                // every rank's S / v hold its points' share plus the FULL blockdiag(Bd) / g_c: sum, then remove the
+                // duplicates.  Band exchange (decided by the caller from global quantities): n (hb + 1) + n doubles in one
+                // collective instead of the dense matrix; only the lower band then holds the sum.
+                TRF_CALL(mm_ba_schur(ctx, pb, cams_of(x), pts_of(x), t.Bd, t.Cd, cams_of(t.g), pts_of(t.g), t.S, t.v, t.Cinv, t.ws_schur,
+                                     t.ws_schur_b));
+                const double dup = (double)(dist->world - 1);
+                if (dist->band_exchange) {
+                    const int hb = (int)(half_bw < nc - 1 ? half_bw : nc - 1);
+                    const int64_t cnt = nc * (hb + 1);
+                    hipLaunchKernelGGL(band_pack_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, (const double *)t.S, nc, hb, t.ex);
+                    MM_HIP(ctx, hipMemcpyAsync(t.ex + cnt, t.v, (size_t)nc * sizeof(double), hipMemcpyDeviceToDevice, st));
+                    TRF_CALL(ar(t.ex, cnt + nc));
+                    hipLaunchKernelGGL(band_unpack_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, t.S, nc, hb,
+                                       (const double *)t.ex, (const double *)t.Bd, dup);
+                    MM_HIP(ctx, hipMemcpyAsync(t.v, t.ex + cnt, (size_t)nc * sizeof(double), hipMemcpyDeviceToDevice, st));
+                } else {
+                    // (v rides behind the matrix: the buffer of S has room for it, one collective instead of two)
+                    MM_HIP(ctx, hipMemcpyAsync(t.S + nc * nc, t.v, (size_t)nc * sizeof(double), hipMemcpyDeviceToDevice, st));
+                    TRF_CALL(ar(t.S, nc * nc + nc));
+                    MM_HIP(ctx, hipMemcpyAsync(t.v, t.S + nc * nc, (size_t)nc * sizeof(double), hipMemcpyDeviceToDevice, st));
+                    hipLaunchKernelGGL(dedup_dense_kernel, dim3((unsigned)((nc * 6 + 255) / 256)), dim3(256), 0, st, t.S, nc,
+                                       (const double *)t.Bd, dup);
+                }
+                hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, st, t.v, (const double *)cams_of(t.g), -dup, nc);
+                MM_LAUNCH_CHECK(ctx, "axpy_kernel");
+                TRF_CALL(mm_chol_solve_sym(ctx, t.S, (int)nc, t.v, half_bw, dist->band_exchange ? 0 : 1, t.info, t.ws_chol, t.ws_chol_b));
+            }
             TRF_CALL(mm_ba_backsub(ctx, pb, cams_of(x), pts_of(x), t.Cinv, pts_of(t.g), t.v, t.dp, t.ws_back, t.ws_back_b));
             {
                 const double *in[4] = {t.v, t.dp, t.si, t.gh};
                 double *outv[2] = {t.gn, t.q1};
                 const double *sc[1] = {t.r0 + 2};
                 TRF_CALL(mm_trf_fused(ctx, 1, in, outv, sc, 0, 0, n, nc, t.r1, t.ws_md, t.ws_md_b));
+                TRF_CALL(exchange({{t.r1, 0}, {t.r1 + 3, 0}}));
             }
             {
                 const double *in[2] = {t.gn, t.q1};
                 double *outv[1] = {t.w};
                 const double *sc[1] = {t.r1 + 2};
                 TRF_CALL(mm_trf_fused(ctx, 2, in, outv, sc, 0, 0, n, nc, t.r2, t.ws_md, t.ws_md_b));
+                TRF_CALL(exchange({{t.r2, 0}}));
             }
             {
                 const double *in[5] = {t.w, t.q1, t.si, t.gh, x};
@@ -300,8 +489,10 @@ extern "C" int mm_ba_trf(mm_ctx *ctx, const mm_ba_problem *pb, double *cams, dou
                 TRF_CALL(mm_trf_fused(ctx, 3, in, outv, sc, 0, 0, n, nc, t.r3, t.ws_md, t.ws_md_b));
             }
             TRF_CALL(mm_ba_jvp_dots(ctx, pb, cams_of(x), pts_of(x), cams_of(t.s2), pts_of(t.s2), t.Jq2, t.u1, t.bs, t.ws_jvp, t.ws_jvp_b));
+            // (the step inner products and the two of J s2 travel together: the Jacobian product only needs s2)
+            TRF_CALL(exchange({{t.r3, 0}, {t.r3 + 3, 0}, {t.r3 + 6, 0}, {t.r3 + 9, 0}, {t.r3 + 12, 0}, {t.bs, 1}, {t.bs + 3, 1}}));
             TRF_CALL(trial(Delta));   // enqueued before the host knows whether the factorisation succeeded
-            const int inf = (int)host[6];
+            const int inf = dist && host[15] > 0 ? -1 : (int)host[6];
             if (inf == 0) {
                 solved = true;
                 break;
@@ -355,7 +546,7 @@ extern "C" int mm_ba_trf(mm_ctx *ctx, const mm_ba_problem *pb, double *cams, dou
             x = x_new;
             x_new = tmp;
             cost = cost_new;
-            TRF_CALL(mm_ba_normal_eq(ctx, pb, cams_of(x), pts_of(x), t.B, cams_of(t.g), t.C, pts_of(t.g)));
+            TRF_CALL(normal_eq(x));
             ++njev;
             TRF_CALL(mm_ba_scale_update(ctx, F, P, t.B, t.C, t.si, 0));
         } else {
@@ -377,4 +568,15 @@ extern "C" int mm_ba_trf(mm_ctx *ctx, const mm_ba_problem *pb, double *cams, dou
     rep->log_rows = n_log;
     rep->min_damping = min_damping;
     return MM_OK;
+}
+
+extern "C" int mm_ba_trf(mm_ctx *ctx, const mm_ba_problem *pb, double *cams, double *pts, const mm_trf_params *prm,
+                         mm_trf_report *rep, mm_trf_row *log, int log_cap, void *ws, size_t ws_bytes) {
+    return trf_run(ctx, pb, cams, pts, prm, rep, log, log_cap, ws, ws_bytes, nullptr);
+}
+
+extern "C" int mm_ba_trf_dist(mm_ctx *ctx, const mm_ba_problem *pb, double *cams, double *pts, const mm_trf_params *prm,
+                              mm_trf_report *rep, mm_trf_row *log, int log_cap, void *ws, size_t ws_bytes, const mm_dist *dist) {
+    if (!dist) return mm_fail(ctx, MM_ERR_ARG, "mm_ba_trf_dist: null communicator description");
+    return trf_run(ctx, pb, cams, pts, prm, rep, log, log_cap, ws, ws_bytes, dist);
 }

@@ -524,6 +524,46 @@ class BADevice:
                 for r in log[:min(rep.log_rows, log_cap)]]
         return rep, rows
 
+    def trf_solve_dist(self, cams, pts, ftol, xtol, gtol, allreduce, half_bandwidth, band_exchange, max_nfev=None,
+                       min_damping=1e-9, log_cap=0):
+        """mm_ba_trf_dist: the same loop sharded over ranks (this problem = the rank's points).  `allreduce` is a callable
+        summing a device tensor over the ranks in place (parallel.AllReduce); the library calls back with pointers into its
+        workspace, which are wrapped as tensor views here.  -> (report, rows) like trf_solve."""
+        for t in (cams, pts):
+            assert t.dtype == torch.float64 and t.is_contiguous() and t.device == self.device
+        need = lib.mm_ba_trf_dist_workspace_bytes(C.byref(self.pb), int(half_bandwidth))
+        if getattr(self, "_trf_ws_dist", None) is None or self._trf_ws_dist.numel() < need:
+            self._trf_ws_dist = torch.empty(need, dtype=torch.uint8, device=self.device)
+        ws = self._trf_ws_dist
+        base = ws.data_ptr()
+        err = []
+
+        def _cb(user, buf, count):
+            try:
+                off = int(buf) - base
+                with torch.cuda.stream(self.ctx.stream):      # ordered on the stream the library launches on
+                    allreduce(ws[off:off + 8 * int(count)].view(torch.float64))
+                return 0
+            except BaseException as e:      # (nothing may propagate through the C frames)
+                err.append(e)
+                return 1
+        cb = _lib.ALLREDUCE_FN(_cb)
+        d = _lib.Dist(int(getattr(allreduce, "rank", 0)), int(getattr(allreduce, "world_size", 1)), int(half_bandwidth),
+                      1 if band_exchange else 0, cb, None)
+        prm = _lib.TrfParams(ftol, xtol, gtol, min_damping, int(max_nfev) if max_nfev else 0)
+        rep = _lib.TrfReport()
+        log = (_lib.TrfRow * max(log_cap, 1))()
+        rc = lib.mm_ba_trf_dist(self.ctx.h, C.byref(self.pb), ptr(cams), ptr(pts), C.byref(prm), C.byref(rep), log,
+                                int(log_cap), ptr(ws), ws.numel(), C.byref(d))
+        if err:
+            raise err[0]
+        if rc and rep.status == -2:
+            raise ValueError("Residuals are not finite in the initial point.")
+        self.ctx.check(rc, "mm_ba_trf_dist")
+        rows = [(r.iteration, r.nfev, r.cost, r.reduction, r.step_norm, r.optimality)
+                for r in log[:min(rep.log_rows, log_cap)]]
+        return rep, rows
+
     def backsub(self, cams, pts, Cinv, gp, dc):
         dp = torch.empty((self.P, 3), dtype=torch.float64, device=self.device)
         if getattr(self, "_backsub_ws", None) is None:

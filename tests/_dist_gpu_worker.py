@@ -61,7 +61,8 @@ def main():
         res = solver.solve(cams0, torch.as_tensor(pr["pts0"][lo:hi].copy()).to(dev), ftol=1e-8, xtol=1e-10, max_nfev=60)
         out.update({f"{tag}_cams": res.cams.cpu().numpy(), f"{tag}_pts": res.pts.cpu().numpy(), f"{tag}_lo": lo,
                     f"{tag}_hi": hi, f"{tag}_cost": res.cost, f"{tag}_nfev": res.nfev, f"{tag}_status": res.status,
-                    f"{tag}_n_pairs": pb.n_pairs, f"{tag}_cam_span": pb.cam_span})
+                    f"{tag}_n_pairs": pb.n_pairs, f"{tag}_cam_span": pb.cam_span,
+                    f"{tag}_collectives": getattr(res, "collectives", -1), f"{tag}_iterations": getattr(res, "iterations", -1)})
 
     # (1) banded exchange: every shard has a pair list (golden G5 case c)
     sharded_ba("band", synth.make_ba_problem(40, 2000, 6, seed=1))

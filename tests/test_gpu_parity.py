@@ -1446,6 +1446,10 @@ def test_two_ranks_on_one_gpu_real_kernels_match_one_rank(tmp_path):
         # summation order differs between 1 and 2 ranks; on a converged, gauge-free problem x agrees to ~1e-6
         np.testing.assert_allclose(pts, one[f"{tag}_pts"], rtol=0, atol=1e-5)
         np.testing.assert_allclose(r0[f"{tag}_cams"], one[f"{tag}_cams"], rtol=0, atol=1e-5)
+        # the sharded solve is the LIBRARY loop (mm_ba_trf_dist): seven packed collectives per evaluation, three to start
+        n_coll, nfev = int(r0[f"{tag}_collectives"]), int(r0[f"{tag}_nfev"])
+        assert int(one[f"{tag}_collectives"]) == 0 and n_coll == int(r1[f"{tag}_collectives"])
+        assert 0 < n_coll <= 7 * nfev + 3, (tag, n_coll, nfev)
     assert int(r0["band_n_pairs"]) > 0 and int(r1["band_n_pairs"]) > 0              # packed band exchange taken
     assert int(r0["long_n_pairs"]) > 0 and int(r1["long_n_pairs"]) == 0              # mixed shards -> dense, same everywhere
     assert int(r1["long_cam_span"]) > 192
