@@ -267,7 +267,7 @@ def main():
         in_timed = dom_full["kernel"] in timed
         pmc = {}
         try:
-            pmc_file = next(f for f in ("r02_pmc_traffic.json", "r01_pmc_traffic.json")
+            pmc_file = next(f for f in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
                             if os.path.exists(os.path.join(ROOT, "profiles", f)))
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))["kernels"].get(dom["kernel"], {})
         except Exception:
@@ -348,7 +348,13 @@ def main():
             "ba": None if res is None else {
                 "nfev": nfev, "njev": res.njev, "iterations": getattr(res, "iterations", None),
                 "ms_per_iteration": stage_ms["ba_solve"] / max(getattr(res, "iterations", 0) or 1, 1),
-                "host_segments_ms_last_step": getattr(res, "host_segments_ms", None)},
+                "host_segments_ms_last_step": getattr(res, "host_segments_ms", None),
+                # N > 1: the same library loop (mm_ba_trf_dist); its exchange points call back into torch.distributed
+                "driver": "mm_ba_trf_dist" if world > 1 and getattr(res, "collectives", 0) else
+                          ("mm_ba_trf" if getattr(res, "host_segments_ms", {}).get("library") is not None else "python"),
+                "collectives": getattr(res, "collectives", None),
+                "collectives_per_evaluation": (getattr(res, "collectives", 0) or 0) / max(nfev, 1),
+                "chol_fallbacks": getattr(res, "chol_fallbacks", None)},
             "problem": {"keypoints": int(kp_count.sum()), "descriptor_pairs": pair_evals,
                         "matches": int(out["match_count"].sum()), "tracks": out["n_tracks"], "observations": n_obs,
                         "ba_nfev": nfev, "ba_status": res.status if res is not None else None,
