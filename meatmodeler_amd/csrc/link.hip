@@ -10,11 +10,16 @@
 //     the match index;
 //   * unmatched feature points spawn new tracks after the survivors, in match order; tracks not updated are popped in
 //     list order -> three block-wide prefix sums per keyframe pair.
-// The per-pair work is a handful of scatters / scans over <= 8192 items, strictly sequential over the pairs: ONE
-// resident workgroup walks the clip (no launch per pair, no host round trip); observations are nodes of per-track
-// linked lists, turned into the CSR (track_ptr, obs_frame, obs_kp) by a second kernel.
+// Two formulations, identical results:
+//   * serial (link_kernel, MM_LINK_VARIANT=serial): ONE resident workgroup walks the clip pair by pair (a handful of
+//     scatters / scans over <= 8192 items per pair, ~34 us each: 17 ms per 500-frame clip);
+//   * parallel (the default, "lp_" kernels below): the live list is always ordered by BIRTH (survivors keep their
+//     order, new tracks are appended), so "the first live track at a coordinate" is the OLDEST track there, and the
+//     whole clip becomes a forest over nodes (frame, canonical key point) that pointer doubling resolves in
+//     log2(frames) rounds over all matches of the clip at once.
 #include "mm_common.h"
 #include <climits>
+#include <type_traits>
 
 namespace {
 
@@ -389,6 +394,333 @@ __global__ __launch_bounds__(256) void link_emit_kernel(LinkWs ws, const int32_t
     }
 }
 
+// ---------------------------------------------------------------------------------------------- the parallel formulation
+// Nodes are (frame f, canonical key point c), n = f cap + c; a match g = k cap + m of pair k is an edge from node
+// (k, canon[q]) to node (k + 1, canon[t]).  With has(n) = "a live track sits at n":
+//   * a node with a track and matches leaving it continues its OLDEST track along its LAST match (the others are absorbed:
+//     Track.update overwrites): next(n);
+//   * every match leaving a node without a track starts a track, born at g (birth order = list order, see above);
+//   * several tracks arriving at one node: the oldest stays the owner, the others are never found again (popped there).
+// So the owner of a node is the smallest birth among the tracks born in the in-tree below it: birth(n) = min over the
+// subtree, computed by pointer doubling (round i pushes a node's minimum to its ancestor 2^i levels up).  The track born
+// at g = k0 cap + m0 then owns every continuation edge leaving a node whose owner it is; its observation at frame f
+// sits at index f - k0; its last frame is the largest one reached.  Final order (popped_tracks in pop order, then the
+// survivors: processor.py:418) = ascending (last frame, birth): a bucket per last frame -- at most `cap` tracks, they were
+// all live at that frame -- sorted by birth inside one workgroup.
+// has(n) itself = some EFFECTIVE edge arrives: the last match of any node always is (continuation or birth), the other
+// matches of a node with several (key points with equal coordinates) only if that node has no track: resolved by a
+// fixed-point pass over those few matches (layered by frame: exact after as many rounds as such nodes chain up).
+struct ParWs {
+    int32_t *canon;                  // [F, cap]
+    int32_t *lastm, *jump[2];        // nodes [F cap]: last match leaving the node (-1), doubling pointers (-1)
+    uint32_t *birth;                 // nodes: smallest birth in the subtree (0xFFFFFFFF = no track)
+    uint8_t *cert, *uin;             // nodes: an effective edge arrives (last matches | resolved others)
+    int32_t *src, *dst;              // matches [(F-1) cap]: node ids, -1 = malformed (ignored)
+    uint8_t *kind, *eff;             // matches: 0 absorbed, 1 starts a track, 2 continues one; scratch of the fixed point
+    int32_t *unc;                    // the matches that are not the last one of their node
+    int32_t *ptr_of;                 // by birth g: the track's first observation
+    int32_t *bcount, *bobs, *tbase, *obase;      // frames [F]: tracks ending there, their observations, exclusive sums
+    int32_t *bucket, *loff;          // [F cap]: births ending at a frame (slot = match index of the arriving edge, then
+                                     // closed up and sorted), observation offset inside the bucket
+    int32_t *scal;                   // [0] uncertain matches, [1] malformed matches
+    size_t ff_bytes, zero_off, zero_bytes;       // the two memset regions
+};
+constexpr uint32_t LP_NONE = 0xFFFFFFFFu;
+
+struct MatchAt {
+    int k, m, M;
+};
+__device__ __forceinline__ bool lp_match_at(int64_t g, int cap, const int32_t *match_count, MatchAt &a) {
+    a.k = (int)(g / cap);
+    a.m = (int)(g - (int64_t)a.k * cap);
+    a.M = min(max(match_count[a.k], 0), cap);
+    return a.m < a.M;
+}
+
+__global__ __launch_bounds__(256) void lp_edges_kernel(int64_t n_match, int cap, const int32_t *__restrict__ kp_count,
+                                                       const int32_t *__restrict__ match_count, const int32_t *__restrict__ matches,
+                                                       ParWs w) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    MatchAt a;
+    if (g >= n_match || !lp_match_at(g, cap, match_count, a)) return;
+    const int2 qt = reinterpret_cast<const int2 *>(matches)[g];
+    const int nk = min(kp_count[a.k], cap), nk1 = min(kp_count[a.k + 1], cap);
+    if (qt.x < 0 || qt.x >= nk || qt.y < 0 || qt.y >= nk1) {      // malformed match: ignored (and reported)
+        w.scal[1] = 1;
+        w.src[g] = -1;
+        return;
+    }
+    const int s_ = a.k * cap + w.canon[(size_t)a.k * cap + qt.x], d = (a.k + 1) * cap + w.canon[(size_t)(a.k + 1) * cap + qt.y];
+    w.src[g] = s_;
+    w.dst[g] = d;
+    atomicMax(&w.lastm[s_], a.m);
+}
+
+__global__ __launch_bounds__(256) void lp_certain_kernel(int64_t n_match, int cap, const int32_t *__restrict__ match_count, ParWs w) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    MatchAt a;
+    if (g >= n_match || !lp_match_at(g, cap, match_count, a)) return;
+    const int s_ = w.src[g];
+    if (s_ < 0) return;
+    if (w.lastm[s_] == a.m) w.cert[w.dst[g]] = 1;
+    else w.unc[atomicAdd(&w.scal[0], 1)] = (int32_t)g;
+}
+
+// effective(u) = the node u leaves has no track = no certain edge and no effective uncertain edge arrives there
+__global__ __launch_bounds__(1024) void lp_uncertain_kernel(int F, ParWs w) {
+    __shared__ int s_changed;
+    const int n = w.scal[0];
+    if (n == 0) return;
+    for (int i = threadIdx.x; i < n; i += 1024) w.eff[i] = !w.cert[w.src[w.unc[i]]];
+    __syncthreads();
+    for (int round = 0; round <= F; ++round) {
+        for (int i = threadIdx.x; i < n; i += 1024) w.uin[w.dst[w.unc[i]]] = 0;
+        if (threadIdx.x == 0) s_changed = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += 1024)
+            if (w.eff[i]) w.uin[w.dst[w.unc[i]]] = 1;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += 1024) {
+            const int s_ = w.src[w.unc[i]];
+            const uint8_t e = !(w.cert[s_] | w.uin[s_]);
+            if (e != w.eff[i]) {
+                w.eff[i] = e;
+                s_changed = 1;
+            }
+        }
+        __syncthreads();
+        if (!s_changed) break;      // (uin was built from the effective set that just proved stable)
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void lp_classify_kernel(int64_t n_match, int cap, const int32_t *__restrict__ match_count, ParWs w) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    MatchAt a;
+    if (g >= n_match || !lp_match_at(g, cap, match_count, a)) return;
+    const int s_ = w.src[g];
+    if (s_ < 0) return;
+    uint8_t kind = 0;
+    if (w.cert[s_] | w.uin[s_]) {
+        if (w.lastm[s_] == a.m) {
+            w.jump[0][s_] = w.dst[g];
+            kind = 2;
+        }
+    } else {
+        atomicMin(&w.birth[w.dst[g]], (uint32_t)g);
+        kind = 1;
+    }
+    w.kind[g] = kind;
+}
+
+// one doubling round: push the node's minimum to the ancestor `jin` points at, then point twice as far
+__global__ __launch_bounds__(256) void lp_jump_kernel(int64_t n_nodes, uint32_t *__restrict__ birth, const int32_t *__restrict__ jin,
+                                                      int32_t *__restrict__ jout) {
+    const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (u >= n_nodes) return;
+    const int j = jin[u];
+    int jj = -1;
+    if (j >= 0) {
+        const uint32_t b = __hip_atomic_load(&birth[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (b != LP_NONE) atomicMin(&birth[j], b);
+        jj = jin[j];
+    }
+    jout[u] = jj;
+}
+
+// The edge that brings a track to its LAST frame is the one whose target either has no match leaving it or is owned by an
+// older track.  That edge is unique per track and -- every live track of a frame arrived by its own match of the pair
+// before -- its match index is a slot of the frame's bucket nobody else writes: plain stores, no atomics.
+__global__ __launch_bounds__(256) void lp_final_kernel(int64_t n_match, int cap, const int32_t *__restrict__ match_count, ParWs w) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    MatchAt a;
+    if (g >= n_match || !lp_match_at(g, cap, match_count, a)) return;
+    if (w.src[g] < 0) return;
+    const uint8_t kind = w.kind[g];
+    if (kind == 0) return;
+    uint32_t g0 = (uint32_t)g;
+    if (kind == 2) {
+        g0 = w.birth[w.src[g]];
+        if (g0 == LP_NONE) {      // (not reached: a node that continues a track owns one)
+            w.scal[1] = 2;
+            return;
+        }
+    }
+    const int d = w.dst[g];
+    if (w.lastm[d] < 0 || w.birth[d] != g0) w.bucket[(size_t)(a.k + 1) * cap + a.m] = (int32_t)g0;
+}
+
+// one workgroup per frame: the births ending there in ascending order (bitonic network in LDS), and the offsets of their
+// observation runs inside the bucket (a track born in pair k0 that ends at frame f has f - k0 + 1 observations)
+__global__ __launch_bounds__(LK_THREADS) void lp_sort_kernel(int cap, ParWs w) {
+    __shared__ uint32_t keys[LK_MAX_CAP];
+    __shared__ int s_wave[17];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    int32_t *bk = w.bucket + (size_t)f * cap;
+    // the bucket has holes (slots = match indices of the pair before): close them up in LDS
+    int len[LK_IPT], off[LK_IPT];
+    uint32_t mine[LK_IPT];
+#pragma unroll
+    for (int q = 0; q < LK_IPT; ++q) {
+        const int i = tid * LK_IPT + q;
+        mine[q] = i < cap ? (uint32_t)bk[i] : LP_NONE;
+        len[q] = mine[q] != LP_NONE;
+    }
+    const int n = block_exscan(len, off, s_wave);
+    if (n == 0) {
+        if (tid == 0) {
+            w.bobs[f] = 0;
+            w.bcount[f] = 0;
+        }
+        return;
+    }
+    int P = 2;
+    while (P < n) P <<= 1;
+    for (int i = n + tid; i < P; i += LK_THREADS) keys[i] = LP_NONE;
+#pragma unroll
+    for (int q = 0; q < LK_IPT; ++q)
+        if (len[q]) keys[off[q]] = mine[q];
+    __syncthreads();
+    for (int k2 = 2; k2 <= P; k2 <<= 1)
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < P / 2; t += LK_THREADS) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), x = i | j;      // the pair (i, i + j)
+                const uint32_t a = keys[i], b = keys[x];
+                if ((a > b) == ((i & k2) == 0)) {
+                    keys[i] = b;
+                    keys[x] = a;
+                }
+            }
+            __syncthreads();
+        }
+#pragma unroll
+    for (int q = 0; q < LK_IPT; ++q) {
+        const int i = tid * LK_IPT + q;
+        len[q] = i < n ? f - (int)(keys[i] / (uint32_t)cap) + 1 : 0;
+    }
+    const int total = block_exscan(len, off, s_wave);
+#pragma unroll
+    for (int q = 0; q < LK_IPT; ++q) {
+        const int i = tid * LK_IPT + q;
+        if (i < n) {
+            bk[i] = (int32_t)keys[i];
+            w.loff[(size_t)f * cap + i] = off[q];
+        }
+    }
+    if (tid == 0) {
+        w.bobs[f] = total;
+        w.bcount[f] = n;
+    }
+}
+
+// exclusive sums over the frames (tracks, observations) and the totals
+__global__ __launch_bounds__(LK_THREADS) void lp_frames_kernel(int F, int cap, ParWs w, int32_t *__restrict__ track_ptr,
+                                                              int64_t *__restrict__ counts) {
+    __shared__ int s_wave[17];
+    const int tid = threadIdx.x;
+    int tb = 0, ob = 0;
+    for (int c0 = 0; c0 < F; c0 += LK_MAX_CAP) {
+        int a[LK_IPT], b[LK_IPT], ra[LK_IPT], rb[LK_IPT];
+#pragma unroll
+        for (int q = 0; q < LK_IPT; ++q) {
+            const int f = c0 + tid * LK_IPT + q;
+            a[q] = f < F ? min(w.bcount[f], cap) : 0;
+            b[q] = f < F ? w.bobs[f] : 0;
+        }
+        const int ta = block_exscan(a, ra, s_wave);
+        __syncthreads();
+        const int tb_ = block_exscan(b, rb, s_wave);
+#pragma unroll
+        for (int q = 0; q < LK_IPT; ++q) {
+            const int f = c0 + tid * LK_IPT + q;
+            if (f < F) {
+                w.tbase[f] = tb + ra[q];
+                w.obase[f] = ob + rb[q];
+            }
+        }
+        tb += ta;
+        ob += tb_;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        track_ptr[tb] = ob;
+        counts[0] = tb;
+        counts[1] = ob;
+        counts[2] = w.scal[1];
+    }
+}
+
+__global__ __launch_bounds__(256) void lp_ptr_kernel(int cap, ParWs w, int32_t *__restrict__ track_ptr) {
+    const int f = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= min(w.bcount[f], cap)) return;
+    const int p = w.obase[f] + w.loff[(size_t)f * cap + i];
+    track_ptr[w.tbase[f] + i] = p;
+    w.ptr_of[w.bucket[(size_t)f * cap + i]] = p;
+}
+
+__global__ __launch_bounds__(256) void lp_emit_kernel(int64_t n_match, int cap, const int32_t *__restrict__ match_count,
+                                                      const int32_t *__restrict__ matches, ParWs w, int32_t *__restrict__ obs_frame,
+                                                      int32_t *__restrict__ obs_kp) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    MatchAt a;
+    if (g >= n_match || !lp_match_at(g, cap, match_count, a)) return;
+    if (w.src[g] < 0) return;
+    const uint8_t kind = w.kind[g];
+    if (kind == 0) return;
+    const int2 qt = reinterpret_cast<const int2 *>(matches)[g];
+    if (kind == 1) {
+        const int p = w.ptr_of[g];
+        obs_frame[p] = a.k;
+        obs_kp[p] = qt.x;
+        obs_frame[p + 1] = a.k + 1;
+        obs_kp[p + 1] = qt.y;
+    } else {
+        const uint32_t g0 = w.birth[w.src[g]];
+        if (g0 == LP_NONE) return;
+        const int p = w.ptr_of[g0] + (a.k + 1 - (int)(g0 / (uint32_t)cap));
+        obs_frame[p] = a.k + 1;
+        obs_kp[p] = qt.y;
+    }
+}
+
+size_t carve_par(ParWs &w, uint8_t *base, int F, int cap) {
+    size_t off = 0;
+    auto take = [&](auto *&p, size_t n) {
+        using T = std::remove_reference_t<decltype(*p)>;
+        p = reinterpret_cast<T *>(base + off);
+        off += mm_align_up(n * sizeof(T), 256);
+    };
+    const size_t nodes = (size_t)F * cap, nm = (size_t)(F > 1 ? F - 1 : 0) * cap;
+    // (0xFF region)
+    take(w.lastm, nodes);
+    take(w.jump[0], nodes);
+    take(w.birth, nodes);
+    take(w.bucket, nodes);
+    w.ff_bytes = off;
+    // (zero region)
+    w.zero_off = off;
+    take(w.cert, nodes);
+    take(w.uin, nodes);
+    take(w.scal, 4);
+    w.zero_bytes = off - w.zero_off;
+    // (written before read)
+    take(w.canon, nodes);
+    take(w.jump[1], nodes);
+    take(w.src, nm + 1);
+    take(w.dst, nm + 1);
+    take(w.kind, nm + 1);
+    take(w.eff, nm + 1);
+    take(w.unc, nm + 1);
+    take(w.ptr_of, nm + 1);
+    take(w.bobs, (size_t)F + 1);
+    take(w.tbase, (size_t)F + 1);
+    take(w.obase, (size_t)F + 1);
+    take(w.bcount, (size_t)F + 1);
+    take(w.loff, nodes);
+    return off;
+}
+
 size_t carve(LinkWs &w, uint8_t *base, int F, int cap) {
     size_t off = 0;
     auto take = [&](int32_t *&p, size_t n) {
@@ -422,7 +754,9 @@ extern "C" {
 size_t mm_link_workspace_bytes(int n_frames, int cap) {
     if (n_frames < 0 || cap < 0) return 0;
     LinkWs w;
-    return carve(w, nullptr, n_frames, cap);
+    ParWs pw;
+    const size_t a = carve(w, nullptr, n_frames, cap), b = carve_par(pw, nullptr, n_frames, cap);
+    return a > b ? a : b;
 }
 
 int mm_link_tracks_device(mm_ctx *ctx, int n_frames, int cap, const int32_t *kp_count, const float *kp_xy,
@@ -441,27 +775,46 @@ int mm_link_tracks_device(mm_ctx *ctx, int n_frames, int cap, const int32_t *kp_
     if (!kp_count || !kp_xy || !match_count || !matches || !ws || !track_ptr || !obs_frame || !obs_kp)
         return mm_fail(ctx, MM_ERR_ARG, "mm_link_tracks_device: null pointer");
     if (((uintptr_t)ws & 255) || ((uintptr_t)kp_xy & 7)) return mm_fail(ctx, MM_ERR_ARG, "mm_link_tracks_device: alignment");
+    if (ws_bytes < mm_link_workspace_bytes(n_frames, cap)) return mm_fail(ctx, MM_ERR_WORKSPACE, "mm_link_tracks_device: workspace too small");
+    const char *variant = getenv("MM_LINK_VARIANT");
+    const bool serial = variant && variant[0] == 's';
     LinkWs w;
-    if (ws_bytes < carve(w, (uint8_t *)ws, n_frames, cap)) return mm_fail(ctx, MM_ERR_WORKSPACE, "mm_link_tracks_device: workspace too small");
+    ParWs pw;
+    carve(w, (uint8_t *)ws, n_frames, cap);
+    carve_par(pw, (uint8_t *)ws, n_frames, cap);
     int slots = 64;
     while (slots < 2 * cap) slots *= 2;      // <= 16384 for cap <= LK_MAX_CAP: 64 KB of LDS
-    {
-        static bool attr_set = false;
-        if (!attr_set && (size_t)slots * sizeof(int32_t) > 48 * 1024) {
-            MM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(link_canon_kernel),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * (int)sizeof(int32_t)));
-            attr_set = true;
-        }
-    }
+    // (the attribute belongs to the device's code object: set per call -- a host-side table lookup -- rather than remembered
+    // in a per-process flag that a second device would never see)
+    if ((size_t)slots * sizeof(int32_t) > 48 * 1024)
+        MM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(link_canon_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        16384 * (int)sizeof(int32_t)));
     MM_LAUNCH(ctx, "link_canon_kernel", link_canon_kernel, dim3(n_frames), dim3(CANON_THREADS), (size_t)slots * sizeof(int32_t), cap,
-              slots, kp_count, kp_xy, w.canon);
+              slots, kp_count, kp_xy, serial ? w.canon : pw.canon);
+    if (!serial) {
+        const int64_t n_match = (int64_t)(n_frames - 1) * cap, n_nodes = (int64_t)n_frames * cap;
+        const dim3 gm((unsigned)((n_match + 255) / 256)), gn((unsigned)((n_nodes + 255) / 256)), b256(256);
+        MM_HIP(ctx, hipMemsetAsync(ws, 0xFF, pw.ff_bytes, ctx->stream));
+        MM_HIP(ctx, hipMemsetAsync((uint8_t *)ws + pw.zero_off, 0, pw.zero_bytes, ctx->stream));
+        MM_LAUNCH(ctx, "lp_edges_kernel", lp_edges_kernel, gm, b256, 0, n_match, cap, kp_count, match_count, matches, pw);
+        MM_LAUNCH(ctx, "lp_certain_kernel", lp_certain_kernel, gm, b256, 0, n_match, cap, match_count, pw);
+        MM_LAUNCH(ctx, "lp_uncertain_kernel", lp_uncertain_kernel, dim3(1), dim3(1024), 0, n_frames, pw);
+        MM_LAUNCH(ctx, "lp_classify_kernel", lp_classify_kernel, gm, b256, 0, n_match, cap, match_count, pw);
+        int cur = 0;
+        for (int64_t reach = 1; reach < n_frames; reach *= 2, cur ^= 1)      // chains have at most n_frames - 1 edges
+            MM_LAUNCH(ctx, "lp_jump_kernel", lp_jump_kernel, gn, b256, 0, n_nodes, pw.birth, (const int32_t *)pw.jump[cur], pw.jump[cur ^ 1]);
+        MM_LAUNCH(ctx, "lp_final_kernel", lp_final_kernel, gm, b256, 0, n_match, cap, match_count, pw);
+        MM_LAUNCH(ctx, "lp_sort_kernel", lp_sort_kernel, dim3(n_frames), dim3(LK_THREADS), 0, cap, pw);
+        MM_LAUNCH(ctx, "lp_frames_kernel", lp_frames_kernel, dim3(1), dim3(LK_THREADS), 0, n_frames, cap, pw, track_ptr, counts);
+        MM_LAUNCH(ctx, "lp_ptr_kernel", lp_ptr_kernel, dim3((unsigned)((cap + 255) / 256), n_frames), b256, 0, cap, pw, track_ptr);
+        MM_LAUNCH(ctx, "lp_emit_kernel", lp_emit_kernel, gm, b256, 0, n_match, cap, match_count, matches, pw, obs_frame, obs_kp);
+        return MM_OK;
+    }
     const int lds_mode = cap <= 4096 ? 2 : 1;      // (cap <= LK_MAX_CAP = 8192: the three tables always fit)
     const size_t lds_bytes = (size_t)(lds_mode == 2 ? 9 : 3) * cap * sizeof(int32_t);
-    static size_t lds_set[3] = {0, 0, 0};
-    if (lds_bytes > 48 * 1024 && lds_bytes > lds_set[lds_mode]) {
+    if (lds_bytes > 48 * 1024) {
         const void *fn = lds_mode == 2 ? reinterpret_cast<const void *>(link_kernel<2>) : reinterpret_cast<const void *>(link_kernel<1>);
         MM_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        lds_set[lds_mode] = lds_bytes;
     }
     if (lds_mode == 2)
         MM_LAUNCH(ctx, "link_kernel", link_kernel<2>, dim3(1), dim3(LK_THREADS), lds_bytes, n_frames, cap, kp_count,

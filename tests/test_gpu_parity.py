@@ -1109,6 +1109,57 @@ def test_link_tracks_device_equals_host_linker(F, nk, frac, seed):
     assert len(tp0) - 1 > 0
 
 
+@pytest.mark.parametrize("variant", ["parallel", "serial"])
+def test_link_tracks_device_formulations_agree_on_degenerate_clips(variant, monkeypatch):
+    """Both formulations of the device linker (pointer doubling over the whole clip / one workgroup walking the pairs)
+    against the host linker where the has-a-track question chains through nodes with several matches: every key point of the
+    clip at ONE coordinate; two coordinates alternating; queries repeated inside a pair."""
+    monkeypatch.setenv("MM_LINK_VARIANT", variant)
+    rng = np.random.default_rng(5)
+    F, nk = 24, 96
+    for mode in range(3):
+        kp_xy = np.zeros((F, nk, 2), np.float32)
+        if mode == 1:
+            kp_xy[:, :, 0] = (np.arange(nk) % 2)[None, :]
+        if mode == 2:
+            kp_xy[:, :, 0] = (np.arange(nk) // 7)[None, :]
+        kp_count = np.full(F, nk, np.int32)
+        mc = np.zeros(F - 1, np.int32)
+        mm = np.zeros((F - 1, nk, 2), np.int32)
+        for f in range(F - 1):
+            m = int(rng.integers(0, nk))
+            mc[f] = m
+            mm[f, :m, 0] = rng.integers(0, nk, size=m)          # repeated queries allowed
+            mm[f, :m, 1] = rng.integers(0, nk, size=m)
+        (tp0, of0, ok0), (tp1, of1, ok1) = _link_both(kp_count, kp_xy, mc, mm)
+        assert np.array_equal(tp0, tp1.astype(np.int64)), mode
+        assert np.array_equal(of0, of1) and np.array_equal(ok0, ok1), mode
+
+
+def test_link_tracks_device_serial_equals_parallel(monkeypatch):
+    """The two device formulations on a clip-sized case with duplicate coordinates: identical CSR."""
+    rng = np.random.default_rng(8)
+    F, nk = 120, 3000
+    kp_xy = (np.round(rng.uniform(0, 90, (F, nk, 2)) * 2) / 2).astype(np.float32)
+    kp_count = rng.integers(nk - 500, nk + 1, size=F).astype(np.int32)
+    mc = np.zeros(F - 1, np.int32)
+    mm = np.zeros((F - 1, nk, 2), np.int32)
+    for f in range(F - 1):
+        m = int(min(kp_count[f], kp_count[f + 1]) * 0.8)
+        mc[f] = m
+        mm[f, :m, 0] = np.sort(rng.choice(kp_count[f], size=m, replace=False))
+        mm[f, :m, 1] = rng.integers(0, kp_count[f + 1], size=m)
+    res = {}
+    for variant in ("parallel", "serial"):
+        monkeypatch.setenv("MM_LINK_VARIANT", variant)
+        tp, of, ok, bad = ops.link_tracks_device(dev(kp_count), dev(kp_xy), dev(mc), dev(mm))
+        assert not bad
+        res[variant] = (tp.cpu().numpy(), of.cpu().numpy(), ok.cpu().numpy())
+    for a, b in zip(res["parallel"], res["serial"]):
+        assert np.array_equal(a, b)
+    assert len(res["serial"][0]) > 1000
+
+
 def test_link_tracks_device_full_size_properties():
     """BASELINE size (500 frames x 4000 key points, ~3000 matches per pair, distinct coordinates): properties that hold
     for any correct linking -- every track has >= 2 observations on consecutive ascending frames, every step of a track
