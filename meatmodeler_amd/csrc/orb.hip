@@ -16,6 +16,8 @@
 //   orb_rank        rank by (Harris desc, y, x) (counting rank, O(m^2), m <= 2n), keep n, scatter in order
 //   orb_describe    one wave per keypoint: 39x39 patch -> LDS, moments, separable integer blur, 256 tests
 #include "mm_common.h"
+#include <algorithm>
+#include <vector>
 
 #pragma clang fp contract(off)
 
@@ -23,6 +25,81 @@ namespace {
 
 constexpr int MAXL = 8;
 constexpr int EDGE = 31;
+
+// products of operands below 2^23 whose result fits 32 bits: the full-rate 24-bit multiplier (v_mul_lo_u32 and
+// v_mad_u64_u32, which the compiler picks for `int * int`, issue at a quarter of the rate)
+// (as instructions: the intrinsics are widened back to 32-bit multiplies wherever the compiler cannot prove the operand range)
+__device__ __forceinline__ int mul24(int a, int b) {
+    int d;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ int mad24(int a, int b, int c) {
+    int d;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+// A run of pyramid levels produced by ONE launch: a workgroup owns a tile of the run's source level and everything of
+// the following levels whose left / upper bilinear tap falls into what it owns one level up (the taps are monotone, so
+// the owned ranges are intervals that partition every level); the few columns / rows beyond, needed as right / lower taps
+// further down, are recomputed (bit-identical) rather than exchanged.  Bounds per tile boundary, as int32 in the workspace:
+//   X: lo[j][0..ntx] (j = 0..n: first owned column at run level j), nh[j][0..ntx-1] (last needed column); then Y likewise.
+constexpr int PY_MAXN = 4, PY_TW = 256, PY_TH = 64, PY_THREADS = 512;
+constexpr int PY_PITCH_A = 280, PY_PITCH_B = 236;      // LDS pitches of the two rectangles (compile-time: row steps are immediates)
+constexpr int PY_BUF_A = 20720, PY_BUF_B = 15340, PY_TABX = 288, PY_TABY = 96;      // 74 rows x 280, 65 rows x 236
+struct PyrChain {
+    int src, n;              // source level, levels produced (src + 1 .. src + n)
+    int ntx, nty;
+    int fused;               // 0: the rectangles do not fit the kernel's LDS buffers -> one launch per level
+    size_t bnd_off;
+};
+__host__ __device__ inline int py_x_lo(int j, int t, int ntx) { return j * (ntx + 1) + t; }
+__host__ __device__ inline int py_x_nh(int j, int t, int n, int ntx) { return (n + 1) * (ntx + 1) + j * ntx + t; }
+__host__ __device__ inline int py_dim_words(int n, int nt) { return (n + 1) * (2 * nt + 1); }
+
+// source coordinate of destination coordinate d (nd destination, ns source samples): the integers of orb_tables_kernel
+__host__ __device__ inline int rz_src0(long long d, long long nd, long long ns) {
+    long long num = (2 * d + 1) * ns - nd;
+    if (num < 0) num = 0;
+    long long i0 = num / (2 * nd);
+    if (i0 >= ns - 1) i0 = ns - 1;
+    return (int)i0;
+}
+// smallest d in [0, nd] with rz_src0(d) >= a (nd: none)
+__host__ __device__ inline int rz_lower(long long a, long long nd, long long ns) {
+    if (a <= 0) return 0;
+    if (a > ns - 1) return (int)nd;
+    const long long num = (2 * a + 1) * nd - ns;
+    long long d = num <= 0 ? 0 : (num + 2 * ns - 1) / (2 * ns);
+    if (d > nd) d = nd;
+    while (d > 0 && rz_src0(d - 1, nd, ns) >= a) --d;
+    while (d < nd && rz_src0(d, nd, ns) < a) ++d;
+    return (int)d;
+}
+// bounds of one tile boundary / tile `t` along one dimension; dims[j] = samples of run level j; out = the dimension's block
+__host__ __device__ inline void py_bounds_lo(int t, int nt, int tile, int n, const int *dims, int32_t *out) {
+    int lo = t * tile < dims[0] ? t * tile : dims[0];
+    out[py_x_lo(0, t, nt)] = lo;
+    for (int j = 1; j <= n; ++j) {
+        lo = t == nt ? dims[j] : rz_lower(lo, dims[j], dims[j - 1]);
+        out[py_x_lo(j, t, nt)] = lo;
+    }
+}
+__host__ __device__ inline void py_bounds_nh(int t, int nt, int n, const int *dims, int32_t *out) {      // (after all lo)
+    int nh = out[py_x_lo(n, t + 1, nt)] - 1;
+    out[py_x_nh(n, t, n, nt)] = nh;
+    for (int j = n; j >= 1; --j) {
+        const int own = out[py_x_lo(j - 1, t + 1, nt)] - 1;
+        int tap = -1;
+        if (nh >= out[py_x_lo(j, t, nt)]) {
+            tap = rz_src0(nh, dims[j], dims[j - 1]) + 1;
+            if (tap > dims[j - 1] - 1) tap = dims[j - 1] - 1;
+        }
+        nh = own > tap ? own : tap;
+        out[py_x_nh(j - 1, t, n, nt)] = nh;
+    }
+}
 
 struct OrbGeom {
     int nlevels, batch, H, W, stride0;
@@ -36,6 +113,8 @@ struct OrbGeom {
     int cand_cap[MAXL];
     size_t cand_off[MAXL];  // byte offset of the candidate key array of level l, frame 0
     size_t tab_off[MAXL];   // resize tables of level l: x0[w], wx[w], y0[h], wy[h] (int32)
+    PyrChain chain[2];      // the pyramid in (at most) two launches: levels 1..3 from the frame, 4..7 from level 3
+    int nchains;
     int kcap;               // kept capacity per segment (>= 2 * nfeat[0])
     size_t cnt_off, hist_off, thr_off, kcnt_off, kkey_off, kh_off;
     int cap_out;  // nfeatures
@@ -54,7 +133,27 @@ __device__ __forceinline__ const uint8_t *level_ptr(const OrbGeom &g, const uint
 // ---- resize tables ------------------------------------------------------------------------------------------------------
 __global__ void orb_tables_kernel(OrbGeom g, uint8_t *ws) {
     const int l = blockIdx.x + 1;
-    if (l >= g.nlevels) return;
+    if (l >= g.nlevels) {      // the blocks behind the levels: tile bounds of the fused pyramid launches
+        const int c = l - g.nlevels;
+        if (c >= g.nchains || !g.chain[c].fused) return;
+        const PyrChain ch = g.chain[c];
+        int32_t *bx = reinterpret_cast<int32_t *>(ws + ch.bnd_off), *by = bx + py_dim_words(ch.n, ch.ntx);
+        int dw[PY_MAXN + 1], dh[PY_MAXN + 1];
+        for (int j = 0; j <= ch.n; ++j) {
+            dw[j] = g.w[ch.src + j];
+            dh[j] = g.h[ch.src + j];
+        }
+        for (int t = threadIdx.x; t <= ch.ntx + ch.nty + 1; t += blockDim.x) {
+            if (t <= ch.ntx) py_bounds_lo(t, ch.ntx, PY_TW, ch.n, dw, bx);
+            else py_bounds_lo(t - ch.ntx - 1, ch.nty, PY_TH, ch.n, dh, by);
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < ch.ntx + ch.nty; t += blockDim.x) {
+            if (t < ch.ntx) py_bounds_nh(t, ch.ntx, ch.n, dw, bx);
+            else py_bounds_nh(t - ch.ntx, ch.nty, ch.n, dh, by);
+        }
+        return;
+    }
     int32_t *tab = reinterpret_cast<int32_t *>(ws + g.tab_off[l]);
     const int wd = g.w[l], hd = g.h[l], wsrc = g.w[l - 1], hsrc = g.h[l - 1];
     for (int i = threadIdx.x; i < wd + hd; i += blockDim.x) {
@@ -146,13 +245,237 @@ __global__ __launch_bounds__(256) void orb_resize_kernel(OrbGeom g, const uint8_
         for (int k = 0; k < 4; ++k) {
             uint32_t v = 0;
             if (tx0 + 4 * cg + k < wd) {
-                const int top = r0[c0[k]] * (2048 - wx[k]) + r0[c1[k]] * wx[k];
-                const int bot = r1[c0[k]] * (2048 - wx[k]) + r1[c1[k]] * wx[k];
-                v = (uint32_t)(top * (2048 - wy) + bot * wy + (1 << 21)) >> 22;
+                const int top = mad24(r0[c0[k]], 2048 - wx[k], mul24(r0[c1[k]], wx[k]));
+                const int bot = mad24(r1[c0[k]], 2048 - wx[k], mul24(r1[c1[k]], wx[k]));
+                v = (uint32_t)mad24(top, 2048 - wy, mad24(bot, wy, 1 << 21)) >> 22;
             }
             packed |= v << (8 * k);
         }
         *reinterpret_cast<uint32_t *>(dst + (size_t)y * pd + tx0 + 4 * cg) = packed;
+    }
+}
+
+// one entry of the resize tables, recomputed in 32-bit (dimensions < 4096: (2 d + 1) ns < 2^25): no table loads between levels
+__device__ __forceinline__ void rz_coord(int d, int nd, int ns, int &i0, int &wgt) {
+    const int num_ = (2 * d + 1) * ns - nd;
+    const unsigned num = num_ < 0 ? 0u : (unsigned)num_, den = 2u * (unsigned)nd;
+    // quotients of numbers below 2^25 by a divisor below 2^13: float estimate (off by at most one), then the exact fix-up
+    const float rcp = 1.0f / (float)den;
+    auto div = [&](unsigned n_) {
+        unsigned q_ = (unsigned)((float)n_ * rcp);
+        int r_ = (int)(n_ - q_ * den);
+        if (r_ < 0) --q_;
+        else if (r_ >= (int)den) ++q_;
+        return q_;
+    };
+    unsigned q = div(num);
+    const unsigned rem = num - q * den;
+    unsigned w_ = div(rem * 2048u + (unsigned)nd);
+    if (q >= (unsigned)(ns - 1)) {
+        q = (unsigned)(ns - 1);
+        w_ = 0;
+    }
+    i0 = (int)q;
+    wgt = (int)w_;
+}
+
+// ---- a run of pyramid levels in one launch -------------------------------------------------------------------------------
+// (see PyrChain.)  Two LDS rectangles hold alternate levels and the levels in between are never read back from memory
+// (10.6 -> 7.1 MB of traffic per 1080p frame, 7 launches -> 2).  The arithmetic is orb_resize_kernel's, bit for bit.
+// Measured (profiles/r03_orb_kernels.txt): 2.7 ms per 500 x 1080p against 3.2 ms for the seven per-level launches; with its phases
+// switched off one at a time the kernel splits into 0.6 ms of per-workgroup latency (launch, bounds, barriers: 93 k workgroups,
+// three resident per CU), 0.6 ms source load, 1.4 ms level arithmetic, 0.25 ms stores -- none of them at a hardware roof.
+// One level of a run: `prev` (pitch PP) -> `cur` (pitch CP) and memory.  lane = four adjacent columns, wave = a run of output
+// rows; the wave walks the SOURCE rows of its run once, interpolating each horizontally as it comes (the bytes of the next row
+// are requested before the arithmetic of the current one) and emitting an output row whenever its lower tap has just been
+// interpolated -- its upper tap is then the row before (taps of consecutive output rows are strictly increasing, checked on
+// the host).  All row decisions are wave-uniform.
+struct PyLevel {
+    int wd, pd, lox, ohx, ohy, loy, nhy, ax, nq, rows;
+    uint8_t *dst;
+};
+template <int PP, int CP>
+__device__ __forceinline__ void py_level(const PyLevel L, const uint8_t *prev, uint8_t *cur, const int4 *s_col, const int4 *s_row, int tid) {
+    const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // (scalar: the row loop is uniform control flow)
+    constexpr int NW = PY_THREADS / 64;
+    const int per = (L.rows + NW - 1) / NW;
+    const int ya = wv * per, yb = min(ya + per, L.rows);
+    if (ya >= yb) return;
+    for (int q = lane; q < L.nq; q += 64) {
+        int wx[4], ux[4];
+        const uint8_t *p0[4], *p1[4];
+        const int4 first = s_row[ya], last = s_row[yb - 1];
+        int t = __builtin_amdgcn_readfirstlane(first.x);
+        const int t_last = __builtin_amdgcn_readfirstlane(last.y);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int4 e = s_col[4 * q + k];
+            p0[k] = prev + t * PP + e.x;
+            p1[k] = prev + t * PP + e.y;
+            wx[k] = e.z & 0xFFF;      // (weights are 0 .. 2047: known bits let the compiler pick the 24-bit multiplier)
+            ux[k] = 2048 - wx[k];
+        }
+        const int x4 = L.ax + 4 * q;
+        const bool full = x4 >= L.lox && x4 + 3 <= L.ohx;
+        const int live = min(max(L.wd - x4, 0), 4);      // columns of the quad inside the image (the rest is zero padding)
+        const uint32_t keep = live >= 4 ? 0xFFFFFFFFu : ((1u << (8 * live)) - 1u);
+        uint8_t *curq = cur + 4 * q;
+        int i = ya;
+        int r0 = t, r1 = __builtin_amdgcn_readfirstlane(first.y), wy = __builtin_amdgcn_readfirstlane(first.z) & 0xFFF;
+        int a[8], bb[8], h0[4] = {0, 0, 0, 0}, h1[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            a[k] = p0[k][0];
+            a[4 + k] = p1[k][0];
+        }
+        // one source row: request the next one into `nx` at row offset OFF, interpolate `cu` into `hc`, emit if due
+        auto step = [&](const int (&cu)[8], int (&nx)[8], const int (&hp)[4], int (&hc)[4], const int OFF) {
+            if (t < t_last) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    nx[k] = p0[k][OFF];
+                    nx[4 + k] = p1[k][OFF];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) hc[k] = mad24(cu[k], ux[k], mul24(cu[4 + k], wx[k]));
+            if (t == r1) {
+                const int uy = 2048 - wy;
+                uint32_t packed = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int top = r0 == r1 ? hc[k] : hp[k];
+                    const uint32_t v = (uint32_t)mad24(top, uy, mad24(hc[k], wy, 1 << 21)) >> 22;
+                    packed |= v << (8 * k);
+                }
+                packed &= keep;
+                *reinterpret_cast<uint32_t *>(curq + i * CP) = packed;
+                const int y = L.loy + i;
+                if (y <= L.ohy && full) *reinterpret_cast<uint32_t *>(L.dst + (size_t)y * L.pd + x4) = packed;
+                ++i;
+                if (i < yb) {
+                    const int4 e = s_row[i];
+                    r0 = __builtin_amdgcn_readfirstlane(e.x);
+                    r1 = __builtin_amdgcn_readfirstlane(e.y);
+                    wy = __builtin_amdgcn_readfirstlane(e.z) & 0xFFF;
+                }
+            }
+            ++t;
+        };
+        while (t <= t_last) {
+            step(a, bb, h0, h1, PP);
+            if (t > t_last) break;
+            step(bb, a, h1, h0, 2 * PP);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                p0[k] += 2 * PP;
+                p1[k] += 2 * PP;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(PY_THREADS) void orb_pyramid_kernel(OrbGeom g, const uint8_t *__restrict__ imgs, uint8_t *__restrict__ ws,
+                                                                int c) {
+    __shared__ __attribute__((aligned(16))) uint8_t bufA[PY_BUF_A];
+    __shared__ __attribute__((aligned(16))) uint8_t bufB[PY_BUF_B];
+    __shared__ int4 s_col[PY_TABX], s_row[PY_TABY];      // {tap 0, tap 1, weight, -} relative to the previous rectangle
+    const PyrChain ch = g.chain[c];
+    const int tx = blockIdx.x, ty = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+    const int32_t *BX = reinterpret_cast<const int32_t *>(ws + ch.bnd_off), *BY = BX + py_dim_words(ch.n, ch.ntx);
+    // all bounds of this tile up front (uniform: scalar loads, one latency instead of one per level)
+    int LX[PY_MAXN + 1], NX[PY_MAXN + 1], OX[PY_MAXN + 1], LY[PY_MAXN + 1], NY[PY_MAXN + 1], OY[PY_MAXN + 1];
+#pragma unroll
+    for (int j = 0; j <= PY_MAXN; ++j) {
+        const int jj = j <= ch.n ? j : ch.n;
+        LX[j] = BX[py_x_lo(jj, tx, ch.ntx)];
+        OX[j] = BX[py_x_lo(jj, tx + 1, ch.ntx)] - 1;
+        NX[j] = BX[py_x_nh(jj, tx, ch.n, ch.ntx)];
+        LY[j] = BY[py_x_lo(jj, ty, ch.nty)];
+        OY[j] = BY[py_x_lo(jj, ty + 1, ch.nty)] - 1;
+        NY[j] = BY[py_x_nh(jj, ty, ch.n, ch.nty)];
+    }
+    // the source rectangle
+    int pax = LX[0] & ~3, ploy = LY[0];
+    {
+        int ps;
+        const uint8_t *src = level_ptr(g, imgs, ws, ch.src, b, ps);
+        const int nw4 = (NX[0] - pax) / 4 + 1, nrow = NY[0] - ploy + 1;
+        const unsigned inv20 = ((1u << 20) + nw4 - 1) / nw4;      // e / nw4 for e < 2^20 / nw4 (e < 74 * 70)
+        for (int e = tid; e < nrow * nw4; e += PY_THREADS) {
+            const int r = (int)(((unsigned)e * inv20) >> 20), c4 = e - r * nw4;
+            const int x = pax + 4 * c4;
+            const uint8_t *rowp = src + (size_t)(ploy + r) * ps;
+            uint32_t v = 0;
+            if (x + 3 < ps) v = *reinterpret_cast<const uint32_t *>(rowp + x);
+            else
+                for (int k = 0; k < 4; ++k)
+                    if (x + k < ps) v |= (uint32_t)rowp[x + k] << (8 * k);
+            *reinterpret_cast<uint32_t *>(bufA + r * PY_PITCH_A + 4 * c4) = v;
+        }
+    }
+#pragma unroll
+    for (int j = 1; j <= PY_MAXN; ++j) {
+        if (j > ch.n) break;
+        const int l = ch.src + j;
+        const uint8_t *prev = (j & 1) ? bufA : bufB;
+        uint8_t *cur = (j & 1) ? bufB : bufA;
+        const int cp = (j & 1) ? PY_PITCH_B : PY_PITCH_A;
+        const int wd = g.w[l], hd = g.h[l], pd = g.pitch[l], ws_ = g.w[l - 1], hs_ = g.h[l - 1];
+        PyLevel L;
+        L.wd = wd;
+        L.pd = pd;
+        L.lox = LX[j];
+        L.loy = LY[j];
+        L.nhy = NY[j];
+        L.ohy = OY[j];
+        // what this workgroup writes to memory: its own columns (the last tile also the zero padding of the word wd - 1 is in)
+        L.ohx = tx == ch.ntx - 1 ? min(pd - 1, (wd - 1) | 3) : OX[j];
+        const int chx = max(NX[j], L.ohx);      // last column computed
+        L.ax = L.lox & ~3;
+        L.nq = chx >= L.lox ? (chx - L.ax) / 4 + 1 : 0;
+        L.rows = L.nhy - L.loy + 1;
+        L.dst = ws + g.pyr_off[l] + (size_t)b * g.pyr_bytes[l];
+        // taps (row taps as row INDICES of the previous rectangle) and weights
+        for (int i = tid; i < 4 * L.nq + L.rows; i += PY_THREADS) {
+            if (i < 4 * L.nq) {
+                int x0, wx_;
+                rz_coord(min(max(L.ax + i, L.lox), wd - 1), wd, ws_, x0, wx_);
+                s_col[i] = make_int4(x0 - pax, min(x0 + 1, ws_ - 1) - pax, wx_, 0);
+            } else {
+                int y0, wy_;
+                rz_coord(L.loy + i - 4 * L.nq, hd, hs_, y0, wy_);
+                s_row[i - 4 * L.nq] = make_int4(y0 - ploy, min(y0 + 1, hs_ - 1) - ploy, wy_, 0);
+            }
+        }
+        __syncthreads();      // (also: the previous level is complete in `prev`)
+        if (L.nq > 0 && L.rows > 0) {
+            if (j & 1) py_level<PY_PITCH_A, PY_PITCH_B>(L, prev, cur, s_col, s_row, tid);
+            else py_level<PY_PITCH_B, PY_PITCH_A>(L, prev, cur, s_col, s_row, tid);
+            // the (at most two) words of a row that straddle the boundary to a neighbouring tile: byte by byte, from LDS
+            __syncthreads();
+            const int nown = min(L.ohy, L.nhy) - L.loy + 1;
+            for (int e = tid; e < 2 * nown; e += PY_THREADS) {
+                const int i = e >> 1, x4 = (e & 1) ? (L.ohx & ~3) : L.ax;
+                if ((e & 1) && x4 == L.ax) continue;
+                if (x4 >= L.lox && x4 + 3 <= L.ohx) continue;      // a full word: written above
+                const uint32_t v = *reinterpret_cast<const uint32_t *>(cur + i * cp + (x4 - L.ax));
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (x4 + k >= L.lox && x4 + k <= L.ohx) L.dst[(size_t)(L.loy + i) * pd + x4 + k] = (uint8_t)(v >> (8 * k));
+            }
+        }
+        // the rest of the row padding (last tile of a row): zeros, as the per-level kernel leaves it
+        if (tx == ch.ntx - 1) {
+            const int z0 = ((wd - 1) | 3) + 1, nz4 = (pd - z0) / 4, nown = L.ohy - L.loy + 1;
+            for (int e = tid; e < nz4 * nown; e += PY_THREADS) {
+                const int r = e / nz4, c4 = e - r * nz4;
+                *reinterpret_cast<uint32_t *>(L.dst + (size_t)(L.loy + r) * pd + z0 + 4 * c4) = 0;
+            }
+        }
+        pax = L.ax;
+        ploy = L.loy;
+        __syncthreads();      // (the tables are rewritten, `prev` becomes the next target)
     }
 }
 
@@ -791,6 +1114,55 @@ int build_geom(int batch, int H, int W, int stride, const mm_orb_params *prm, Or
         g.tab_off[l] = off;
         off += mm_align_up((size_t)(2 * g.w[l] + 2 * g.h[l]) * 4, 256);
     }
+    // the pyramid as runs of levels per launch, where the rectangles of a run fit the fused kernel's LDS buffers
+    g.nchains = 0;
+    for (int src = 0; src + 1 < g.nlevels; ) {
+        PyrChain &ch = g.chain[g.nchains++];
+        ch.src = src;
+        ch.n = src == 0 ? (g.nlevels - 1 < 3 ? g.nlevels - 1 : 3) : g.nlevels - 1 - src;      // (MAXL = 8: 3 + 4)
+        ch.ntx = (g.w[src] + PY_TW - 1) / PY_TW;
+        ch.nty = (g.h[src] + PY_TH - 1) / PY_TH;
+        ch.bnd_off = off;
+        const int wx_ = py_dim_words(ch.n, ch.ntx), wy_ = py_dim_words(ch.n, ch.nty);
+        off += mm_align_up((size_t)(wx_ + wy_) * 4, 256);
+        std::vector<int32_t> bx(wx_), by(wy_);
+        int dw[PY_MAXN + 1], dh[PY_MAXN + 1];
+        for (int j = 0; j <= ch.n; ++j) {
+            dw[j] = g.w[src + j];
+            dh[j] = g.h[src + j];
+        }
+        for (int t = 0; t <= ch.ntx; ++t) py_bounds_lo(t, ch.ntx, PY_TW, ch.n, dw, bx.data());
+        for (int t = 0; t <= ch.nty; ++t) py_bounds_lo(t, ch.nty, PY_TH, ch.n, dh, by.data());
+        for (int t = 0; t < ch.ntx; ++t) py_bounds_nh(t, ch.ntx, ch.n, dw, bx.data());
+        for (int t = 0; t < ch.nty; ++t) py_bounds_nh(t, ch.nty, ch.n, dh, by.data());
+        bool fits = ch.ntx <= 65535 && ch.nty <= 65535;
+        for (int j = 1; j <= ch.n && fits; ++j) {      // the kernel walks source rows: lower taps strictly increasing, one apart
+            int prev_r1 = -1;
+            for (int y = 0; y < dh[j] && fits; ++y) {
+                const int y0 = rz_src0(y, dh[j], dh[j - 1]), r1 = std::min(y0 + 1, dh[j - 1] - 1);
+                if (r1 <= prev_r1) fits = false;
+                prev_r1 = r1;
+            }
+        }
+        for (int j = 0; j <= ch.n && fits; ++j) {
+            const int pitch_ = (j & 1) ? PY_PITCH_B : PY_PITCH_A, cap_ = (j & 1) ? PY_BUF_B : PY_BUF_A;
+            for (int tx = 0; tx < ch.ntx && fits; ++tx) {
+                const int lo = bx[py_x_lo(j, tx, ch.ntx)], nh = bx[py_x_nh(j, tx, ch.n, ch.ntx)];
+                int ohx = bx[py_x_lo(j, tx + 1, ch.ntx)] - 1;
+                if (j > 0 && tx == ch.ntx - 1) ohx = std::min(g.pitch[src + j] - 1, (dw[j] - 1) | 3);
+                const int chx = std::max(nh, ohx);
+                const int nq = chx >= lo ? (chx - (lo & ~3)) / 4 + 1 : 0;
+                if (4 * nq + 4 > pitch_ || (j > 0 && 4 * nq > PY_TABX)) fits = false;
+            }
+            for (int ty = 0; ty < ch.nty && fits; ++ty) {
+                const int rows = by[py_x_nh(j, ty, ch.n, ch.nty)] - by[py_x_lo(j, ty, ch.nty)] + 1;
+                if ((j > 0 && rows > PY_TABY) || rows * pitch_ > cap_) fits = false;
+            }
+        }
+        ch.fused = fits ? 1 : 0;
+        src += ch.n;
+        if (g.nchains == 2) break;
+    }
     int nmax = 0;
     for (int l = 0; l < g.nlevels; ++l) nmax = g.nfeat[l] > nmax ? g.nfeat[l] : nmax;
     g.kcap = 2 * nmax + 8;
@@ -857,16 +1229,25 @@ int mm_orb_detect_compute(mm_ctx *ctx, const uint8_t *imgs, int batch, int heigh
     // counters, kept counters and histograms are contiguous: [cnt_off, thr_off)
     MM_HIP(ctx, hipMemsetAsync(w8 + g.cnt_off, 0, g.thr_off - g.cnt_off, st));
     if (g.nlevels > 1) {
-        MM_LAUNCH(ctx, "orb_tables_kernel", orb_tables_kernel, dim3(g.nlevels - 1), dim3(256), 0, g, w8);
-        for (int l = 1; l < g.nlevels; ++l) {
-            // output tile whose source footprint fits the kernel's LDS tile (256 x 16 for any scale factor <= 1.2)
-            const double rx = (double)g.w[l - 1] / g.w[l], ry = (double)g.h[l - 1] / g.h[l];
-            int tw = (int)((RZ_SW - 8) / rx) & ~3, th = (int)((RZ_SR - 2) / ry);
-            tw = tw > RZ_TW ? RZ_TW : (tw < 4 ? 4 : tw);
-            th = th > RZ_TH ? RZ_TH : (th < 1 ? 1 : th);
-            if (rx > (RZ_SW - 8) / 4.0 || ry > RZ_SR - 2) return mm_fail(ctx, MM_ERR_ARG, "mm_orb_detect_compute: scale factor too large");
-            dim3 grid((g.pitch[l] + tw - 1) / tw, (g.h[l] + th - 1) / th, batch);
-            MM_LAUNCH(ctx, "orb_resize_kernel", orb_resize_kernel, grid, dim3(256), 0, g, imgs, w8, l, tw, th);
+        const char *pyr_env = getenv("MM_ORB_PYRAMID");
+        const bool per_level = pyr_env && pyr_env[0] == 'l';      // MM_ORB_PYRAMID=levels: one launch per level (cross-check)
+        MM_LAUNCH(ctx, "orb_tables_kernel", orb_tables_kernel, dim3(g.nlevels - 1 + g.nchains), dim3(256), 0, g, w8);
+        for (int c = 0; c < g.nchains; ++c) {
+            const PyrChain &ch = g.chain[c];
+            if (ch.fused && !per_level) {
+                MM_LAUNCH(ctx, "orb_pyramid_kernel", orb_pyramid_kernel, dim3(ch.ntx, ch.nty, batch), dim3(PY_THREADS), 0, g, imgs, w8, c);
+                continue;
+            }
+            for (int l = ch.src + 1; l <= ch.src + ch.n; ++l) {
+                // output tile whose source footprint fits the kernel's LDS tile (256 x 16 for any scale factor <= 1.2)
+                const double rx = (double)g.w[l - 1] / g.w[l], ry = (double)g.h[l - 1] / g.h[l];
+                int tw = (int)((RZ_SW - 8) / rx) & ~3, th = (int)((RZ_SR - 2) / ry);
+                tw = tw > RZ_TW ? RZ_TW : (tw < 4 ? 4 : tw);
+                th = th > RZ_TH ? RZ_TH : (th < 1 ? 1 : th);
+                if (rx > (RZ_SW - 8) / 4.0 || ry > RZ_SR - 2) return mm_fail(ctx, MM_ERR_ARG, "mm_orb_detect_compute: scale factor too large");
+                dim3 grid((g.pitch[l] + tw - 1) / tw, (g.h[l] + th - 1) / th, batch);
+                MM_LAUNCH(ctx, "orb_resize_kernel", orb_resize_kernel, grid, dim3(256), 0, g, imgs, w8, l, tw, th);
+            }
         }
     }
     if (g.tile_start[g.nlevels] > 0) {

@@ -193,6 +193,47 @@ def test_orb_4k_8000_keypoints_bit_exact():
     _cmp_orb(frames, 8000)
 
 
+def _orb_pyramid_levels(frames, nfeatures, scale_factor=1.2):
+    """The pyramid mm_orb_detect_compute leaves at the head of its workspace: list over levels >= 1 of [B, h, pitch] u8."""
+    B, H, W = frames.shape
+    prm = ops.orb_params(nfeatures)
+    prm.scale_factor = scale_factor
+    wsp = ops.OrbWorkspace(B, H, W, prm, DEV, brief_pattern())
+    wsp.ws.fill_(0xA5)
+    ops.orb_detect_compute(dev(frames), wsp)
+    torch.cuda.synchronize()
+    w, h, _, _ = ops.orb_level_sizes(H, W, prm)
+    ws, off, out = wsp.ws.cpu().numpy(), 0, []
+    for l in range(1, len(w)):
+        pitch = (int(w[l]) + 63) // 64 * 64
+        per = (pitch * int(h[l]) + 64 + 255) // 256 * 256
+        out.append(np.stack([ws[off + b * per: off + b * per + pitch * int(h[l])].reshape(int(h[l]), pitch) for b in range(B)]))
+        off += per * B
+    return out, w, h
+
+
+@pytest.mark.parametrize("W,H,scale", [(640, 480, 1.2), (652, 364, 1.2), (1920, 1080, 1.2), (332, 258, 1.2), (1284, 722, 1.5),
+                                       (800, 600, 1.05), (3840, 2160, 1.2)])
+def test_orb_pyramid_fused_launches_equal_oracle_and_per_level(W, H, scale, monkeypatch):
+    """The pyramid from the fused launches (runs of levels through LDS, halos recomputed) == the per-level kernel == the
+    oracle's resize chain, byte for byte, zero row padding included; odd sizes, other scale factors (1.05: the fused
+    rectangles do not fit and the per-level kernel is taken), 4K."""
+    rng = np.random.default_rng(W + H)
+    frames = rng.integers(0, 256, (2, H, W), dtype=np.uint8)
+    fused, w, h = _orb_pyramid_levels(frames, 500, scale)
+    monkeypatch.setenv("MM_ORB_PYRAMID", "levels")
+    per_level, _, _ = _orb_pyramid_levels(frames, 500, scale)
+    for l, (a, b) in enumerate(zip(fused, per_level), start=1):
+        np.testing.assert_array_equal(a, b, err_msg=f"level {l}")
+        assert not a[:, :, int(w[l]):].any()
+    if scale == 1.2 and W <= 1920:
+        for b in range(2):
+            prev = frames[b]
+            for l in range(1, len(w)):
+                prev = oo.resize(prev, int(w[l]), int(h[l]))
+                np.testing.assert_array_equal(fused[l - 1][b][:, :int(w[l])], prev, err_msg=f"frame {b} level {l}")
+
+
 def test_orb_flat_image_gives_no_keypoints():
     frames = np.full((1, 480, 640), 90, np.uint8)
     n = _orb_gpu(frames, 500)[5]
