@@ -22,6 +22,16 @@
 #include <type_traits>
 #include <cstdlib>
 
+// The single-launch factorisation hands tiles from workgroup to workgroup INSIDE one launch with write-through (sc1)
+// stores, agent-scope relaxed loads and words that are polled for a sentinel value instead of release / acquire fences.
+// That is a property of the CDNA3 / CDNA4 memory system (stores tracked by vmcnt, sc1 stores written through to memory,
+// agent-scope loads missing the other XCDs' L2), not of the HIP memory model: refuse to build for anything else, so that a
+// new target shows up as a compile error and not as a rare wrong factor.  (MM_CHOL_FUSED=0 selects the launch-per-column
+// factorisation, which needs none of this; tests/test_gpu_parity.py runs the parity cases on both.)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "chol.hip: the cross-workgroup hand-over of chol_band_fused_kernel is written for gfx942 / gfx950"
+#endif
+
 namespace {
 
 constexpr int NB = 64;

@@ -139,7 +139,13 @@ __global__ __launch_bounds__(64) void lk_track_kernel(LkLevels L, const float *_
         for (int e = lane; e < npx; e += 64) {
             const int y = e / ww, x = e % ww;
             auto at = [&](int xx, int yy) { return (int)Ipatch[(yy + 1) * cw + xx + 1]; };   // (xx, yy) relative to (ipx, ipy)
+            // (derivative samples outside the image are zero, as in OpenCV's zero-padded derivative image; inside, the taps
+            // reflect at the edges like the staged intensities)
             auto scharr = [&](int xx, int yy, int &dx, int &dy) {
+                if (ipx + xx < 0 || ipx + xx >= W || ipy + yy < 0 || ipy + yy >= H) {
+                    dx = dy = 0;
+                    return;
+                }
                 const int a = at(xx - 1, yy - 1), b = at(xx, yy - 1), c = at(xx + 1, yy - 1);
                 const int d = at(xx - 1, yy), f = at(xx + 1, yy);
                 const int g = at(xx - 1, yy + 1), hh = at(xx, yy + 1), ii = at(xx + 1, yy + 1);

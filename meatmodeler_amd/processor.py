@@ -198,13 +198,14 @@ def _frame_pyramid(frame_grey, max_level, ctx):
     if isinstance(frame_grey, torch.Tensor):
         return ops.pyramid(frame_grey.to(ctx.device).contiguous(), max_level, ctx)
     for ref, lv, pyr in _PYR_CACHE:
-        if ref() is frame_grey and lv == max_level and not frame_grey.flags.writeable:
+        if ref() is frame_grey and lv == max_level and not frame_grey.flags.writeable and frame_grey.base is None:
             return pyr
     img = _upload_u8(frame_grey, ctx.device)
     pyr = ops.pyramid(img, max_level, ctx)
     try:
-        # (only frames that cannot change behind the cache's back are remembered: the caller opts in by freezing them)
-        if not frame_grey.flags.writeable:
+        # (only frames that cannot change behind the cache's back are remembered: the caller opts in by freezing an array
+        # that OWNS its data -- a read-only view of a writable base can still change through the base)
+        if not frame_grey.flags.writeable and frame_grey.base is None:
             _PYR_CACHE.append((weakref.ref(frame_grey), max_level, pyr))
             del _PYR_CACHE[:-2]
     except TypeError:
@@ -214,9 +215,14 @@ def _frame_pyramid(frame_grey, max_level, ctx):
 
 def calcOpticalFlowPyrLK(prevImg, nextImg, prevPts, nextPts=None, winSize=(21, 21), maxLevel=3, criteria=(3, 30, 0.01),
                          **_ignored):
-    """cv2.calcOpticalFlowPyrLK (processor.py:79) -> (nextPts [n,1,2] f32, status [n,1] u8, err [n,1] f32);
-    (None, None, None) without points."""
-    if prevPts is None or len(prevPts) == 0:
+    """cv2.calcOpticalFlowPyrLK (processor.py:79) -> (nextPts [n,1,2] f32, status [n,1] u8, err [n,1] f32).
+    prevPts = None raises, as the cv2 call does (the reference reaches it when goodFeaturesToTrack found no corner at the
+    last keyframe, processor.py:104-110, and fails there -- it must not turn into "never a keyframe again" here);
+    an EMPTY point array gives (None, None, None), cv2's empty outputs."""
+    if prevPts is None:
+        raise ValueError("calcOpticalFlowPyrLK: prevPts is None (no points to track; cv2 raises "
+                         "'(npoints = prevPtsMat.checkVector(2, CV_32F, true)) >= 0' here)")
+    if len(prevPts) == 0:
         return None, None, None
     ctx = default_context()
     pp = _frame_pyramid(prevImg, maxLevel, ctx)

@@ -45,8 +45,14 @@ void frc_pyr_down(const uint8_t *src, int w, int h, int ps, uint8_t *dst, int pd
 }
 
 static inline int pix(const uint8_t *img, int w, int h, int p, int x, int y) { return img[(size_t)refl(y, h) * p + refl(x, w)]; }
-/* Scharr derivatives at integer position (x, y) */
+/* Scharr derivatives at integer position (x, y).  Inside the image the taps reflect (101) at the edges; OUTSIDE it the
+ * derivative is zero: OpenCV pads the derivative image of calcOpticalFlowPyrLK with BORDER_CONSTANT zeros, only the
+ * intensity pyramid continues by reflection (lkpyramid.cpp: calcSharrDeriv + copyMakeBorder(..., BORDER_CONSTANT)). */
 static inline void scharr(const uint8_t *img, int w, int h, int p, int x, int y, int *dx, int *dy) {
+    if (x < 0 || x >= w || y < 0 || y >= h) {
+        *dx = *dy = 0;
+        return;
+    }
     const int a = pix(img, w, h, p, x - 1, y - 1), b = pix(img, w, h, p, x, y - 1), c = pix(img, w, h, p, x + 1, y - 1);
     const int d = pix(img, w, h, p, x - 1, y), f = pix(img, w, h, p, x + 1, y);
     const int g = pix(img, w, h, p, x - 1, y + 1), hh = pix(img, w, h, p, x, y + 1), i = pix(img, w, h, p, x + 1, y + 1);

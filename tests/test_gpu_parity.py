@@ -509,6 +509,33 @@ def test_chol_solve_banded(n, hb):
     np.testing.assert_allclose(L, np.linalg.cholesky(A), rtol=1e-9, atol=1e-10)
 
 
+@pytest.mark.parametrize("n,hb", [(3000, 528), (770, 63), (320, 5)])
+def test_chol_launch_per_column_path_agrees_with_single_launch(n, hb):
+    """The narrow-band shapes again with the context told to avoid the single-launch factorisation (whose cross-workgroup
+    hand-over leans on gfx942 / gfx950 memory-system behaviour, see the guard at the top of chol.hip): the launch-per-column
+    path -- ordinary kernel boundaries, no hand-over inside a launch -- gives the same solution to rounding, so a toolchain or
+    ASIC change that broke the hand-over would show up as a difference between the two."""
+    from meatmodeler_amd._lib import default_context
+    ctx = default_context()
+    rng = np.random.default_rng(n + hb)
+    M = np.tril(np.triu(rng.normal(size=(n, n)), -hb // 2))
+    A = M @ M.T + n * np.eye(n)
+    b = rng.normal(size=n)
+    sols = []
+    for avoid in (0, 1):
+        ctx.control(ctx.CTL_CHOL_AVOID_FUSED, avoid)
+        try:
+            Ad, bd = dev(A), dev(b)
+            assert int(ops.chol_solve(Ad, bd, half_bandwidth=hb)) == 0
+            ctx.sync()
+            sols.append((bd.cpu().numpy(), int(ctx.control(ctx.CTL_CHOL_LAST_PATH))))
+        finally:
+            ctx.control(ctx.CTL_CHOL_AVOID_FUSED, 0)
+    assert sols[0][1] != sols[1][1], "the two runs must have taken different factorisation paths"
+    np.testing.assert_allclose(sols[0][0], sols[1][0], rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(sols[1][0], np.linalg.solve(A, b), rtol=1e-9, atol=1e-12)
+
+
 @pytest.mark.parametrize("both", [True, False])
 @pytest.mark.parametrize("n,hb", [(3000, 528), (1000, 130), (770, 63), (320, 5), (500, 40), (1200, 300), (2048, 64),
                                    (1500, 900)])
@@ -1599,6 +1626,27 @@ def test_lk_track_bit_exact(win, levels, count):
     np.testing.assert_array_equal(nx.cpu().numpy(), nx_o)
     np.testing.assert_array_equal(er.cpu().numpy(), er_o)
     assert st_o.sum() > 200 and st_o[-1] == 0 and st_o[-3] == 0
+
+
+def test_calc_optical_flow_without_points_fails_like_cv2():
+    """prevPts = None (goodFeaturesToTrack found nothing at the last keyframe): the cv2 call of the reference raises
+    (processor.py:79); an empty point array yields empty outputs.  And the pyramid cache only trusts frozen arrays that own
+    their data: a read-only VIEW of a writable frame is re-uploaded when the frame changes underneath."""
+    rng = np.random.default_rng(2)
+    a = rng.integers(0, 256, (120, 160), dtype=np.uint8)
+    b = np.roll(a, 2, axis=1)
+    with pytest.raises(ValueError):
+        processor.calcOpticalFlowPyrLK(a, b, None)
+    assert processor.calcOpticalFlowPyrLK(a, b, np.zeros((0, 1, 2), np.float32)) == (None, None, None)
+    pts = np.array([[[80.0, 60.0]]], np.float32)
+    view = a.view()
+    view.flags.writeable = False
+    p1, st1, _ = processor.calcOpticalFlowPyrLK(view, b, pts)
+    a[:] = np.roll(a, 5, axis=1)                     # the base changes behind the read-only view
+    p2, st2, _ = processor.calcOpticalFlowPyrLK(view, b, pts)
+    po, so, _ = fo.lk_track(a, b, pts.reshape(-1, 2), (21, 21), 3, 30, 0.01)
+    np.testing.assert_array_equal(p2.reshape(-1, 2), po)
+    assert st1[0, 0] == 1 and not np.array_equal(p1, p2)
 
 
 def test_lk_track_recovers_a_known_shift():
