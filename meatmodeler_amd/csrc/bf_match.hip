@@ -885,12 +885,18 @@ template <int WAVES, bool PIPE>
 __global__ __launch_bounds__(BF_THREADS, WAVES) void bf_knn2_fp4min_kernel(
     const uint8_t *__restrict__ q, const int32_t *__restrict__ nq_dev, int nq_cap, size_t q_stride,
     const uint8_t *__restrict__ tx, const uint8_t *__restrict__ tpk, size_t t_stride, const int32_t *__restrict__ nt_dev,
-    int nt_cap, int ntp, int32_t *__restrict__ idx, int32_t *__restrict__ dist) {
+    int nt_cap, int ntp, int32_t *__restrict__ idx, int32_t *__restrict__ dist, int qtiles, int n_pairs) {
     __shared__ __attribute__((aligned(16))) uint8_t tile[3][MF_TT][F4_PITCH];
-    const int pair = blockIdx.z;
+    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so the linear id is read as
+    // (slot, xcd) and an XCD walks ITS pairs one after the other, all query tiles of a pair side by side: the expanded
+    // train set of a pair (512 KB at 4000 key points) is fetched into one L2 instead of into all eight.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int grp = slot / qtiles;
+    const int pair = grp * 8 + xcd;
+    if (pair >= n_pairs) return;      // (padding of the last group of eight pairs)
     const int nq = nq_dev ? min(nq_dev[pair], nq_cap) : nq_cap;
     const int nt = nt_dev ? min(nt_dev[pair], nt_cap) : nt_cap;
-    const int qbase = blockIdx.x * BF_THREADS;
+    const int qbase = (slot - grp * qtiles) * BF_THREADS;
     if (qbase >= nq) return;  // workgroup-uniform
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int c = lane & 31, h = lane >> 5;
@@ -1105,7 +1111,7 @@ __global__ __launch_bounds__(BF_THREADS, WAVES) void bf_knn2_fp4min_kernel(
     }
 #ifdef MM_BF_CLOCK
     if (threadIdx.x == 0) {
-        const unsigned w = (blockIdx.z * gridDim.x + blockIdx.x) & 4095u;
+        const unsigned w = blockIdx.x & 4095u;
         g_bf_clock[2 * w] = __builtin_readcyclecounter() - clk_t0;
         g_bf_clock[2 * w + 1] = (long long)(__builtin_amdgcn_s_memrealtime() - clk_r0);
     }
@@ -1187,14 +1193,16 @@ int mm_bf_knn2_batched(mm_ctx *ctx, const uint8_t *q, const int32_t *nq, int nq_
             const size_t chunks = (size_t)n_pairs * ntp * 8;
             MM_LAUNCH(ctx, "bf_expand_kernel", bf_expand_fp4_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, t, nt_cap,
                       t_set_stride, ntp, n_pairs, (uint8_t *)ws);
+            const int qtiles = (int)grid.x;
+            const dim3 grid_x(8u * (unsigned)((n_pairs + 7) / 8) * grid.x);      // (slot, xcd): see the kernel
             if (bf_variant(n_pairs, nq_cap) == 310) {
-                MM_LAUNCH(ctx, "bf_knn2_fp4min_kernel", (bf_knn2_fp4min_kernel<3, true>), grid, dim3(BF_THREADS), 0, q, nq, nq_cap, q_set_stride,
-                          (const uint8_t *)ws, t, t_set_stride, nt, nt_cap, ntp, idx, dist);
+                MM_LAUNCH(ctx, "bf_knn2_fp4min_kernel", (bf_knn2_fp4min_kernel<3, true>), grid_x, dim3(BF_THREADS), 0, q, nq, nq_cap, q_set_stride,
+                          (const uint8_t *)ws, t, t_set_stride, nt, nt_cap, ntp, idx, dist, qtiles, n_pairs);
                 return MM_OK;
             }
             if (bf_variant(n_pairs, nq_cap) == 314) {
-                MM_LAUNCH(ctx, "bf_knn2_fp4min_kernel", (bf_knn2_fp4min_kernel<4, false>), grid, dim3(BF_THREADS), 0, q, nq, nq_cap, q_set_stride,
-                          (const uint8_t *)ws, t, t_set_stride, nt, nt_cap, ntp, idx, dist);
+                MM_LAUNCH(ctx, "bf_knn2_fp4min_kernel", (bf_knn2_fp4min_kernel<4, false>), grid_x, dim3(BF_THREADS), 0, q, nq, nq_cap, q_set_stride,
+                          (const uint8_t *)ws, t, t_set_stride, nt, nt_cap, ntp, idx, dist, qtiles, n_pairs);
                 return MM_OK;
             }
             MM_LAUNCH(ctx, "bf_knn2_fp4_kernel", bf_knn2_fp4_kernel, grid, dim3(BF_THREADS), 0, q, nq, nq_cap, q_set_stride,
