@@ -45,9 +45,9 @@ __device__ __forceinline__ int mad24(int a, int b, int c) {
 // the owned ranges are intervals that partition every level); the few columns / rows beyond, needed as right / lower taps
 // further down, are recomputed (bit-identical) rather than exchanged.  Bounds per tile boundary, as int32 in the workspace:
 //   X: lo[j][0..ntx] (j = 0..n: first owned column at run level j), nh[j][0..ntx-1] (last needed column); then Y likewise.
-constexpr int PY_MAXN = 4, PY_TW = 256, PY_TH = 64, PY_THREADS = 512;
-constexpr int PY_PITCH_A = 280, PY_PITCH_B = 236;      // LDS pitches of the two rectangles (compile-time: row steps are immediates)
-constexpr int PY_BUF_A = 20720, PY_BUF_B = 15340, PY_TABX = 288, PY_TABY = 96;      // 74 rows x 280, 65 rows x 236
+constexpr int PY_MAXN = 4, PY_TW = 192, PY_TH = 64, PY_THREADS = 512;
+constexpr int PY_PITCH_A = 216, PY_PITCH_B = 184;      // LDS pitches of the two rectangles (compile-time: row steps are immediates)
+constexpr int PY_BUF_A = 15984, PY_BUF_B = 11960, PY_TABX = 224, PY_TABY = 96;      // 74 rows x 216, 65 rows x 184: 34 KB with the tables, 4 workgroups per CU
 struct PyrChain {
     int src, n;              // source level, levels produced (src + 1 .. src + n)
     int ntx, nty;
@@ -282,9 +282,9 @@ __device__ __forceinline__ void rz_coord(int d, int nd, int ns, int &i0, int &wg
 // ---- a run of pyramid levels in one launch -------------------------------------------------------------------------------
 // (see PyrChain.)  Two LDS rectangles hold alternate levels and the levels in between are never read back from memory
 // (10.6 -> 7.1 MB of traffic per 1080p frame, 7 launches -> 2).  The arithmetic is orb_resize_kernel's, bit for bit.
-// Measured (profiles/r03_orb_kernels.txt): 2.7 ms per 500 x 1080p against 3.2 ms for the seven per-level launches; with its phases
-// switched off one at a time the kernel splits into 0.6 ms of per-workgroup latency (launch, bounds, barriers: 93 k workgroups,
-// three resident per CU), 0.6 ms source load, 1.4 ms level arithmetic, 0.25 ms stores -- none of them at a hardware roof.
+// Measured (profiles/r03_orb_kernels.txt): 2.55 ms per 500 x 1080p against 3.2 ms for the seven per-level launches; with its phases
+// switched off one at a time the kernel (256-wide tiles then) split into 0.6 ms of per-workgroup latency (launch, bounds,
+// barriers: 93 k workgroups, three resident per CU), 0.6 ms source load, 1.4 ms level arithmetic, 0.25 ms stores -- none of them at a hardware roof.
 // One level of a run: `prev` (pitch PP) -> `cur` (pitch CP) and memory.  lane = four adjacent columns, wave = a run of output
 // rows; the wave walks the SOURCE rows of its run once, interpolating each horizontally as it comes (the bytes of the next row
 // are requested before the arithmetic of the current one) and emitting an output row whenever its lower tap has just been
