@@ -1327,17 +1327,24 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, TwGeom 
         // start -- nothing depends on them until the streamed solve, and two tile loads at the end of the row would sit on
         // the critical chain  L_{r-1,r-2} -> product with it -> streamed solve behind the factorisation of L_{r-1,r-1}.
         // (The first two rows of M wait for their pre-accumulators, which finish late: they fetch before the last column.)
+        // The FIRST row of M is special: its block left of the diagonal, (a, a - 1), is an ordinary block of T, while its
+        // diagonal block waits for a pre-accumulator that needs the other end's last column -- the latest thing in the whole
+        // factorisation.  Its solve must not queue behind that wait (the pre-accumulators of column a wait for L_{a,a-1} in
+        // turn, and the next rows for them): the diagonal tile is fetched after the streamed solve, where it is first used.
+        const bool defer_diag = diag_pre && r == g.a && has_sub;
         bool fetched = false, fetch_ok = true;
         auto fetch_own = [&]() __attribute__((always_inline)) {
             fetched = true;
-            if (diag_pre && !wg_wait<MODE>(pflag(r - g.a, r - g.a), sub_pre ? pflag(r - g.a, r - 1 - g.a) : nullptr, abort_flag, &s_ok)) fetch_ok = false;
+            if (diag_pre && !defer_diag &&
+                !wg_wait<MODE>(pflag(r - g.a, r - g.a), sub_pre ? pflag(r - g.a, r - 1 - g.a) : nullptr, abort_flag, &s_ok))
+                fetch_ok = false;
             if (fetch_ok && diag_here && !rows_ready(nat(side, r))) fetch_ok = false;
             if (fetch_ok && side == 1 && has_sub && !rows_ready(nat(1, r - 1))) fetch_ok = false;
             if (!fetch_ok) return;
-            if (diag_here) load_tile_shared<MODE>(Ds, dt);      // (the upper triangle is masked where the tile is used)
+            if (diag_here && !defer_diag) load_tile_shared<MODE>(Ds, dt);      // (the upper triangle is masked where the tile is used)
             if (has_sub) load_tile_shared<MODE>(Ss, st);
         };
-        if (!diag_pre || r >= g.a + 2) {
+        if (!diag_pre || r >= g.a + 2 || defer_diag) {
             fetch_own();
             if (!fetch_ok) MM_FUSED_ABANDON;
         }
@@ -1456,6 +1463,10 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, TwGeom 
             }
             __syncthreads();
             continue;
+        }
+        if (defer_diag) {      // (see above: the first row of M takes its pre-accumulated diagonal tile only now)
+            if (!wg_wait<MODE>(pflag(0, 0), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
+            load_tile_shared<MODE>(Ds, dt);
         }
         __syncthreads();  // As / Bs are reused as M / X from here
         MM_ACC_FOREACH(M[row][col] = (dt.rv(row) && dt.cv(col) && col <= row) ? Ds[row][col] - acc[a][b][i]
