@@ -1669,6 +1669,33 @@ def test_two_ranks_on_one_gpu_real_kernels_match_one_rank(tmp_path):
     assert np.all(np.abs(r0["win_cost"] - one["win_cost"]) <= 0.3 * one["win_cost"])
 
 
+def test_library_dist_loop_over_rccl_one_rank(tmp_path):
+    """backend "nccl" (RCCL) under the sharded library loop, as far as one GPU allows: one rank whose all-reduce always goes
+    through torch.distributed.  The sums are trivial, the path is the real one (ProcessGroupNCCL on views of the library's
+    workspace, ordered on the library's stream, seven calls per evaluation): same evaluations and cost as mm_ba_trf."""
+    import socket
+    import subprocess
+    import sys
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    out = os.path.join(str(tmp_path), "rccl1.npz")
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_rccl_one_rank_worker.py")
+    p = subprocess.run([sys.executable, worker, out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert p.returncode == 0, p.stdout.decode(errors="replace")[-4000:]
+    d = np.load(out)
+    assert str(d["backend"]) == "nccl"
+    assert int(d["nfev"][0]) == int(d["nfev"][1]) and int(d["status"][0]) == int(d["status"][1]) > 0
+    assert abs(float(d["cost"][0]) - float(d["cost"][1])) <= 1e-10 * float(d["cost"][0])
+    np.testing.assert_allclose(d["cams_rccl"], d["cams_plain"], rtol=0, atol=1e-7)
+    # every collective of the library loop went through the process group (+ the initial cost and the span reduction of the
+    # Python prologue)
+    assert int(d["collectives"]) > 0 and int(d["calls"]) == int(d["collectives"]) + 2
+    assert int(d["collectives"]) <= 7 * int(d["nfev"][1]) + 3
+
+
 # ============================================================================================== keyframe gating, contrast
 
 from oracle import frame_oracle as fo  # noqa: E402
