@@ -250,30 +250,34 @@ __global__ __launch_bounds__(64 * SP_WAVES, 2) void schur_pairs_kernel(mm_ba_pro
         ba_eval_vals<true, true>(cv_i, Xp, Ks, pb.obs[2 * (size_t)o], pb.obs[2 * (size_t)o + 1], pr);
         const double *ci = Cinv + (size_t)p * 6;
         const double q00 = ci[0], q01 = ci[1], q02 = ci[2], q11 = ci[3], q12 = ci[4], q22 = ci[5];
-        double Y[6][3];
+        // E_o C^-1 E_o2^T = Jc_o^T (Jp_o C^-1 Jp_o2^T) Jc_o2: the middle factor is 2 x 2, so the 6 x 6 block costs
+        // 18 + 12 + 24 + 72 multiply-adds through Z = Jp_o C^-1 (2 x 3), M = Z Jp_o2^T (2 x 2), T = M Jc_o2 (2 x 6)
+        // instead of 90 + 36 + 108 through the two 6 x 3 products E_o C^-1 and E_o2
+        double Z[2][3];
 #pragma unroll
-        for (int a = 0; a < 6; ++a) {
-            const double x0 = pr.Jc[0][a] * pr.Jp[0][0] + pr.Jc[1][a] * pr.Jp[1][0];
-            const double x1 = pr.Jc[0][a] * pr.Jp[0][1] + pr.Jc[1][a] * pr.Jp[1][1];
-            const double x2 = pr.Jc[0][a] * pr.Jp[0][2] + pr.Jc[1][a] * pr.Jp[1][2];
-            Y[a][0] = x0 * q00 + x1 * q01 + x2 * q02;
-            Y[a][1] = x0 * q01 + x1 * q11 + x2 * q12;
-            Y[a][2] = x0 * q02 + x1 * q12 + x2 * q22;
+        for (int m = 0; m < 2; ++m) {
+            Z[m][0] = pr.Jp[m][0] * q00 + pr.Jp[m][1] * q01 + pr.Jp[m][2] * q02;
+            Z[m][1] = pr.Jp[m][0] * q01 + pr.Jp[m][1] * q11 + pr.Jp[m][2] * q12;
+            Z[m][2] = pr.Jp[m][0] * q02 + pr.Jp[m][1] * q12 + pr.Jp[m][2] * q22;
         }
         if (o2 == o) {  // self pair: once per observation -> right-hand side
             const double g0 = gp[(size_t)p * 3], g1 = gp[(size_t)p * 3 + 1], g2 = gp[(size_t)p * 3 + 2];
+            const double z0 = Z[0][0] * g0 + Z[0][1] * g1 + Z[0][2] * g2, z1 = Z[1][0] * g0 + Z[1][1] * g1 + Z[1][2] * g2;
 #pragma unroll
-            for (int a = 0; a < 6; ++a) acc[36 + a] += Y[a][0] * g0 + Y[a][1] * g1 + Y[a][2] * g2;
+            for (int a = 0; a < 6; ++a) acc[36 + a] += pr.Jc[0][a] * z0 + pr.Jc[1][a] * z1;
         }
         Proj p2;
         ba_eval_vals<true, true>(cv_2, Xp, Ks, pb.obs[2 * (size_t)o2], pb.obs[2 * (size_t)o2 + 1], p2);
+        double M[2][2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n_ = 0; n_ < 2; ++n_) M[m][n_] = Z[m][0] * p2.Jp[n_][0] + Z[m][1] * p2.Jp[n_][1] + Z[m][2] * p2.Jp[n_][2];
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
-            const double x0 = p2.Jc[0][b] * p2.Jp[0][0] + p2.Jc[1][b] * p2.Jp[1][0];
-            const double x1 = p2.Jc[0][b] * p2.Jp[0][1] + p2.Jc[1][b] * p2.Jp[1][1];
-            const double x2 = p2.Jc[0][b] * p2.Jp[0][2] + p2.Jc[1][b] * p2.Jp[1][2];
+            const double t0 = M[0][0] * p2.Jc[0][b] + M[0][1] * p2.Jc[1][b], t1 = M[1][0] * p2.Jc[0][b] + M[1][1] * p2.Jc[1][b];
 #pragma unroll
-            for (int a = 0; a < 6; ++a) acc[a * 6 + b] += Y[a][0] * x0 + Y[a][1] * x1 + Y[a][2] * x2;
+            for (int a = 0; a < 6; ++a) acc[a * 6 + b] += pr.Jc[0][a] * t0 + pr.Jc[1][a] * t1;
         }
     };
     const int trips = (e_end - e_begin + 63) / 64;   // wave-uniform
