@@ -410,6 +410,10 @@ __global__ __launch_bounds__(256) void link_emit_kernel(LinkWs ws, const int32_t
 // has(n) itself = some EFFECTIVE edge arrives: the last match of any node always is (continuation or birth), the other
 // matches of a node with several (key points with equal coordinates) only if that node has no track: resolved by a
 // fixed-point pass over those few matches (layered by frame: exact after as many rounds as such nodes chain up).
+// Cost of that pass: one workgroup, three sweeps over the uncertain matches per round (36 us at 500 x 4000, 0.64 ms at
+// 2000 x 8000 key points, where ORB levels produce more coincident coordinates); the loop is bounded by the number of frames.
+// A clip whose key points ALL share one coordinate (every match uncertain, chains as long as the clip) is the worst case:
+// seconds, not a hang -- MM_LINK_VARIANT=serial has no such case and is what to use for synthetic stress inputs of that kind.
 struct ParWs {
     int32_t *canon;                  // [F, cap]
     int32_t *lastm, *jump[2];        // nodes [F cap]: last match leaving the node (-1), doubling pointers (-1)
