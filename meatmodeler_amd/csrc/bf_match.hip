@@ -960,8 +960,12 @@ __global__ __launch_bounds__(BF_THREADS, WAVES) void bf_knn2_fp4min_kernel(
     };
 #define F4M_A(j) (bf_v8i{A4[j][0], A4[j][1], A4[j][2], A4[j][3], 0, 0, 0, 0})
 #define F4M_B(u, j) (bf_v8i{B4[u][j][0], B4[u][j][1], B4[u][j][2], B4[u][j][3], 0, 0, 0, 0})
+    // A wave whose 64 queries all lie past the pair's last one (the fourth wave of the 16th query tile at 4000 key points)
+    // only helps to stage the train tiles: no matrix instructions, no bookkeeping -- 1/64 of the matrix work at that size.
+    const bool wave_active = __builtin_amdgcn_readfirstlane(qbase + 64 * wv) < nq;
     auto tile_step = [&](int tt, auto first_tag, int nxt, bool have_next) __attribute__((always_inline)) {
         constexpr bool HAVE_PREV = !decltype(first_tag)::value;
+        if (!wave_active) return;
         if constexpr (!PIPE) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) read_a((nxt + 2) % 3, j);
@@ -1048,6 +1052,7 @@ __global__ __launch_bounds__(BF_THREADS, WAVES) void bf_knn2_fp4min_kernel(
         f4m_chunk2<PARTIAL>(st, tile32);
         f4m_update(st.key, b0[u], b1[u]);
     };
+    if (!wave_active) return;      // (no barrier follows)
     if (nfull > 0) book(acc1_prev, (uint32_t)(nfull - 1) * MF_TT, 1, std::false_type{}, 0);
     if (nfull < ntiles) {      // the partial last tile, unpipelined: rows past the last train never win
         bf_v16f acc0 = cinit, acc1 = cinit;      // (PIPE: the operands of tile nfull were read during the last iteration)
