@@ -29,8 +29,8 @@ def bf_knn2_batched(q, t, nq=None, nt=None, ctx=None):
     assert q.stride(-1) == 1 and q.stride(-2) == 32 and t.stride(-1) == 1 and t.stride(-2) == 32
     n_pairs, nq_cap, nt_cap = q.shape[0], q.shape[1], t.shape[1]
     assert t.shape[0] == n_pairs
-    idx = torch.full((n_pairs, nq_cap, 2), -1, dtype=torch.int32, device=q.device)
-    dist = torch.full((n_pairs, nq_cap, 2), -1, dtype=torch.int32, device=q.device)
+    both = torch.full((2, n_pairs, nq_cap, 2), -1, dtype=torch.int32, device=q.device)      # (one fill, two views)
+    idx, dist = both[0], both[1]
     if n_pairs == 0 or nq_cap == 0:
         return idx, dist
     wsb = lib.mm_bf_workspace_bytes(n_pairs, nq_cap, nt_cap)
