@@ -33,6 +33,8 @@ extern "C" {
 typedef struct mm_ctx mm_ctx;
 
 /* ---- context ------------------------------------------------------------------------------- */
+/* 3 since round 4: mm_trf_report is 64 bytes (chol_fallbacks, collectives), mm_ctx_control / mm_flatten_* /
+ * mm_ba_trf_dist / mm_ba_trf_batched exist.  A caller built against an older header must refuse to run. */
 int mm_abi_version(void);
 /* hip_stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or NULL for the default stream. */
 int mm_ctx_create(int device, void *hip_stream, mm_ctx **out);
@@ -44,15 +46,22 @@ int mm_ctx_sync(mm_ctx *ctx); /* (sync) hipStreamSynchronize on the context stre
  *     their workgroups had not become resident (info = -1) -- exercises the fall-back to the launch-per-column path;
  *   MM_CTL_CHOL_LAST_PATH: path of the last mm_chol_solve* on this context: 1 single launch, 0 per column, -1 none yet;
  *   MM_CTL_CHOL_RESERVED: workgroups this context currently holds of the per-process budget of co-resident
- *     factorisation workgroups (one compute unit each; given back at the context's next synchronisation);
+ *     factorisation workgroups (one compute unit each; given back at the context's next synchronisation, at every
+ *     read-back inside mm_ba_trf, or -- once the event recorded behind the solve has completed -- at this context's next
+ *     reservation or when another context finds the budget spent);
  *   MM_CTL_CU_COUNT: compute units of the device;
  *   MM_CTL_CHOL_AVOID_FUSED: value != 0: this context takes the launch-per-column factorisation from now on (what a
- *     caller that sequences the solver itself does after it has seen info = -1); 0: back to the default. */
+ *     caller that sequences the solver itself does after it has seen info = -1); 0: back to the default; < 0: query.
+ *     Returns the setting as it was BEFORE the call (0 / 1), so a caller can restore it. */
 #define MM_CTL_CHOL_FORCE_ABANDON 1
 #define MM_CTL_CHOL_LAST_PATH 2
 #define MM_CTL_CHOL_RESERVED 3
 #define MM_CTL_CU_COUNT 4
 #define MM_CTL_CHOL_AVOID_FUSED 5
+/*   MM_CTL_LINK_LAST_VARIANT: formulation the last mm_link_tracks_device on this context took: 1 parallel (pointer
+ *     doubling), 0 serial (asked for with MM_LINK_VARIANT=serial, or the safety valve: the parallel formulation's
+ *     fixed-point pass over key points with coincident coordinates exceeded its work budget), -1 none yet. */
+#define MM_CTL_LINK_LAST_VARIANT 6
 long long mm_ctx_control(mm_ctx *ctx, int what, long long value);
 /* HIP-event timing on the context stream (bench.py's roofline leg). */
 int mm_timer_create(mm_ctx *ctx, void **timer_out);
@@ -338,7 +347,13 @@ int mm_ba_trf(mm_ctx *ctx, const mm_ba_problem *pb, double *cams /*dev, in/out*/
  *   half_bandwidth: of the reduced camera system, from the GLOBAL camera span (6 * max over ranks of cam_span + 5);
  *   band_exchange != 0: every rank's S is confined to that band (all shards have a pair list): n (hb + 1) + n doubles are
  *     exchanged instead of n^2 + n.  Both must be the same on every rank (decide them from all-reduced quantities).
- * All ranks see identical scalars and take identical decisions; the replicated cameras come out bit-identical. */
+ * All ranks see identical scalars and take identical decisions; the replicated cameras come out bit-identical: that
+ * includes the choice between the two factorisation paths (a rank whose context is set to avoid the single launch, finds
+ * no room in the co-residency budget, or sees its factorisation abandoned tells the others inside the exchanges above
+ * and all switch together).
+ * FATAL ERRORS ARE GROUP-WIDE: a non-zero return of the callback, or any error on one rank, makes THAT rank return; its
+ * peers are then waiting inside their next all-reduce.  The caller must treat a failed mm_ba_trf_dist as fatal for the
+ * whole group (abort / destroy the communicator, which releases the peers with an error, or rely on its timeout). */
 typedef int (*mm_allreduce_fn)(void *user, double *buf /*dev*/, int64_t count);
 typedef struct mm_dist {
     int32_t rank, world;   /* world <= 16 */

@@ -190,11 +190,12 @@ class Context:
         self.check(lib.mm_ctx_sync(self.h), "mm_ctx_sync")
 
     CTL_CHOL_FORCE_ABANDON, CTL_CHOL_LAST_PATH, CTL_CHOL_RESERVED, CTL_CU_COUNT, CTL_CHOL_AVOID_FUSED = 1, 2, 3, 4, 5
+    CTL_LINK_LAST_VARIANT = 6
 
     def control(self, what, value=0):
         """mm_ctx_control: knobs / queries of the context (see include/meatmodeler.h)."""
         r = int(lib.mm_ctx_control(self.h, int(what), int(value)))
-        if r < -1 or (r == -1 and what != self.CTL_CHOL_LAST_PATH):
+        if r < -1 or (r == -1 and what not in (self.CTL_CHOL_LAST_PATH, self.CTL_LINK_LAST_VARIANT)):
             self.check(r, "mm_ctx_control")
         return r
 

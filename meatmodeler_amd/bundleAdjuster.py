@@ -624,6 +624,22 @@ def _solve_device(self, x, g, cost, half_bw, band_exchange, ftol, xtol, gtol, ma
         info = pb.chol_solve_sym(S, v, half_bw, both_triangles=not band_exchange)
         return info, v, Cinv
 
+    # an abandoned single-launch factorisation switches THIS solve to the launch-per-column path; the context's setting
+    # (normally the shared default context) and this object's flag are restored on the way out, as trf.hip's FusedGuard does
+    self._avoid_fused = False
+    prev_avoid = pb.ctx.control(pb.ctx.CTL_CHOL_AVOID_FUSED, -1) if hasattr(pb, "ctx") else None
+    try:
+        return _solve_device_loop(self, x, g, cost, half_bw, ftol, xtol, gtol, max_nfev, verbose, fix_params, fix_residual,
+                                  reduced_solve)
+    finally:
+        if prev_avoid is not None:
+            pb.ctx.control(pb.ctx.CTL_CHOL_AVOID_FUSED, prev_avoid)
+        self._avoid_fused = False
+
+
+def _solve_device_loop(self, x, g, cost, half_bw, ftol, xtol, gtol, max_nfev, verbose, fix_params, fix_residual, reduced_solve):
+    pb = self.pb
+    ar = self.allreduce
     F, P, nc = pb.F, pb.P, self.nc
     n = nc + 3 * P
     f64 = dict(dtype=torch.float64, device=pb.device)

@@ -18,6 +18,7 @@
 // MFMA fragment maps for f64 16x16x4 (guide section 3): A lane l -> A[l&15][l>>4], B lane l -> B[l>>4][l&15],
 // D reg i of lane l -> D[(l>>4) + 4 i][l&15].
 #include "mm_common.h"
+#include <mutex>
 #include <atomic>
 #include <type_traits>
 #include <cstdlib>
@@ -1852,25 +1853,66 @@ int mm_chol_solve_sym(mm_ctx *ctx, double *A, int n, double *b, int half_bandwid
 // instead, and a context returns its share at its next host synchronisation.  (Conservative: a reservation outlives its
 // kernel until the owner synchronises.  Per process and device 0..15; other processes on the GPU are not seen -- their
 // case is covered by the bounded spins + mm_ba_trf's retry on the per-column path.)
-static std::atomic<int> g_fused_reserved[16];
+// A reservation is also returned without a host synchronisation of its owner: every single-launch solve records an
+// event behind its last kernel, and a context whose event has completed gives its share back at its own next
+// reservation -- or when ANOTHER context finds the budget exhausted and sweeps the registry (the Python-sequenced
+// driver and direct mm_chol_solve* callers synchronise through torch and never reach mm_ctx_sync).
+static std::mutex g_budget_mu;
+static int g_fused_reserved[16];
+static std::vector<mm_ctx *> g_budget_holders;      // contexts with fused_wgs > 0
+
+static void budget_drop_locked(mm_ctx *ctx) {
+    if (ctx->fused_wgs > 0) {
+        g_fused_reserved[ctx->device & 15] -= ctx->fused_wgs;
+        ctx->fused_wgs = 0;
+        for (size_t i = 0; i < g_budget_holders.size(); ++i)
+            if (g_budget_holders[i] == ctx) {
+                g_budget_holders[i] = g_budget_holders.back();
+                g_budget_holders.pop_back();
+                break;
+            }
+    }
+    ctx->fused_ev_pending = false;
+}
 
 void mm_chol_release_budget(mm_ctx *ctx) {
-    if (ctx && ctx->fused_wgs > 0) {
-        g_fused_reserved[ctx->device & 15].fetch_sub(ctx->fused_wgs);
-        ctx->fused_wgs = 0;
+    if (!ctx) return;
+    std::lock_guard<std::mutex> lk(g_budget_mu);
+    budget_drop_locked(ctx);
+}
+
+// the solve whose grid was reserved has been enqueued completely: remember where it ends on the stream
+static void chol_budget_mark(mm_ctx *ctx) {
+    if (!ctx->fused_ev && hipEventCreateWithFlags(&ctx->fused_ev, hipEventDisableTiming) != hipSuccess) {
+        ctx->fused_ev = nullptr;
+        return;
     }
+    if (hipEventRecord(ctx->fused_ev, ctx->stream) != hipSuccess) return;
+    std::lock_guard<std::mutex> lk(g_budget_mu);
+    ctx->fused_ev_pending = ctx->fused_wgs > 0;
 }
 
 static bool chol_reserve_budget(mm_ctx *ctx, int grid) {
-    std::atomic<int> &total = g_fused_reserved[ctx->device & 15];
-    const int delta = grid - ctx->fused_wgs;      // this context's earlier launch is stream-ordered before the new one
-    const int after = total.fetch_add(delta) + delta;
-    ctx->fused_wgs = grid;
-    if (ctx->cu_count > 0 && after > ctx->cu_count) {
-        total.fetch_sub(grid);
-        ctx->fused_wgs = 0;
-        return false;
+    std::lock_guard<std::mutex> lk(g_budget_mu);
+    int &total = g_fused_reserved[ctx->device & 15];
+    // this context's earlier launch is stream-ordered before the new one: its share is replaced, not added to
+    const int own = ctx->fused_wgs;
+    if (ctx->cu_count > 0 && total - own + grid > ctx->cu_count) {
+        // exhausted: collect the shares of contexts whose solves have finished meanwhile (never this context's own --
+        // its earlier kernel may still be running and keeps its share until the stream has passed it)
+        for (size_t i = 0; i < g_budget_holders.size();) {
+            mm_ctx *o = g_budget_holders[i];
+            if (o != ctx && o->device == ctx->device && o->fused_ev_pending && hipEventQuery(o->fused_ev) == hipSuccess)
+                budget_drop_locked(o);      // (swaps the last holder into slot i)
+            else
+                ++i;
+        }
+        if (total - own + grid > ctx->cu_count) return false;
     }
+    total += grid - own;
+    if (own == 0 && grid > 0) g_budget_holders.push_back(ctx);
+    ctx->fused_wgs = grid;
+    ctx->fused_ev_pending = false;
     return true;
 }
 
@@ -1932,6 +1974,11 @@ int mm_chol_solve_gated(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int 
     const int fused_grid = g.b > 0 ? 2 * G_side + g.m * (g.m + 1) / 2 : G_side;
     if (fused && !chol_reserve_budget(ctx, fused_grid)) {
         if (slab_ready) return mm_fail(ctx, MM_ERR_HIP, "mm_chol_solve_gated: no room for the single-launch factorisation");
+        if (ctx->chol_strict_budget) {      // sharded solve: say so instead of diverging from the other ranks' path
+            ctx->chol_last_path = -1;
+            MM_HIP(ctx, hipMemsetAsync(info, 0xFF, sizeof(int32_t), ctx->stream));      // info = -1
+            return MM_OK;
+        }
         fused = false;
         g = TwGeom{n, nblk, bwb, nblk, 0, 0, nblk * NB - n};
     }
@@ -2019,5 +2066,6 @@ int mm_chol_solve_gated(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int 
                       (const double *)(Linv + (size_t)k * NB * NB), ytmp, bc, n, k0, col_begin);
         }
     }
+    if (fused) chol_budget_mark(ctx);
     return MM_OK;
 }

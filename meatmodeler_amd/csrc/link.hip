@@ -426,7 +426,7 @@ struct ParWs {
     int32_t *bcount, *bobs, *tbase, *obase;      // frames [F]: tracks ending there, their observations, exclusive sums
     int32_t *bucket, *loff;          // [F cap]: births ending at a frame (slot = match index of the arriving edge, then
                                      // closed up and sorted), observation offset inside the bucket
-    int32_t *scal;                   // [0] uncertain matches, [1] malformed matches
+    int32_t *scal;                   // [0] uncertain matches, [1] malformed matches, [2] the fixed-point pass gave up
     size_t ff_bytes, zero_off, zero_bytes;       // the two memset regions
 };
 constexpr uint32_t LP_NONE = 0xFFFFFFFFu;
@@ -471,13 +471,25 @@ __global__ __launch_bounds__(256) void lp_certain_kernel(int64_t n_match, int ca
 }
 
 // effective(u) = the node u leaves has no track = no certain edge and no effective uncertain edge arrives there
-__global__ __launch_bounds__(1024) void lp_uncertain_kernel(int F, ParWs w) {
+// Work budget: the pass is one workgroup, so rounds x uncertain matches is its running time (~1 ns per entry and sweep).
+// Past `budget` entries (a clip whose key points coincide clip-wide: every match uncertain, chains as long as the clip) it
+// gives up and says so in scal[2]; mm_link_tracks_device then takes the serial formulation, whose cost does not depend on
+// the input (no input may occupy the GPU for seconds).
+__global__ __launch_bounds__(1024) void lp_uncertain_kernel(int F, ParWs w, long long budget) {
     __shared__ int s_changed;
     const int n = w.scal[0];
     if (n == 0) return;
+    if ((long long)n > budget) {
+        if (threadIdx.x == 0) w.scal[2] = 1;
+        return;
+    }
     for (int i = threadIdx.x; i < n; i += 1024) w.eff[i] = !w.cert[w.src[w.unc[i]]];
     __syncthreads();
     for (int round = 0; round <= F; ++round) {
+        if ((long long)(round + 1) * n > budget) {      // (uniform: every thread sees the same round and n)
+            if (threadIdx.x == 0) w.scal[2] = 1;
+            return;
+        }
         for (int i = threadIdx.x; i < n; i += 1024) w.uin[w.dst[w.unc[i]]] = 0;
         if (threadIdx.x == 0) s_changed = 0;
         __syncthreads();
@@ -781,7 +793,11 @@ int mm_link_tracks_device(mm_ctx *ctx, int n_frames, int cap, const int32_t *kp_
     if (((uintptr_t)ws & 255) || ((uintptr_t)kp_xy & 7)) return mm_fail(ctx, MM_ERR_ARG, "mm_link_tracks_device: alignment");
     if (ws_bytes < mm_link_workspace_bytes(n_frames, cap)) return mm_fail(ctx, MM_ERR_WORKSPACE, "mm_link_tracks_device: workspace too small");
     const char *variant = getenv("MM_LINK_VARIANT");
-    const bool serial = variant && variant[0] == 's';
+    bool serial = variant && variant[0] == 's';
+    // entries (rounds x uncertain matches) the parallel formulation's fixed-point pass may sweep before the call switches
+    // to the serial formulation: ~1 ns each, i.e. a few milliseconds -- what the serial walk costs on a large clip
+    long long unc_budget = 4000000;
+    if (const char *e = getenv("MM_LINK_UNCERTAIN_BUDGET")) unc_budget = atoll(e);
     LinkWs w;
     ParWs pw;
     carve(w, (uint8_t *)ws, n_frames, cap);
@@ -802,7 +818,19 @@ int mm_link_tracks_device(mm_ctx *ctx, int n_frames, int cap, const int32_t *kp_
         MM_HIP(ctx, hipMemsetAsync((uint8_t *)ws + pw.zero_off, 0, pw.zero_bytes, ctx->stream));
         MM_LAUNCH(ctx, "lp_edges_kernel", lp_edges_kernel, gm, b256, 0, n_match, cap, kp_count, match_count, matches, pw);
         MM_LAUNCH(ctx, "lp_certain_kernel", lp_certain_kernel, gm, b256, 0, n_match, cap, match_count, pw);
-        MM_LAUNCH(ctx, "lp_uncertain_kernel", lp_uncertain_kernel, dim3(1), dim3(1024), 0, n_frames, pw);
+        MM_LAUNCH(ctx, "lp_uncertain_kernel", lp_uncertain_kernel, dim3(1), dim3(1024), 0, n_frames, pw, unc_budget);
+        {   // safety valve: one 4-byte read-back (the call is followed by a read-back of `counts` anyway)
+            int32_t gave_up = 0;
+            MM_HIP(ctx, hipMemcpyAsync(&gave_up, pw.scal + 2, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+            MM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            ctx->link_last_variant = gave_up ? 0 : 1;
+            if (gave_up) {
+                serial = true;      // (the two formulations share the workspace: start over with the serial one's layout)
+                MM_LAUNCH(ctx, "link_canon_kernel", link_canon_kernel, dim3(n_frames), dim3(CANON_THREADS), (size_t)slots * sizeof(int32_t),
+                          cap, slots, kp_count, kp_xy, w.canon);
+            }
+        }
+      if (!serial) {
         MM_LAUNCH(ctx, "lp_classify_kernel", lp_classify_kernel, gm, b256, 0, n_match, cap, match_count, pw);
         int cur = 0;
         for (int64_t reach = 1; reach < n_frames; reach *= 2, cur ^= 1)      // chains have at most n_frames - 1 edges
@@ -813,6 +841,9 @@ int mm_link_tracks_device(mm_ctx *ctx, int n_frames, int cap, const int32_t *kp_
         MM_LAUNCH(ctx, "lp_ptr_kernel", lp_ptr_kernel, dim3((unsigned)((cap + 255) / 256), n_frames), b256, 0, cap, pw, track_ptr);
         MM_LAUNCH(ctx, "lp_emit_kernel", lp_emit_kernel, gm, b256, 0, n_match, cap, match_count, matches, pw, obs_frame, obs_kp);
         return MM_OK;
+      }
+    } else {
+        ctx->link_last_variant = 0;
     }
     const int lds_mode = cap <= 4096 ? 2 : 1;      // (cap <= LK_MAX_CAP = 8192: the three tables always fit)
     const size_t lds_bytes = (size_t)(lds_mode == 2 ? 9 : 3) * cap * sizeof(int32_t);

@@ -32,6 +32,17 @@ struct mm_ctx {
     // abandoned factorisation); chol_last_path: 1 single launch, 0 per column, -1 none yet; debug_abandon: test hook.
     int cu_count = 0, fused_wgs = 0, chol_last_path = -1, debug_abandon = 0;
     bool chol_avoid_fused = false;
+    // mm_ba_trf_dist: the choice between the two factorisation paths must be the same on every rank (they order their
+    // sums differently and the replicated cameras must stay bit-identical).  With this set, a launch that finds no room
+    // in the budget does NOT quietly take the per-column path: it reports info = -1 like an abandoned factorisation, the
+    // flag travels with the trial cost, and all ranks switch together.
+    bool chol_strict_budget = false;
+    // recorded behind the last kernel of a single-launch solve: once it has completed the reservation can be returned
+    // without a host synchronisation (by the owner's next reservation or by another context that finds the budget spent)
+    hipEvent_t fused_ev = nullptr;
+    bool fused_ev_pending = false;
+    // link.hip: formulation the last mm_link_tracks_device took (1 parallel, 0 serial -- asked for, or the safety valve), -1 none
+    int link_last_variant = -1;
     // rotation coefficients of the cameras the BA sweeps were last called with (ba.hip: mm_cam_coef_table)
     void *cam_tab = nullptr;
     int cam_tab_cap = 0, cam_tab_F = 0;

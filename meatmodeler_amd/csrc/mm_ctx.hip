@@ -3,7 +3,7 @@
 
 extern "C" {
 
-int mm_abi_version(void) { return 2; }
+int mm_abi_version(void) { return 3; }
 
 int mm_ctx_create(int device, void *hip_stream, mm_ctx **out) {
     if (!out) return MM_ERR_ARG;
@@ -32,6 +32,7 @@ void mm_ctx_destroy(mm_ctx *ctx) {
     for (auto e : ctx->pool) (void)hipEventDestroy(e);
     if (ctx->cam_tab) (void)hipFree(ctx->cam_tab);
     if (ctx->host_board) (void)hipHostFree(ctx->host_board);
+    if (ctx->fused_ev) (void)hipEventDestroy(ctx->fused_ev);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
@@ -100,7 +101,12 @@ long long mm_ctx_control(mm_ctx *ctx, int what, long long value) {
         case MM_CTL_CHOL_LAST_PATH: return ctx->chol_last_path;
         case MM_CTL_CHOL_RESERVED: return ctx->fused_wgs;
         case MM_CTL_CU_COUNT: return ctx->cu_count;
-        case MM_CTL_CHOL_AVOID_FUSED: ctx->chol_avoid_fused = value != 0; return MM_OK;
+        case MM_CTL_CHOL_AVOID_FUSED: {      // value < 0: query only; returns the PREVIOUS setting (0 / 1)
+            const long long prev = ctx->chol_avoid_fused ? 1 : 0;
+            if (value >= 0) ctx->chol_avoid_fused = value != 0;
+            return prev;
+        }
+        case MM_CTL_LINK_LAST_VARIANT: return ctx->link_last_variant;
         default: return mm_fail(ctx, MM_ERR_ARG, "mm_ctx_control: unknown request %d", what);
     }
 }

@@ -275,13 +275,18 @@ static int trf_run(mm_ctx *ctx, const mm_ba_problem *pb, double *cams, double *p
     // the launch-per-column factorisation; the context's setting is restored on the way out, its budget share returned
     struct FusedGuard {
         mm_ctx *c;
-        bool saved;
-        explicit FusedGuard(mm_ctx *ctx) : c(ctx), saved(ctx->chol_avoid_fused) {}
+        bool saved, saved_strict;
+        FusedGuard(mm_ctx *ctx, bool sharded) : c(ctx), saved(ctx->chol_avoid_fused), saved_strict(ctx->chol_strict_budget) {
+            // sharded: no rank-local choice of the factorisation path (a full budget reports info = -1 instead, and the
+            // "a rank's factorisation was abandoned" flag of the trial-cost exchange moves all ranks together)
+            if (sharded) c->chol_strict_budget = true;
+        }
         ~FusedGuard() {
             c->chol_avoid_fused = saved;
+            c->chol_strict_budget = saved_strict;
             mm_chol_release_budget(c);
         }
-    } fused_guard(ctx);
+    } fused_guard(ctx, dist != nullptr);
     const int F = pb->F, P = pb->P;
     const int64_t nc = 6 * (int64_t)F, n = nc + 3 * (int64_t)P;
     hipStream_t st = ctx->stream;
@@ -351,12 +356,14 @@ static int trf_run(mm_ctx *ctx, const mm_ba_problem *pb, double *cams, double *p
             }
         }
         for (int i = 0; i < count; ++i) host[i] = ((volatile double *)hb->v)[i];
+        mm_chol_release_budget(ctx);      // the stream has passed everything enqueued before the publishing kernel
         return MM_OK;
     };
     auto read_board = [&](const double *dev, int count) -> int {
         if (!spin) {
             MM_HIP(ctx, hipMemcpyAsync(host, dev, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, st));
             MM_HIP(ctx, hipStreamSynchronize(st));
+            mm_chol_release_budget(ctx);
             return MM_OK;
         }
         HostBoard *hb = (HostBoard *)ctx->host_board;
@@ -367,7 +374,16 @@ static int trf_run(mm_ctx *ctx, const mm_ba_problem *pb, double *cams, double *p
     };
     // initial cost
     TRF_CALL(mm_ba_residual(ctx, pb, cams_of(x), pts_of(x), nullptr, t.cost2, t.ws_res, t.ws_res_b));
-    TRF_CALL(exchange({{t.cost2, 3}}));
+    if (dist) {
+        // "this rank's context is set to avoid the single-launch factorisation" rides with the initial cost: if any rank
+        // is, all are -- the two paths order their sums differently and the replicated cameras must stay bit-identical
+        const double av = ctx->chol_avoid_fused ? 1.0 : 0.0;
+        MM_HIP(ctx, hipMemcpyAsync(t.board + 15, &av, sizeof(double), hipMemcpyHostToDevice, st));
+        MM_HIP(ctx, hipStreamSynchronize(st));
+        TRF_CALL(exchange({{t.cost2, 3}, {t.board + 15, 3}}));
+        TRF_CALL(read_board(t.board + 15, 1));
+        if (host[0] > 0) ctx->chol_avoid_fused = true;
+    }
     TRF_CALL(read_board(t.cost2, 1));
     double cost = 0.5 * host[0];
     rep->cost0 = cost;

@@ -528,7 +528,10 @@ class BADevice:
                        min_damping=1e-9, log_cap=0):
         """mm_ba_trf_dist: the same loop sharded over ranks (this problem = the rank's points).  `allreduce` is a callable
         summing a device tensor over the ranks in place (parallel.AllReduce); the library calls back with pointers into its
-        workspace, which are wrapped as tensor views here.  -> (report, rows) like trf_solve."""
+        workspace, which are wrapped as tensor views here.  -> (report, rows) like trf_solve.
+        An exception raised by `allreduce` -- or any error on this rank -- is FATAL FOR THE WHOLE GROUP: this rank leaves
+        the loop while its peers wait inside their next collective (include/meatmodeler.h); it is re-raised here and the
+        caller is expected to tear the process group down (its timeout bounds the peers' wait otherwise)."""
         for t in (cams, pts):
             assert t.dtype == torch.float64 and t.is_contiguous() and t.device == self.device
         need = lib.mm_ba_trf_dist_workspace_bytes(C.byref(self.pb), int(half_bandwidth))

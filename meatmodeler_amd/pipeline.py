@@ -339,12 +339,17 @@ class ClipPipeline:
         return out
 
     # ------------------------------------------------------------------------------------------- whole clip
-    def run(self, frames, K, extrinsics, ba=True, ftol=1e-4, verbose=0, dist=None, timers=None):
+    def run(self, frames, K, extrinsics, ba=True, ftol=1e-4, verbose=0, dist=None, timers=None, max_nfev=None,
+            force_collectives=False):
         """frames [F,H,W] u8 (device).  With `dist` = torch.distributed (initialised), frames are the FULL clip on
-        every rank (synthetic input is generated locally) and the work is sharded as described in parallel.py."""
+        every rank (synthetic input is generated locally) and the work is sharded as described in parallel.py.
+        `max_nfev`: evaluation budget of the adjustment (None = SciPy's default, as adjustPoints).
+        `force_collectives`: take the gather / all-reduce path even in a one-rank group (the collectives are trivial
+        but travel the real backend: how backend "nccl" is exercised on a single GPU)."""
         F = frames.shape[0]
         world = dist.get_world_size() if dist is not None else 1
         rank = dist.get_rank() if dist is not None else 0
+        sharded = world > 1 or (dist is not None and force_collectives)
         T = timers if timers is not None else {}
 
         def tic(name):
@@ -367,7 +372,7 @@ class ClipPipeline:
             m = torch.zeros(0, dtype=torch.int32, device=self.device)
         toc("match")
         tic("link")
-        if world > 1:
+        if sharded:
             # every rank needs every frame's key points and every pair's matches to link identical tracks.  The block
             # partition is arithmetic on (F, world), so every rank knows every rank's row counts: fixed-shape device
             # all-gathers (RCCL over xGMI under "nccl"), nothing goes through host memory.
@@ -420,10 +425,10 @@ class ClipPipeline:
         coords_d, of_d, pi_d = ops.flatten_tracks(track_ptr, obs_frame, obs_kp, xy_dev, t_lo=lo, n_sel=hi - lo, ctx=self.ctx)
         pb = ops.BADevice(K, of_d, pi_d, coords_d, F, hi - lo, d, self.ctx)
         pts0 = X[lo:hi].contiguous()
-        solver = SchurTRF(pb, allreduce=parallel.AllReduce() if world > 1 else None)
+        solver = SchurTRF(pb, allreduce=parallel.AllReduce(force=force_collectives) if sharded else None)
         cams_d = torch.as_tensor(cams0).to(self.device)
         tic("ba_solve")
-        res = solver.solve(cams_d, pts0, ftol=ftol, verbose=verbose if rank == 0 else 0)
+        res = solver.solve(cams_d, pts0, ftol=ftol, max_nfev=max_nfev, verbose=verbose if rank == 0 else 0)
         toc("ba_solve")
         toc("ba")
         out.update(ba=res, n_obs_local=pb.O, cam_span=pb.cam_span, n_pairs=pb.n_pairs)

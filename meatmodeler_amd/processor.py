@@ -8,8 +8,11 @@ return order, HIP kernels underneath (no CPU fallback: a missing extension or GP
     pointTracking                  processor.py:190  pointTracking       (hash join; same list semantics)
     triangulatePoints              processor.py:246  triangulatePoints   (mm_triangulate_dlt, batched over tracks)
     managePoints                   processor.py:264  managePoints
+    keyframeTracking               processor.py:61   keyframeTracking    (mm-LK + mm-GFTT: calcOpticalFlowPyrLK / goodFeaturesToTrack)
+    increaseContrast               processor.py:12   increaseContrast    (fixed-point L*a*b* + CLAHE), cvtColorBGR2GRAY
+    PLY tail                       processor.py:480  savePointCloud      (mm_write_ply)
 
-Frame I/O, CLAHE, keyframe gating, calibration, PnP and PLY export stay outside (SURVEY.md §8 "out of scope").
+Video decode, calibration (chessboard / calibrateCamera) and PnP stay outside (SURVEY.md §8 "out of scope").
 """
 import math
 

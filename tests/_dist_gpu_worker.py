@@ -62,7 +62,8 @@ def main():
         out.update({f"{tag}_cams": res.cams.cpu().numpy(), f"{tag}_pts": res.pts.cpu().numpy(), f"{tag}_lo": lo,
                     f"{tag}_hi": hi, f"{tag}_cost": res.cost, f"{tag}_nfev": res.nfev, f"{tag}_status": res.status,
                     f"{tag}_n_pairs": pb.n_pairs, f"{tag}_cam_span": pb.cam_span,
-                    f"{tag}_collectives": getattr(res, "collectives", -1), f"{tag}_iterations": getattr(res, "iterations", -1)})
+                    f"{tag}_collectives": getattr(res, "collectives", -1), f"{tag}_iterations": getattr(res, "iterations", -1),
+                    f"{tag}_fallbacks": getattr(res, "chol_fallbacks", -1) or 0})
 
     # (1) banded exchange: every shard has a pair list (golden G5 case c)
     sharded_ba("band", synth.make_ba_problem(40, 2000, 6, seed=1))
@@ -76,6 +77,32 @@ def main():
                clip_obs_kp=o["obs_kp_dev"].cpu().numpy(), clip_match_count=o["match_count"], clip_kp_count=o["kp_count"],
                clip_cost=o["ba"].cost, clip_nfev=o["ba"].nfev, clip_cams=o["ba"].cams.cpu().numpy(),
                clip_n_pairs=o["n_pairs"], clip_points0=o["points0"].cpu().numpy())
+    # (3b) ONE trust-region iteration of the same outlier-laden real-match problem (max_nfev = 2: initial cost, one trial
+    # step): the full path above is chaotic in the iteration count, a single step is not -- 1 rank vs 2 ranks differ by the
+    # order of the sums only.  This is the regression detector of the SHARDED arithmetic on real matches.
+    o1 = pipe.run(torch.as_tensor(frames).to(dev), K, ext, ba=True, ftol=1e-4, dist=dist, max_nfev=2)
+    out.update(step_cams=o1["ba"].cams.cpu().numpy(), step_cost=o1["ba"].cost, step_nfev=o1["ba"].nfev,
+               step_status=o1["ba"].status, step_cost0=float(getattr(o1["ba"], "cost0", np.nan)))
+    lo_, hi_, _, _ = (parallel.partition_tracks(o1["track_ptr_dev"], rank, world) if world > 1
+                      else (0, o1["n_tracks"], 0, 0))
+    pts_full = torch.zeros((o1["n_tracks"], 3), dtype=torch.float64, device=dev)
+    pts_full[lo_:hi_] = o1["ba"].pts
+    if world > 1:
+        parallel.AllReduce()(pts_full)
+    out.update(step_pts=pts_full.cpu().numpy())
+    # (3c) ADVICE round 3: the choice between the two factorisation paths must be GLOBAL.  Rank 1 alone is told to avoid
+    # the single launch / rank 0 alone has its next factorisation abandoned: every rank must end on the same path with
+    # bit-identical replicated cameras.
+    pr = synth.make_ba_problem(120, 3000, 6, seed=4)           # 120 cameras: the banded single-launch path
+    for tag, knob, who in (("avoid", ctx.CTL_CHOL_AVOID_FUSED, 1), ("abandon", ctx.CTL_CHOL_FORCE_ABANDON, 0)):
+        if world > 1 and rank == who:
+            ctx.control(knob, 1)
+        try:
+            sharded_ba(tag, pr)
+        finally:
+            ctx.control(ctx.CTL_CHOL_AVOID_FUSED, 0)
+            ctx.control(ctx.CTL_CHOL_FORCE_ABANDON, 0)
+        out[f"{tag}_last_path"] = ctx.control(ctx.CTL_CHOL_LAST_PATH)
     w = pipe.adjust_windows(o, K, ext, window=5, stride=2, ftol=1e-4, dist=dist)
     out.update(win_cams=w["cams"].cpu().numpy(), win_pts=w["points"].cpu().numpy(),
                win_nfev=np.array([s["nfev"] for s in w["windows"]]), win_cost=np.array([s["cost"] for s in w["windows"]]),

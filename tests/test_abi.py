@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_sizes_without_gpu():
     from meatmodeler_amd import _lib
-    assert _lib.lib.mm_abi_version() == 2
+    assert _lib.lib.mm_abi_version() == 3
     assert _lib.lib.mm_bf_workspace_bytes(1, 4000, 4000) > 0
     assert _lib.lib.mm_chol_workspace_bytes(3000) >= 47 * 64 * 64 * 8
     p = _lib.OrbParams(4000, 8, 31, 20, 1.2, 0)

@@ -1292,6 +1292,38 @@ def test_link_tracks_device_formulations_agree_on_degenerate_clips(variant, monk
         assert np.array_equal(of0, of1) and np.array_equal(ok0, ok1), mode
 
 
+def test_link_tracks_device_safety_valve_takes_the_serial_formulation(monkeypatch):
+    """ADVICE / VERDICT round 3: a clip whose key points all share one coordinate makes every match 'uncertain' and the
+    parallel formulation's one-workgroup fixed-point pass run as many rounds as the clip is long.  Past a work budget
+    (rounds x uncertain matches) the call now switches to the serial formulation by itself: same CSR as the host linker, and
+    the context says which formulation ran.  An ordinary clip stays on the parallel formulation."""
+    from meatmodeler_amd._lib import default_context
+    monkeypatch.delenv("MM_LINK_VARIANT", raising=False)
+    ctx = default_context()
+    rng = np.random.default_rng(6)
+    F, nk = 40, 256
+    kp_xy = np.zeros((F, nk, 2), np.float32)                # every key point of the clip at (0, 0)
+    kp_count = np.full(F, nk, np.int32)
+    mc = np.zeros(F - 1, np.int32)
+    mm = np.zeros((F - 1, nk, 2), np.int32)
+    for f in range(F - 1):
+        m = int(rng.integers(nk // 2, nk))
+        mc[f] = m
+        mm[f, :m, 0] = rng.integers(0, nk, size=m)
+        mm[f, :m, 1] = rng.integers(0, nk, size=m)
+    monkeypatch.setenv("MM_LINK_UNCERTAIN_BUDGET", "2000")     # ~170 uncertain matches per pair x 39 pairs: over at once
+    (tp0, of0, ok0), (tp1, of1, ok1) = _link_both(kp_count, kp_xy, mc, mm)
+    assert ctx.control(ctx.CTL_LINK_LAST_VARIANT) == 0
+    assert np.array_equal(tp0, tp1.astype(np.int64)) and np.array_equal(of0, of1) and np.array_equal(ok0, ok1)
+    monkeypatch.delenv("MM_LINK_UNCERTAIN_BUDGET")              # default budget: this small clip fits, parallel again
+    (tp0, of0, ok0), (tp2, of2, ok2) = _link_both(kp_count, kp_xy, mc, mm)
+    assert ctx.control(ctx.CTL_LINK_LAST_VARIANT) == 1
+    assert np.array_equal(tp1, tp2) and np.array_equal(of1, of2) and np.array_equal(ok1, ok2)
+    monkeypatch.setenv("MM_LINK_VARIANT", "serial")
+    _link_both(kp_count, kp_xy, mc, mm)
+    assert ctx.control(ctx.CTL_LINK_LAST_VARIANT) == 0
+
+
 def test_link_tracks_device_serial_equals_parallel(monkeypatch):
     """The two device formulations on a clip-sized case with duplicate coordinates: identical CSR."""
     rng = np.random.default_rng(8)
@@ -1672,6 +1704,27 @@ def test_two_ranks_on_one_gpu_real_kernels_match_one_rank(tmp_path):
     # decide which outlier the path chases, so only "same ballpark, same decisions on every rank" is asserted)
     assert float(r0["clip_cost"]) == float(r1["clip_cost"]) and int(r0["clip_nfev"]) == int(r1["clip_nfev"])
     assert abs(float(r0["clip_cost"]) - float(one["clip_cost"])) <= 0.3 * float(one["clip_cost"])
+    # ... and ONE trust-region iteration of that same real-match problem is pinned tightly: the sharded arithmetic (partial
+    # B / g_c / S / v summed over two ranks) differs from one rank's by the order of the sums only
+    assert int(one["step_nfev"]) == int(r0["step_nfev"]) == int(r1["step_nfev"]) == 2
+    np.testing.assert_array_equal(r0["step_cams"], r1["step_cams"])
+    np.testing.assert_array_equal(r0["step_pts"], r1["step_pts"])
+    assert float(r0["step_cost"]) == float(r1["step_cost"])
+    assert abs(float(r0["step_cost"]) - float(one["step_cost"])) <= 1e-9 * float(one["step_cost"])
+    sc = max(np.abs(one["step_cams"]).max(), 1.0)
+    assert np.abs(r0["step_cams"] - one["step_cams"]).max() <= 1e-9 * sc
+    sp = max(np.median(np.abs(one["step_pts"])), 1.0)
+    assert np.median(np.abs(r0["step_pts"] - one["step_pts"])) <= 1e-9 * sp
+    # the factorisation path is a GROUP decision: one rank told to avoid the single launch / one rank's
+    # factorisation abandoned -> both ranks end on the launch-per-column path with bit-identical cameras
+    if os.environ.get("MM_TRF_DRIVER", "library") == "library":
+        for tag in ("avoid", "abandon"):
+            np.testing.assert_array_equal(r0[f"{tag}_cams"], r1[f"{tag}_cams"])
+            assert float(r0[f"{tag}_cost"]) == float(r1[f"{tag}_cost"]) and int(r0[f"{tag}_nfev"]) == int(r1[f"{tag}_nfev"])
+            assert int(r0[f"{tag}_last_path"]) == int(r1[f"{tag}_last_path"]) == 0, tag
+            assert int(one[f"{tag}_last_path"]) == 1
+            assert abs(float(r0[f"{tag}_cost"]) - float(one[f"{tag}_cost"])) <= 1e-9 * float(one[f"{tag}_cost"])
+        assert int(r0["abandon_fallbacks"]) == int(r1["abandon_fallbacks"]) == 1
     np.testing.assert_array_equal(r0["win_points"], one["win_points"])
     np.testing.assert_array_equal(r0["win_cams"], r1["win_cams"])
     np.testing.assert_array_equal(r0["win_pts"], r1["win_pts"])
@@ -1682,6 +1735,42 @@ def test_two_ranks_on_one_gpu_real_kernels_match_one_rank(tmp_path):
         np.testing.assert_array_equal(r0[k], one[k])
     assert len(one["wf_table"]) == len(one["win_points"]) and set(one["wf_table"][:, 7]) >= {0.0, 1.0}
     assert np.all(np.abs(r0["win_cost"] - one["win_cost"]) <= 0.3 * one["win_cost"])
+
+
+def _run_bench(args, env_extra, timeout=600):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **env_extra)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, timeout=timeout, cwd=root)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` with no launcher around it starts N ranks itself (fresh children of a
+    parent that never touches HIP) and rank 0's JSON line says n_gpus = N.  Two ranks share this one GPU through gloo -- a
+    functional rehearsal of the driver's command shape, not a timing."""
+    p = _run_bench(["--gpus", "2", "--frames", "48", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                   {"MM_DIST_BACKEND": "gloo"})
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-4000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout.decode()[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong"
+    if os.environ.get("MM_TRF_DRIVER", "library") == "library":
+        assert line["ba"]["driver"] == "mm_ba_trf_dist" and line["ba"]["collectives"] > 0
+    assert line["value"] > 0 and line["problem"]["tracks"] > 0
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """... and `--gpus 8` on a box with fewer GPUs fails loudly instead of reporting a one-GPU run as eight."""
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("8 GPUs visible")
+    p = _run_bench(["--gpus", "8", "--frames", "16", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], {}, timeout=120)
+    assert p.returncode != 0
+    assert b"GPU(s) visible" in p.stderr and not any(ln.startswith(b"{") for ln in p.stdout.splitlines())
 
 
 def test_library_dist_loop_over_rccl_one_rank(tmp_path):
@@ -1710,6 +1799,10 @@ def test_library_dist_loop_over_rccl_one_rank(tmp_path):
     # Python prologue)
     assert int(d["collectives"]) > 0 and int(d["calls"]) == int(d["collectives"]) + 2
     assert int(d["collectives"]) <= 7 * int(d["nfev"][1]) + 3
+    # the clip path through the same backend: four device all-gathers, identical tracks, the same adjustment
+    assert int(d["clip_gathers"]) == 4 and bool(d["clip_tracks_equal"])
+    assert int(d["clip_nfev"][0]) == int(d["clip_nfev"][1]) and int(d["clip_collectives"]) > 0
+    assert abs(float(d["clip_cost"][0]) - float(d["clip_cost"][1])) <= 1e-9 * float(d["clip_cost"][0])
 
 
 # ============================================================================================== keyframe gating, contrast
