@@ -601,8 +601,8 @@ def _solve_device(self, x, g, cost, half_bw, band_exchange, ftol, xtol, gtol, ma
         rows[:, 2] = t
         return rows
 
-    def reduced_solve(Bd, Cd, gc, gp):
-        """-> (info, v = solution of the reduced camera system, Cinv)."""
+    def reduced_solve(x, Bd, Cd, gc, gp):
+        """-> (info, v = solution of the reduced camera system, Cinv) at the current iterate x."""
         if ar is None:
             return pb.schur_solve(self._cams(x), self._pts(x), Bd, Cd, gc, gp, half_bw)
         S, v, Cinv = pb.schur(self._cams(x), self._pts(x), Bd, Cd, gc, gp)
@@ -679,7 +679,7 @@ def _solve_device_loop(self, x, g, cost, half_bw, ftol, xtol, gtol, max_nfev, ve
         vals = None
         for attempt in range(6):
             Bd, Cd = self._damped_blocks(B, C, si, reg_eff)
-            info, v, Cinv = reduced_solve(Bd, Cd, gc, gp)
+            info, v, Cinv = reduced_solve(x, Bd, Cd, gc, gp)
             dp = pb.backsub(cams(x), pts(x), Cinv, gp, v.view(F, 6)).reshape(-1)
             # orthonormal basis of span{g_h, gn_h} (trf.py:481-482) in three fused passes (see the generic loop)
             r1 = fix_params(pb.trf_fused(1, [v, dp, si, gh], [gn, q1], [gh2_t], split=nc), 2)

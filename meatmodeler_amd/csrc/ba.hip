@@ -21,7 +21,7 @@ namespace {
 
 // ---- residual + cost ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ba_residual_kernel(mm_ba_problem pb, const double *__restrict__ cams,
-                                                          const double *__restrict__ pts, const CamCoef *__restrict__ ctab, double *__restrict__ res,
+                                                          const double *__restrict__ pts, const double *__restrict__ ctab, double *__restrict__ res,
                                                           double *__restrict__ partial) {
     __shared__ double sm[4];
     __shared__ double Ks[9];
@@ -31,8 +31,7 @@ __global__ __launch_bounds__(256) void ba_residual_kernel(mm_ba_problem pb, cons
     for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < pb.O; o += (int64_t)gridDim.x * 256) {
         Proj pr;
         const int f = pb.fi[o];
-        ba_eval_cc<false, false>(cams + (size_t)f * 6, ctab[f],
-                                 pts + (size_t)pb.pi[o] * 3, Ks, pb.obs[2 * o], pb.obs[2 * o + 1], pr);
+        lean_eval_tab<false, false>(ctab + (size_t)f * CAMTAB2, pts + (size_t)pb.pi[o] * 3, Ks, pb.obs[2 * o], pb.obs[2 * o + 1], pr);
         if (res) {
             res[2 * o] = pr.r0;
             res[2 * o + 1] = pr.r1;
@@ -78,7 +77,7 @@ __global__ __launch_bounds__(256) void sum_partials_publish_kernel(const double 
 
 // ---- analytic Jacobian blocks (parity surface) --------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ba_jacobian_kernel(mm_ba_problem pb, const double *__restrict__ cams,
-                                                          const double *__restrict__ pts, const CamCoef *__restrict__ ctab, double *__restrict__ Jc,
+                                                          const double *__restrict__ pts, const double *__restrict__ ctab, double *__restrict__ Jc,
                                                           double *__restrict__ Jp) {
     __shared__ double Ks[9];
     if (threadIdx.x < 9) Ks[threadIdx.x] = pb.K[threadIdx.x];
@@ -87,8 +86,7 @@ __global__ __launch_bounds__(256) void ba_jacobian_kernel(mm_ba_problem pb, cons
     if (o >= pb.O) return;
     Proj pr;
     const int f = pb.fi[o];
-    ba_eval_cc<true, true>(cams + (size_t)f * 6, ctab[f],
-                           pts + (size_t)pb.pi[o] * 3, Ks, pb.obs[2 * o], pb.obs[2 * o + 1], pr);
+    lean_eval_tab<true, true>(ctab + (size_t)f * CAMTAB2, pts + (size_t)pb.pi[o] * 3, Ks, pb.obs[2 * o], pb.obs[2 * o + 1], pr);
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
         Jc[o * 12 + k] = pr.Jc[0][k];
@@ -103,7 +101,7 @@ __global__ __launch_bounds__(256) void ba_jacobian_kernel(mm_ba_problem pb, cons
 
 // ---- point blocks: C[P,6] (upper triangle) and gp[P,3]; one thread per point, its observations are contiguous ------
 __global__ __launch_bounds__(256) void ba_point_blocks_kernel(mm_ba_problem pb, const double *__restrict__ cams,
-                                                              const double *__restrict__ pts, const CamCoef *__restrict__ ctab, double *__restrict__ C,
+                                                              const double *__restrict__ pts, const double *__restrict__ ctab, double *__restrict__ C,
                                                               double *__restrict__ gp) {
     __shared__ double Ks[9];
     if (threadIdx.x < 9) Ks[threadIdx.x] = pb.K[threadIdx.x];
@@ -116,7 +114,7 @@ __global__ __launch_bounds__(256) void ba_point_blocks_kernel(mm_ba_problem pb, 
         int o = pb.pt_obs[e];
         Proj pr;
         const int f = pb.fi[o];
-        ba_eval_cc<false, true>(cams + (size_t)f * 6, ctab[f], Xp, Ks,
+        lean_eval_tab<false, true>(ctab + (size_t)f * CAMTAB2, Xp, Ks,
                                 pb.obs[2 * (size_t)o], pb.obs[2 * (size_t)o + 1], pr);
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
@@ -138,20 +136,19 @@ __global__ __launch_bounds__(256) void ba_camera_blocks_kernel(mm_ba_problem pb,
                                                                double *__restrict__ gc) {
     __shared__ double smn[4 * 27];
     __shared__ double Ks[9];
-    __shared__ double cs[6];
+    __shared__ double trow[CAMTAB2];
     const int f = blockIdx.x;
     if (threadIdx.x < 9) Ks[threadIdx.x] = pb.K[threadIdx.x];
-    if (threadIdx.x < 6) cs[threadIdx.x] = cams[(size_t)f * 6 + threadIdx.x];
+    if (threadIdx.x == 0) cam_table2_row(cams + (size_t)f * 6, pb.K, trow);      // (the same values as the sweeps' table)
     __syncthreads();
-    const CamCoef ccf = cam_coef_of(cs);
     double acc[27];
 #pragma unroll
     for (int i = 0; i < 27; ++i) acc[i] = 0;
     for (int e = pb.cam_ptr[f] + threadIdx.x; e < pb.cam_ptr[f + 1]; e += 256) {
         int o = pb.cam_obs[e];
         Proj pr;
-        ba_eval_cc<true, false>(cs, ccf, pts + (size_t)pb.pi[o] * 3, Ks, pb.obs[2 * (size_t)o], pb.obs[2 * (size_t)o + 1],
-                                pr);
+        lean_eval_tab<true, false>(trow, pts + (size_t)pb.pi[o] * 3, Ks, pb.obs[2 * (size_t)o], pb.obs[2 * (size_t)o + 1],
+                                   pr);
         int t = 0;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
@@ -181,7 +178,7 @@ __global__ __launch_bounds__(256) void ba_camera_blocks_kernel(mm_ba_problem pb,
 
 // ---- out = Jc wc[fi] + Jp wp[pi] ----------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ba_jvp_kernel(mm_ba_problem pb, const double *__restrict__ cams,
-                                                     const double *__restrict__ pts, const CamCoef *__restrict__ ctab, const double *__restrict__ wc,
+                                                     const double *__restrict__ pts, const double *__restrict__ ctab, const double *__restrict__ wc,
                                                      const double *__restrict__ wp, double *__restrict__ out) {
     __shared__ double Ks[9];
     if (threadIdx.x < 9) Ks[threadIdx.x] = pb.K[threadIdx.x];
@@ -190,8 +187,7 @@ __global__ __launch_bounds__(256) void ba_jvp_kernel(mm_ba_problem pb, const dou
     if (o >= pb.O) return;
     const int f = pb.fi[o], p = pb.pi[o];
     Proj pr;
-    ba_eval_cc<true, true>(cams + (size_t)f * 6, ctab[f],
-                           pts + (size_t)p * 3, Ks, pb.obs[2 * o], pb.obs[2 * o + 1], pr);
+    lean_eval_tab<true, true>(ctab + (size_t)f * CAMTAB2, pts + (size_t)p * 3, Ks, pb.obs[2 * o], pb.obs[2 * o + 1], pr);
     double y0 = 0, y1 = 0;
     if (wc) {
 #pragma unroll
@@ -219,7 +215,7 @@ __global__ __launch_bounds__(256) void ba_jvp_kernel(mm_ba_problem pb, const dou
 // two vector passes less per iteration.  Deterministic: fixed tree per workgroup, then one small launch adds the
 // per-workgroup partials in index order.
 __global__ __launch_bounds__(256) void ba_jvp_dots_kernel(mm_ba_problem pb, const double *__restrict__ cams,
-                                                          const double *__restrict__ pts, const CamCoef *__restrict__ ctab, const double *__restrict__ wc,
+                                                          const double *__restrict__ pts, const double *__restrict__ ctab, const double *__restrict__ wc,
                                                           const double *__restrict__ wp, double *__restrict__ out,
                                                           const double *__restrict__ other, double *__restrict__ partial) {
     __shared__ double Ks[9];
@@ -231,8 +227,7 @@ __global__ __launch_bounds__(256) void ba_jvp_dots_kernel(mm_ba_problem pb, cons
     for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < pb.O; o += (int64_t)gridDim.x * 256) {
         const int f = pb.fi[o], p = pb.pi[o];
         Proj pr;
-        ba_eval_cc<true, true>(cams + (size_t)f * 6, ctab[f],
-                               pts + (size_t)p * 3, Ks, pb.obs[2 * o], pb.obs[2 * o + 1], pr);
+        lean_eval_tab<true, true>(ctab + (size_t)f * CAMTAB2, pts + (size_t)p * 3, Ks, pb.obs[2 * o], pb.obs[2 * o + 1], pr);
         double y0 = 0, y1 = 0;
         if (wc) {
 #pragma unroll
@@ -285,7 +280,7 @@ __global__ __launch_bounds__(256) void jvp_rows_kernel(const double *__restrict_
 
 // ---- back-substitution: dp = Cinv (gp - sum_o Jp_o^T (Jc_o dc[f_o])) ------------------------------------------------
 __global__ __launch_bounds__(256) void ba_backsub_kernel(mm_ba_problem pb, const double *__restrict__ cams,
-                                                         const double *__restrict__ pts, const CamCoef *__restrict__ ctab,
+                                                         const double *__restrict__ pts, const double *__restrict__ ctab,
                                                          const double *__restrict__ Cinv, const double *__restrict__ gp,
                                                          const double *__restrict__ dc, double *__restrict__ dp) {
     __shared__ double Ks[9];
@@ -299,7 +294,7 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(mm_ba_problem pb, const
         int o = pb.pt_obs[e];
         int f = pb.fi[o];
         Proj pr;
-        ba_eval_cc<true, true>(cams + (size_t)f * 6, ctab[f], Xp, Ks,
+        lean_eval_tab<true, true>(ctab + (size_t)f * CAMTAB2, Xp, Ks,
                                pb.obs[2 * (size_t)o], pb.obs[2 * (size_t)o + 1], pr);
         double s0 = 0, s1 = 0;
 #pragma unroll
@@ -324,7 +319,7 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(mm_ba_problem pb, const
 // 3-vector Jp^T (Jc dc) into a scratch array in CSR-by-point order, pass 2 adds each point's rows in that order (a fixed
 // order: deterministic) and applies Cinv.
 __global__ __launch_bounds__(256) void ba_backsub_obs_kernel(mm_ba_problem pb, const double *__restrict__ cams,
-                                                             const double *__restrict__ pts, const CamCoef *__restrict__ ctab,
+                                                             const double *__restrict__ pts, const double *__restrict__ ctab,
                                                              const double *__restrict__ dc, double *__restrict__ T) {
     __shared__ double Ks[9];
     if (threadIdx.x < 9) Ks[threadIdx.x] = pb.K[threadIdx.x];
@@ -334,7 +329,7 @@ __global__ __launch_bounds__(256) void ba_backsub_obs_kernel(mm_ba_problem pb, c
     const int o = pb.pt_obs[e];
     const int f = pb.fi[o], p = pb.pi[o];
     Proj pr;
-    ba_eval_cc<true, true>(cams + (size_t)f * 6, ctab[f], pts + (size_t)p * 3, Ks, pb.obs[2 * (size_t)o],
+    lean_eval_tab<true, true>(ctab + (size_t)f * CAMTAB2, pts + (size_t)p * 3, Ks, pb.obs[2 * (size_t)o],
                            pb.obs[2 * (size_t)o + 1], pr);
     double s0 = 0, s1 = 0;
 #pragma unroll
@@ -368,9 +363,10 @@ __global__ __launch_bounds__(256) void ba_backsub_points_kernel(mm_ba_problem pb
 // ---- rotation coefficients of every camera, once per parameter vector ------------------------------------------------
 // (Every workgroup of every sweep used to fill its own LDS copy: two sincos per thread -- more arithmetic than the
 // observations it then processed -- and 40 KB of LDS.  Now: one small launch per NEW camera vector, gathers from L2.)
-__global__ __launch_bounds__(256) void cam_coef_kernel(const double *__restrict__ cams, int F, CamCoef *__restrict__ tab) {
+__global__ __launch_bounds__(256) void cam_coef_kernel(const double *__restrict__ cams, int F, const double *__restrict__ K,
+                                                       double *__restrict__ tab) {
     const int f = blockIdx.x * 256 + threadIdx.x;
-    if (f < F) tab[f] = cam_coef_of(cams + (size_t)f * 6);
+    if (f < F) cam_table2_row(cams + (size_t)f * 6, K, tab + (size_t)f * CAMTAB2);
 }
 
 int check_pb(mm_ctx *ctx, const mm_ba_problem *pb, const char *who) {
@@ -407,19 +403,20 @@ __global__ void trf_damping_kernel(const double *__restrict__ gh2, const double 
 // The table lives in the context.  `cam_tab_for` remembers which camera vector it was computed from; a caller that
 // knows the vector has not changed since (the library's own trust-region loop, trf.hip) keeps it valid with
 // mm_cam_table_hold() and the sweeps then skip the launch.  Everybody else gets a fresh table per call.
-int mm_cam_coef_table(mm_ctx *ctx, const double *cams, int F, const void **tab_out) {
+int mm_cam_coef_table(mm_ctx *ctx, const double *cams, int F, const double *K, const void **tab_out) {
     if (F > ctx->cam_tab_cap) {
         if (ctx->cam_tab) (void)hipFree(ctx->cam_tab);
         ctx->cam_tab = nullptr;
         ctx->cam_tab_cap = 0;
         const int cap = F < 1024 ? 1024 : F + F / 2;
-        MM_HIP(ctx, hipMalloc(&ctx->cam_tab, (size_t)cap * sizeof(CamCoef)));
+        MM_HIP(ctx, hipMalloc(&ctx->cam_tab, (size_t)cap * CAMTAB2 * sizeof(double)));
         ctx->cam_tab_cap = cap;
         ctx->cam_tab_for = nullptr;
     }
-    if (!(ctx->cam_tab_hold && ctx->cam_tab_for == cams && ctx->cam_tab_F == F)) {
+    if (!(ctx->cam_tab_hold && ctx->cam_tab_for == cams && ctx->cam_tab_F == F && ctx->cam_tab_K == K)) {
         if (F > 0)
-            MM_LAUNCH(ctx, "cam_coef_kernel", cam_coef_kernel, dim3((F + 255) / 256), dim3(256), 0, cams, F, (CamCoef *)ctx->cam_tab);
+            MM_LAUNCH(ctx, "cam_coef_kernel", cam_coef_kernel, dim3((F + 255) / 256), dim3(256), 0, cams, F, K, (double *)ctx->cam_tab);
+        ctx->cam_tab_K = K;
         ctx->cam_tab_for = cams;
         ctx->cam_tab_F = F;
     }
@@ -437,12 +434,12 @@ int mm_ba_residual_publish(mm_ctx *ctx, const mm_ba_problem *pb, const double *c
                            size_t ws_bytes, double *board, int cost_slot, int count, void *host_board, unsigned long long seq);
 
 #define MM_CAM_TABLE(ctx, pb, cams)                                               \
-    const CamCoef *ctab = nullptr;                                                \
+    const double *ctab = nullptr;                                                 \
     do {                                                                          \
         const void *t_ = nullptr;                                                 \
-        int rc_ = mm_cam_coef_table(ctx, cams, (pb)->F, &t_);                     \
+        int rc_ = mm_cam_coef_table(ctx, cams, (pb)->F, (pb)->K, &t_);            \
         if (rc_) return rc_;                                                      \
-        ctab = (const CamCoef *)t_;                                               \
+        ctab = (const double *)t_;                                                \
     } while (0)
 
 extern "C" {

@@ -128,13 +128,36 @@ struct SlabSync {
 // Per-camera table for the pair kernel: parameters + rotation coefficients (11 doubles per camera), computed once
 // per build instead of a sincos / sqrt / four divisions in every chunk's prologue.
 constexpr int CAMTAB = 11;
+// per-chunk descriptors of the lean pair kernel (struct ChunkDesc below): 8 int32 per chunk
+__device__ __forceinline__ void write_chunk_desc(const mm_ba_problem &pb, int32_t *__restrict__ desc, int64_t first, int64_t stride) {
+    for (int64_t k = first; k < pb.n_chunks; k += stride) {
+        const int sidx = pb.chunk_seg[k], seg = pb.seg_ids[sidx];
+        const int ci = seg / (pb.cam_span + 1), cdd = seg % (pb.cam_span + 1);
+        const int c_first = pb.seg_chunk_ptr[sidx];
+        int32_t *o = desc + 8 * k;
+        o[0] = ci;
+        o[1] = ci - cdd;
+        o[2] = pb.chunk_begin[k];
+        o[3] = pb.chunk_end[k];
+        o[4] = sidx;
+        o[5] = c_first;
+        o[6] = pb.seg_chunk_ptr[sidx + 1] - c_first;
+        o[7] = 0;
+    }
+}
 __global__ __launch_bounds__(64) void cam_table_kernel(int F, const double *__restrict__ cams, double *__restrict__ tab,
-                                                       int32_t *__restrict__ seg_done, int64_t n_seg) {
+                                                       int32_t *__restrict__ seg_done, int64_t n_seg, const double *__restrict__ K_lean,
+                                                       mm_ba_problem pb, int32_t *__restrict__ desc) {
     const int f = blockIdx.x * 64 + threadIdx.x;
     // (also clears the finished-chunk counters of the build that follows: one fill launch less)
     for (int64_t k = f; k < n_seg; k += (int64_t)gridDim.x * 64) seg_done[k] = 0;
+    if (desc) write_chunk_desc(pb, desc, f, (int64_t)gridDim.x * 64);
     if (f >= F) return;
     const double *c = cams + (size_t)f * 6;
+    if (K_lean) {      // the lean pair kernel's table (P, q, J_r: 24 doubles per camera)
+        cam_table2_row(c, K_lean, tab + (size_t)f * CAMTAB2);
+        return;
+    }
     const CamCoef k = cam_coef_of(c);
     double *t = tab + (size_t)f * CAMTAB;
     for (int q = 0; q < 6; ++q) t[q] = c[q];
@@ -200,8 +223,11 @@ __device__ __forceinline__ void wave_reduce_42(const double (&acc)[42], double *
     }
 }
 
+// The round-3 formulation (MM_SCHUR_PAIRS=ref): both observations of a pair go through the sweeps' full evaluator
+// (projection, residual, both Jacobians from the Rodrigues coefficients: ~200 f64 instructions each).  Kept as the
+// cross-check of the lean kernel below.
 // launch bound 2 waves per SIMD (no scratch: the cameras' values live in scalar registers)
-__global__ __launch_bounds__(64 * SP_WAVES, 2) void schur_pairs_kernel(mm_ba_problem pb, const double *__restrict__ camtab,
+__global__ __launch_bounds__(64 * SP_WAVES, 2) void schur_pairs_ref_kernel(mm_ba_problem pb, const double *__restrict__ camtab,
                                                                     const double *__restrict__ pts,
                                                                     const double *__restrict__ Cinv,
                                                                     const double *__restrict__ gp,
@@ -359,6 +385,238 @@ __global__ __launch_bounds__(64 * SP_WAVES, 2) void schur_pairs_kernel(mm_ba_pro
     }
 }
 
+
+// ---- the lean pair kernel (round 4) ---------------------------------------------------------------------------------------
+// S needs the two Jacobians of an observation, not its residual, and both follow from per-CAMERA matrices:
+//   u = P X + q           P = K R (3 x 3), q = K t                       (9 FMA)
+//   Jp[m] = (P[m] - p_m P[2]) / u_2      d proj / d X                    (12)
+//   Jt[m] = (K[m] - p_m K[2]) / u_2      d proj / d t                    (12)
+//   Jr[m] = (X x Jp[m])^T J_r            d proj / d rvec                 (6 + 9 per row)
+// with J_r = a I - b [r]x + e r r^T the right Jacobian of SO(3) (d (R X) / d r = -R [X]x J_r; a = sin th / th,
+// b = (1 - cos th) / th^2, e = (1 - a) / th^2).  64 f64 instructions per observation instead of ~200; the observed
+// coordinates are not read at all.  Per pair: two of these, Z = Jp_o C^-1 (18), the 2 x 2 middle factor (12), T = M Jc_o2
+// (24) and the 72 multiply-adds of the block: ~255 instructions (was ~530).  Pairs of the diagonal segment (o2 == o) reuse
+// the first evaluation.  P, q of both cameras are wave-uniform scalars; J_r of both and K sit in the wave's LDS slab and
+// arrive as broadcast reads.
+struct CamPQ {
+    double P[9], q[3];
+};
+// 1 / x by v_rcp_f64 (about 26 bits) + two Newton steps: within an ulp or two of the quotient; x is a depth in front of a
+// camera, far from the denormal / overflow cases the 12-instruction IEEE sequence exists for
+__device__ __forceinline__ double fast_rcp(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    return fma(y, e, y);
+}
+
+struct LeanJ {
+    double Jc[2][6];      // d proj / d (rvec, tvec)
+    double Jp[2][3];      // d proj / d X
+};
+// cs: the wave's LDS slab {K[9], Jr[9]} of this camera (broadcast reads)
+__device__ __forceinline__ void lean_eval(const CamPQ &c, const double *__restrict__ Ks, const double *__restrict__ Jr,
+                                          double X0, double X1, double X2, LeanJ &o) {
+    const double u0 = fma(c.P[0], X0, fma(c.P[1], X1, fma(c.P[2], X2, c.q[0])));
+    const double u1 = fma(c.P[3], X0, fma(c.P[4], X1, fma(c.P[5], X2, c.q[1])));
+    const double u2 = fma(c.P[6], X0, fma(c.P[7], X1, fma(c.P[8], X2, c.q[2])));
+    const double iz = fast_rcp(u2);
+    const double p[2] = {u0 * iz, u1 * iz};
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            o.Jp[m][k] = fma(-p[m], c.P[6 + k], c.P[3 * m + k]) * iz;
+            o.Jc[m][3 + k] = fma(-p[m], Ks[6 + k], Ks[3 * m + k]) * iz;
+        }
+        const double g0 = X1 * o.Jp[m][2] - X2 * o.Jp[m][1];
+        const double g1 = X2 * o.Jp[m][0] - X0 * o.Jp[m][2];
+        const double g2 = X0 * o.Jp[m][1] - X1 * o.Jp[m][0];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) o.Jc[m][k] = fma(g0, Jr[k], fma(g1, Jr[3 + k], g2 * Jr[6 + k]));
+    }
+}
+
+constexpr int SLAB2 = 32;      // doubles per wave beside the reduction slab: Jr_i[9] (+pad to 16), Jr_2[9]
+// Per-chunk descriptor, written by schur_prepare_kernel in front of every build: what a wave needs to start on its chunk
+// in ONE (scalar) load instead of the chain chunk_seg -> seg_ids -> seg_chunk_ptr.  The kernel is bound by the latency of
+// its chain of dependent loads times the waves in flight (two per SIMD), not by arithmetic: halving the instruction count
+// (lean evaluator) alone changed nothing; three dependent hops instead of seven did.
+struct ChunkDesc {
+    int32_t i, f2, e_begin, e_end, sidx, c_first, n_ch, pad;
+};
+__device__ __forceinline__ CamPQ cam_pq_scalar(const double *__restrict__ t) {   // t uniform -> s_load
+    CamPQ v;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) v.P[k] = t[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v.q[k] = t[9 + k];
+    return v;
+}
+template <int OCC>      // waves per SIMD the register allocation aims at (2: no scratch; 3: a few spilled values)
+__global__ __launch_bounds__(64 * SP_WAVES, OCC) void schur_pairs_kernel(mm_ba_problem pb, const double *__restrict__ camtab,
+                                                                    const ChunkDesc *__restrict__ desc,
+                                                                    const double *__restrict__ pts,
+                                                                    const double *__restrict__ Cinv,
+                                                                    const double *__restrict__ gp,
+                                                                    double *partial, const double *__restrict__ Bd,
+                                                                    const double *__restrict__ gc, double *S, double *v,
+                                                                    int32_t *seg_done, SlabSync slabs, unsigned wg_begin,
+                                                                    unsigned wg_total) {
+    __shared__ double Ks[9];
+    __shared__ double red[SP_WAVES][21 * RED_LD];
+    __shared__ double jrs[SP_WAVES][SLAB2];
+    if (threadIdx.x < 9) Ks[threadIdx.x] = pb.K[threadIdx.x];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned gpos = blockIdx.x + wg_begin;
+    const unsigned wg = (gpos & 1) ? wg_total - 1 - (gpos >> 1) : (gpos >> 1);
+    const int64_t c = (int64_t)wg * SP_WAVES + wv;
+    const bool live = c < pb.n_chunks;
+    ChunkDesc cd = {};
+    if (live) cd = desc[c];      // (uniform address: one scalar load)
+    const int i = cd.i, f2 = cd.f2, d = cd.i - cd.f2, sidx = cd.sidx;
+    const int e_begin = cd.e_begin, e_end = cd.e_end;
+    // second hop, all at once: the two cameras' tables (scalar P, q; J_r through the wave's LDS slab) and the first trip's
+    // point index
+    auto point_of = [&](int e) { return pb.pair_p ? pb.pair_p[e] : pb.pi[pb.pair_o[e]]; };
+    auto self_of = [&](int e) { return d == 0 && pb.pair_o[e] == pb.pair_o2[e]; };
+    int e = e_begin + lane;
+    int p_next = -1;
+    bool self_next = false;
+    if (live) {
+        if (e < e_end) {
+            p_next = point_of(e);
+            self_next = self_of(e);
+        }
+        if (lane < 9) jrs[wv][lane] = camtab[(size_t)i * CAMTAB2 + 12 + lane];
+        else if (lane >= 16 && lane < 25) jrs[wv][lane] = camtab[(size_t)f2 * CAMTAB2 + 12 + lane - 16];
+    }
+    __syncthreads();      // (Ks; the wave's own slab would only need a wave barrier)
+    if (!live) return;    // wave-uniform; no workgroup barriers below
+    const CamPQ cp_i = cam_pq_scalar(camtab + (size_t)i * CAMTAB2), cp_2 = cam_pq_scalar(camtab + (size_t)f2 * CAMTAB2);
+    const double *Jr_i = jrs[wv], *Jr_2 = jrs[wv] + 16;
+    double acc[42];
+#pragma unroll
+    for (int q = 0; q < 42; ++q) acc[q] = 0.0;
+    // (the point of a pair is all the kernel gathers by: the observed coordinates are not needed)
+    auto pair_body = [&](int p, bool self) {
+        const double *Xp = pts + (size_t)p * 3;
+        const double X0 = Xp[0], X1 = Xp[1], X2 = Xp[2];
+        const double *ci = Cinv + (size_t)p * 6;
+        const double q00 = ci[0], q01 = ci[1], q02 = ci[2], q11 = ci[3], q12 = ci[4], q22 = ci[5];
+        LeanJ a;
+        lean_eval(cp_i, Ks, Jr_i, X0, X1, X2, a);
+        // E_o C^-1 E_o2^T = Jc_o^T (Jp_o C^-1 Jp_o2^T) Jc_o2 through the 2 x 2 middle factor
+        double Z[2][3];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            Z[m][0] = a.Jp[m][0] * q00 + a.Jp[m][1] * q01 + a.Jp[m][2] * q02;
+            Z[m][1] = a.Jp[m][0] * q01 + a.Jp[m][1] * q11 + a.Jp[m][2] * q12;
+            Z[m][2] = a.Jp[m][0] * q02 + a.Jp[m][1] * q12 + a.Jp[m][2] * q22;
+        }
+        double M[2][2], T[2][6];
+        if (d == 0) {
+            // (wave-uniform) the diagonal segment: both observations see the point from the SAME camera, so their Jacobians
+            // are the same whether or not o2 == o (a point observed twice in one frame) -- no second evaluation.  The
+            // right-hand side takes one term per observation: the self pairs.
+            if (self) {
+                const double g0 = gp[(size_t)p * 3], g1 = gp[(size_t)p * 3 + 1], g2 = gp[(size_t)p * 3 + 2];
+                const double z0 = Z[0][0] * g0 + Z[0][1] * g1 + Z[0][2] * g2, z1 = Z[1][0] * g0 + Z[1][1] * g1 + Z[1][2] * g2;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) acc[36 + q] += a.Jc[0][q] * z0 + a.Jc[1][q] * z1;
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n_ = 0; n_ < 2; ++n_) M[m][n_] = Z[m][0] * a.Jp[n_][0] + Z[m][1] * a.Jp[n_][1] + Z[m][2] * a.Jp[n_][2];
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                T[0][b] = M[0][0] * a.Jc[0][b] + M[0][1] * a.Jc[1][b];
+                T[1][b] = M[1][0] * a.Jc[0][b] + M[1][1] * a.Jc[1][b];
+            }
+        } else {
+            LeanJ b2;
+            lean_eval(cp_2, Ks, Jr_2, X0, X1, X2, b2);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n_ = 0; n_ < 2; ++n_) M[m][n_] = Z[m][0] * b2.Jp[n_][0] + Z[m][1] * b2.Jp[n_][1] + Z[m][2] * b2.Jp[n_][2];
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                T[0][b] = M[0][0] * b2.Jc[0][b] + M[0][1] * b2.Jc[1][b];
+                T[1][b] = M[1][0] * b2.Jc[0][b] + M[1][1] * b2.Jc[1][b];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int b = 0; b < 6; ++b) acc[q * 6 + b] += a.Jc[0][q] * T[0][b] + a.Jc[1][q] * T[1][b];
+    };
+    // software pipeline over the trips of the chunk: the NEXT pair's point index is requested before the current pair is
+    // worked on (a chunk holds at most 256 pairs = four trips, longer ones for other callers)
+    for (; e - lane < e_end; e += 64) {      // (wave-uniform trip count)
+        const int p = p_next;
+        const bool self = self_next;
+        const int en = e + 64;
+        p_next = en < e_end ? point_of(en) : -1;
+        self_next = en < e_end && self_of(en);
+        if (p >= 0) pair_body(p, self);
+    }
+    double tot0, tot1;
+    wave_reduce_42(acc, red[wv], lane, tot0, tot1);
+    // ---- finish the segment (as in the reference formulation above) ----
+    const int c_first = cd.c_first, n_ch = cd.n_ch;
+    const size_t n = (size_t)pb.F * 6;
+    bool writer = true;
+    if (n_ch > 1) {
+        if (lane < 21) {
+            __hip_atomic_store(partial + (size_t)c * 42 + lane, tot0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(partial + (size_t)c * 42 + 21 + lane, tot1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        int last = 0;
+        if (lane == 0) last = atomicAdd(seg_done + sidx, 1) == n_ch - 1;
+        writer = __shfl(last, 0, 64) != 0;
+        if (writer && lane < 21) {
+            tot0 = 0.0;
+            tot1 = 0.0;
+            for (int cc = 0; cc < n_ch; ++cc) {
+                tot0 += __hip_atomic_load(partial + (size_t)(c_first + cc) * 42 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                tot1 += __hip_atomic_load(partial + (size_t)(c_first + cc) * 42 + 21 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    if (!writer) return;
+    if (lane < 21) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int q = 21 * h + lane;
+            const double sum = h == 0 ? tot0 : tot1;
+            if (q < 36) {
+                double val = -sum;
+                if (d == 0) val += Bd[(size_t)i * 36 + q];
+                __hip_atomic_store(S + ((size_t)i * 6 + q / 6) * n + (size_t)f2 * 6 + q % 6, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (d != 0)
+                    __hip_atomic_store(S + ((size_t)f2 * 6 + q % 6) * n + (size_t)i * 6 + q / 6, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (d == 0) {
+                __hip_atomic_store(v + (size_t)i * 6 + (q - 36), gc[(size_t)i * 6 + (q - 36)] - sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    if (slabs.ready) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            const int sl = i / slabs.cams_per_slab;
+            if (atomicAdd(slabs.done + sl, 1) == slabs.seg_count[sl] - 1)
+                __hip_atomic_store(slabs.ready + sl, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // marks a camera slab without any segment as complete (its rows only hold what schur_diag_fill wrote)
 __global__ void slab_flag_kernel(int32_t *flags, int s) {
     __hip_atomic_store(flags + s, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -381,20 +639,26 @@ __global__ __launch_bounds__(256) void schur_prepare_kernel(mm_ba_problem pb, co
                                                             const double *__restrict__ Bd, const double *__restrict__ Cd,
                                                             const double *__restrict__ gc, double *__restrict__ Cinv,
                                                             double *__restrict__ S, double *__restrict__ v,
-                                                            double *__restrict__ tab, int32_t *__restrict__ seg_done) {
+                                                            double *__restrict__ tab, int32_t *__restrict__ seg_done, bool lean,
+                                                            int32_t *__restrict__ desc /* [n_chunks][8] or NULL */) {
     const int b = blockIdx.x, tid = threadIdx.x;
     for (int64_t k = (int64_t)b * 256 + tid; k < pb.n_seg; k += (int64_t)gridDim.x * 256) seg_done[k] = 0;
+    if (desc) write_chunk_desc(pb, desc, (int64_t)b * 256 + tid, (int64_t)gridDim.x * 256);
     const int f = b * 256 + tid;
     if (f < pb.F) {
         const double *c = cams + (size_t)f * 6;
-        const CamCoef k = cam_coef_of(c);
-        double *t = tab + (size_t)f * CAMTAB;
-        for (int q = 0; q < 6; ++q) t[q] = c[q];
-        t[6] = k.c;
-        t[7] = k.a;
-        t[8] = k.b;
-        t[9] = k.a1;
-        t[10] = k.b1;
+        if (lean) {
+            cam_table2_row(c, pb.K, tab + (size_t)f * CAMTAB2);
+        } else {
+            const CamCoef k = cam_coef_of(c);
+            double *t = tab + (size_t)f * CAMTAB;
+            for (int q = 0; q < 6; ++q) t[q] = c[q];
+            t[6] = k.c;
+            t[7] = k.a;
+            t[8] = k.b;
+            t[9] = k.a1;
+            t[10] = k.b1;
+        }
     }
     if (b < pb.F && pb.cam_ptr[b + 1] == pb.cam_ptr[b]) {      // camera b never appears in a segment: (Bd, gc) as they are
         const size_t n = (size_t)pb.F * 6;
@@ -486,13 +750,41 @@ extern "C" size_t mm_ba_schur_workspace_bytes(const mm_ba_problem *pb) {
     return mm_align_up((size_t)pb->n_chunks * 42 * sizeof(double), 256) /* partial sums of multi-chunk segments */ +
            mm_align_up((size_t)pb->n_seg * sizeof(int32_t), 256) /* finished-chunk counters */ +
            mm_align_up(2 * MAX_SLABS * sizeof(int32_t), 256) /* slab flags, slab counters */ +
-           mm_align_up((size_t)pb->F * CAMTAB * sizeof(double), 256) /* per-camera table */;
+           mm_align_up((size_t)pb->F * CAMTAB2 * sizeof(double), 256) /* per-camera table */ +
+           mm_align_up((size_t)pb->n_chunks * 32, 256) /* per-chunk descriptors */;
 }
 
 namespace {
+// MM_SCHUR_PAIRS=ref: the round-3 pair kernel (full evaluator per observation); default: the lean one
+bool schur_pairs_lean() {
+    static const bool lean = [] {
+        const char *e = getenv("MM_SCHUR_PAIRS");
+        return !(e && e[0] == 'r');
+    }();
+    return lean;
+}
+int schur_pairs_occ() {
+    static const int occ = [] {
+        const char *e = getenv("MM_SCHUR_OCC");
+        return e ? atoi(e) : 2;
+    }();
+    return occ;
+}
+#define MM_LAUNCH_PAIRS(ctx, grid, pbv, camtab_, desc_, ...)                                                             \
+    do {                                                                                                                 \
+        if (schur_pairs_lean() && schur_pairs_occ() == 3)                                                                \
+            MM_LAUNCH(ctx, "schur_pairs_kernel", schur_pairs_kernel<3>, grid, dim3(64 * SP_WAVES), 0, pbv, camtab_,      \
+                      (const ChunkDesc *)(desc_), __VA_ARGS__);                                                          \
+        else if (schur_pairs_lean())                                                                                     \
+            MM_LAUNCH(ctx, "schur_pairs_kernel", schur_pairs_kernel<2>, grid, dim3(64 * SP_WAVES), 0, pbv, camtab_,      \
+                      (const ChunkDesc *)(desc_), __VA_ARGS__);                                                          \
+        else                                                                                                             \
+            MM_LAUNCH(ctx, "schur_pairs_ref_kernel", schur_pairs_ref_kernel, grid, dim3(64 * SP_WAVES), 0, pbv, camtab_, \
+                      __VA_ARGS__);                                                                                      \
+    } while (0)
 struct SchurWs {
     double *partial, *camtab;
-    int32_t *seg_done, *slab_ready, *slab_done;
+    int32_t *seg_done, *slab_ready, *slab_done, *desc;
 };
 SchurWs carve_schur_ws(const mm_ba_problem *pb, void *ws) {
     SchurWs w;
@@ -505,6 +797,8 @@ SchurWs carve_schur_ws(const mm_ba_problem *pb, void *ws) {
     w.slab_done = w.slab_ready + MAX_SLABS;
     p += mm_align_up(2 * MAX_SLABS * sizeof(int32_t), 256);
     w.camtab = (double *)p;
+    p += mm_align_up((size_t)pb->F * CAMTAB2 * sizeof(double), 256);
+    w.desc = (int32_t *)p;
     return w;
 }
 }  // namespace
@@ -528,10 +822,9 @@ extern "C" int mm_ba_schur(mm_ctx *ctx, const mm_ba_problem *pb, const double *c
         SlabSync none = {};
         const int prep = (pb->P + 255) / 256 > pb->F ? (pb->P + 255) / 256 : pb->F;
         MM_LAUNCH(ctx, "schur_prepare_kernel", schur_prepare_kernel, dim3(prep), dim3(256), 0, *pb, cams, Bd, Cd, gc, Cinv, S, v,
-                  w.camtab, w.seg_done);
-        MM_LAUNCH(ctx, "schur_pairs_kernel", schur_pairs_kernel, dim3((unsigned)wgs), dim3(64 * SP_WAVES), 0, *pb,
-                  (const double *)w.camtab, pts, (const double *)Cinv, gp, w.partial, Bd, gc, S, v, w.seg_done, none, 0u,
-                  (unsigned)wgs);
+                  w.camtab, w.seg_done, schur_pairs_lean(), schur_pairs_lean() ? w.desc : (int32_t *)nullptr);
+        MM_LAUNCH_PAIRS(ctx, dim3((unsigned)wgs), *pb, (const double *)w.camtab, w.desc, pts, (const double *)Cinv, gp, w.partial, Bd, gc, S, v,
+                        w.seg_done, none, 0u, (unsigned)wgs);
         return MM_OK;
     }
     if (pb->P > 0)
@@ -586,7 +879,8 @@ extern "C" int mm_ba_schur_solve(mm_ctx *ctx, const mm_ba_problem *pb, const dou
     slabs.cams_per_slab = cams_per_slab;
     for (int sl = 0; sl < n_slabs; ++sl) slabs.seg_count[sl] = (int32_t)(slab_seg_ptr[sl + 1] - slab_seg_ptr[sl]);
     MM_LAUNCH(ctx, "cam_table_kernel", cam_table_kernel, dim3((pb->F + 63) / 64), dim3(64), 0, pb->F, cams, w.camtab, w.seg_done,
-              (int64_t)pb->n_seg);
+              (int64_t)pb->n_seg, schur_pairs_lean() ? pb->K : (const double *)nullptr, *pb,
+              schur_pairs_lean() ? w.desc : (int32_t *)nullptr);
     MM_HIP(ctx, hipMemsetAsync(S, 0, (size_t)n * n * sizeof(double), ctx->stream));
     MM_HIP(ctx, hipMemsetAsync(w.slab_ready, 0, 2 * MAX_SLABS * sizeof(int32_t), ctx->stream));
     MM_LAUNCH(ctx, "schur_diag_fill_kernel", schur_diag_fill_kernel, dim3(pb->F), dim3(64), 0, *pb, Bd, gc, S, v);
@@ -600,8 +894,8 @@ extern "C" int mm_ba_schur_solve(mm_ctx *ctx, const mm_ba_problem *pb, const dou
     const unsigned wg_total = (unsigned)((pb->n_chunks + SP_WAVES - 1) / SP_WAVES);
     const unsigned wg_first = wg_total / 2;
     if (wg_first > 0)
-        MM_LAUNCH(ctx, "schur_pairs_kernel", schur_pairs_kernel, dim3(wg_first), dim3(64 * SP_WAVES), 0, *pb,
-                  (const double *)w.camtab, pts, (const double *)Cinv, gp, w.partial, Bd, gc, S, v, w.seg_done, slabs, 0u, wg_total);
+        MM_LAUNCH_PAIRS(ctx, dim3(wg_first), *pb, (const double *)w.camtab, w.desc, pts, (const double *)Cinv, gp, w.partial, Bd, gc, S, v,
+                        w.seg_done, slabs, 0u, wg_total);
     MM_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
     MM_HIP(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
     {
@@ -614,8 +908,8 @@ extern "C" int mm_ba_schur_solve(mm_ctx *ctx, const mm_ba_problem *pb, const dou
         }
         MM_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
     }
-    MM_LAUNCH(ctx, "schur_pairs_kernel", schur_pairs_kernel, dim3(wg_total - wg_first), dim3(64 * SP_WAVES), 0, *pb,
-              (const double *)w.camtab, pts, (const double *)Cinv, gp, w.partial, Bd, gc, S, v, w.seg_done, slabs, wg_first, wg_total);
+    MM_LAUNCH_PAIRS(ctx, dim3(wg_total - wg_first), *pb, (const double *)w.camtab, w.desc, pts, (const double *)Cinv, gp, w.partial, Bd, gc, S, v,
+                    w.seg_done, slabs, wg_first, wg_total);
     MM_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     return MM_OK;
 }
