@@ -1546,10 +1546,13 @@ extern "C" int mm_debug_chol_trace(unsigned long long *host /*[128*32]*/) {
 // contribution buffer start out as a NaN sentinel (host memset 0xFF) and every reader polls the very 8 bytes it needs
 // (written by one write-through store), so a hand-over costs one memory latency instead of store-ack + flag + load.
 // Every tile a workgroup needs next is already in flight (registers) while it waits.
+// (Round 4, tried and dropped: the chain's workgroup also owning the SECOND sub-diagonal -- on the theory that the chain
+// waits for the d = 2 term's two trips through memory -- made a step 1.6 us LONGER (121 -> 166 us per solve at n = 3000):
+// the chain is bound by its own tile commits, matrix-vector products and barriers, not by the hand-over.)
 // Two-ended: side 0 walks M then T upwards; side 1 starts from the x of M (polled like any other) and walks its own
 // columns in its reversed numbering -- the two chains of a + m and b steps run side by side.
 constexpr unsigned long long BWD_SENTINEL = ~0ull;
-constexpr size_t BWD_LDS_BYTES = (size_t)(3 * NB * LDT + 4 * NB + 2 * NB) * sizeof(double);
+constexpr size_t BWD_LDS_BYTES = (size_t)(2 * NB * LDT + 4 * NB + 2 * NB) * sizeof(double);
 
 __device__ __forceinline__ void tile_prefetch(double (&pre)[16], const TileRef &t) {
 #pragma unroll
@@ -1592,9 +1595,8 @@ __global__ __launch_bounds__(256) void chol_band_bwd_kernel(double *A, TwGeom g,
     extern __shared__ double smem[];
     double (*T0)[LDT] = reinterpret_cast<double (*)[LDT]>(smem);
     double (*T1)[LDT] = reinterpret_cast<double (*)[LDT]>(smem + NB * LDT);
-    double (*T2)[LDT] = reinterpret_cast<double (*)[LDT]>(smem + 2 * NB * LDT);
-    double (*part)[NB] = reinterpret_cast<double (*)[NB]>(smem + 3 * NB * LDT);
-    double *vec = smem + 3 * NB * LDT + 4 * NB, *vec2 = vec + NB;
+    double (*part)[NB] = reinterpret_cast<double (*)[NB]>(smem + 2 * NB * LDT);
+    double *vec = smem + 2 * NB * LDT + 4 * NB, *vec2 = vec + NB;
     const int bwb = g.bwb, W = bwb + 1, nblk = g.nblk, n = g.n;
     const int GB = bwb >= 2 ? bwb : 1;  // workgroups per side
     const int side = (int)blockIdx.x / GB, lid = (int)blockIdx.x % GB;
@@ -1610,22 +1612,14 @@ __global__ __launch_bounds__(256) void chol_band_bwd_kernel(double *A, TwGeom g,
     };
     int failed = 0;
     // tiles are fetched two steps ahead (a step is shorter than a trip to memory): two register slots, loop unrolled by 2
-    // Round 4: the chain's workgroup also owns the SECOND sub-diagonal.  With d = 2 on a neighbour the term
-    // L_{k+2,k}^T x_{k+2} had exactly one step of the chain (x_{k+2} out, polled by the neighbour, 64-vector back, polled
-    // here) to make two trips through memory, and the chain waited for it every step (4.4 us per step against ~2 us of
-    // own work); the nearest remote term is now d = 3 with two steps of slack.  Same products, same summation order:
-    // bit-identical results.
-    const bool own2 = bwb >= 2;
     if (lid == 0) {
-        double p0a[16], p1a[16], p2a[16], p0b[16], p1b[16], p2b[16];
-        auto fetch = [&](int k, double (&p0)[16], double (&p1)[16], double (&p2)[16]) {  // tiles of step k: L_kk^-1, L_{k,k-1}, L_{k,k-2}
+        double p0a[16], p1a[16], p0b[16], p1b[16];
+        auto fetch = [&](int k, double (&p0)[16], double (&p1)[16]) {  // tiles of step k: L_kk^-1 and L_{k,k-1}
             if (k < 0) return;
             tile_prefetch_dense(p0, Linv + (size_t)nat(k) * NB * NB);
             if (k > 0) tile_prefetch(p1, tile_ref(A, g, side, k, k - 1));
-            if (own2 && k > 1) tile_prefetch(p2, tile_ref(A, g, side, k, k - 2));
         };
         double local = 0.0;  // L_{k+1,k}^T x_{k+1}, element threadIdx.x (first 64 threads)
-        double l2_cur = 0.0, l2_pending = 0.0;  // L_{k+2,k}^T x_{k+2} for this step / for the next one
         bool dead = false;
         // y_k and the contributions of step k are requested during step k + 1 (right after x_{k+1} went out), so their
         // memory latency overlaps the local matrix-vector work; what is still the sentinel then gets polled
@@ -1635,20 +1629,18 @@ __global__ __launch_bounds__(256) void chol_band_bwd_kernel(double *A, TwGeom g,
             long vi;
             yk = vpos(k, vi) ? y[vi] : 0.0;
 #pragma unroll
-            for (int dd = 3; dd <= FUSED_MAX_BWB; ++dd)
+            for (int dd = 2; dd <= FUSED_MAX_BWB; ++dd)
                 if (dd <= bwb && k + dd < nrows)
                     cv[dd] = __hip_atomic_load(cslot(k, dd) + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
-        auto step = [&](int k, double (&p0)[16], double (&p1)[16], double (&p2)[16]) {
+        auto step = [&](int k, double (&p0)[16], double (&p1)[16]) {
             tile_commit(T0, p0);
             if (k > 0) tile_commit(T1, p1);
-            if (own2 && k > 1) tile_commit(T2, p2);
-            fetch(k - 2, p0, p1, p2);
+            fetch(k - 2, p0, p1);
             if (threadIdx.x < NB) {
                 double rhs = yk - local;
-                if (own2 && k + 2 < nrows) rhs -= l2_cur;      // (the d = 2 term, in its place of the fixed order)
 #pragma unroll
-                for (int dd = 3; dd <= FUSED_MAX_BWB; ++dd)  // fixed summation order
+                for (int dd = 2; dd <= FUSED_MAX_BWB; ++dd)  // fixed summation order
                     if (dd <= bwb && k + dd < nrows) {
                         if ((unsigned long long)__double_as_longlong(cv[dd]) == BWD_SENTINEL)
                             cv[dd] = poll_value(cslot(k, dd) + threadIdx.x, abort_flag, failed);
@@ -1670,20 +1662,13 @@ __global__ __launch_bounds__(256) void chol_band_bwd_kernel(double *A, TwGeom g,
             request(k - 1);
             __syncthreads();
             if (k > 0) local = tile_matvec_t(T1, vec2, part);
-            __syncthreads();  // part is rewritten
-            l2_cur = l2_pending;
-            if (own2 && k > 1) {
-                l2_pending = tile_matvec_t(T2, vec2, part);
-                __syncthreads();  // T0 / T1 / T2 / part are rewritten by the next step
-            } else {
-                l2_pending = 0.0;
-            }
+            __syncthreads();  // T0 / T1 / part are rewritten by the next step
         };
         const int ktop = ncols - 1;  // first block this chain solves for
         if (ktop < 0) return;
         if (side == 1 && ktop + 1 < nrows && bwb >= 1) {
-            // the rows above the chain's first block belong to M: their x comes from side 0, the blocks (ktop + 1, ktop),
-            // (ktop + 2, ktop) and (ktop + 1, ktop - 1) are this side's -> `local`, `l2_cur`, `l2_pending` of the first steps
+            // the row above the chain's first block belongs to M: x of that row comes from side 0, the block
+            // (ktop + 1, ktop) is this side's -> `local` for the first step
             double pt[16];
             tile_prefetch(pt, tile_ref(A, g, side, ktop + 1, ktop));
             tile_commit(T1, pt);
@@ -1694,36 +1679,17 @@ __global__ __launch_bounds__(256) void chol_band_bwd_kernel(double *A, TwGeom g,
             if (__syncthreads_or(failed)) MM_FUSED_ABANDON;
             local = tile_matvec_t(T1, vec2, part);
             __syncthreads();
-            if (own2 && ktop >= 1) {      // (ktop + 1, ktop - 1): needs the same x_{ktop+1}
-                tile_prefetch(pt, tile_ref(A, g, side, ktop + 1, ktop - 1));
-                tile_commit(T2, pt);
-                __syncthreads();
-                l2_pending = tile_matvec_t(T2, vec2, part);
-                __syncthreads();
-            }
-            if (own2 && ktop + 2 < nrows) {      // (ktop + 2, ktop)
-                tile_prefetch(pt, tile_ref(A, g, side, ktop + 2, ktop));
-                tile_commit(T2, pt);
-                if (threadIdx.x < NB) {
-                    long vi;
-                    vec[threadIdx.x] = vpos(ktop + 2, vi) ? poll_value(x + vi, abort_flag, failed) : 0.0;
-                }
-                if (__syncthreads_or(failed)) MM_FUSED_ABANDON;
-                l2_cur = tile_matvec_t(T2, vec, part);
-                __syncthreads();
-            }
         }
         request(ktop);
-        fetch(ktop, p0a, p1a, p2a);
-        fetch(ktop - 1, p0b, p1b, p2b);
+        fetch(ktop, p0a, p1a);
+        fetch(ktop - 1, p0b, p1b);
         for (int k = ktop; k >= 0 && !dead; k -= 2) {
-            step(k, p0a, p1a, p2a);
-            if (k - 1 >= 0 && !dead) step(k - 1, p0b, p1b, p2b);
+            step(k, p0a, p1a);
+            if (k - 1 >= 0 && !dead) step(k - 1, p0b, p1b);
         }
         if (dead) MM_FUSED_ABANDON;
         return;
     }
-    if (own2 && lid == 1) return;      // d = 2 lives on the chain's workgroup now
     const int d = lid + 1;  // 2 .. bwb
     const int kfirst = min(nrows - 1 - d, ncols - 1);
     if (kfirst < 0) return;

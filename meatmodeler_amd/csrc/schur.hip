@@ -454,7 +454,7 @@ __device__ __forceinline__ CamPQ cam_pq_scalar(const double *__restrict__ t) {  
     for (int k = 0; k < 3; ++k) v.q[k] = t[9 + k];
     return v;
 }
-template <int OCC>      // waves per SIMD the register allocation aims at (2: no scratch; 3: a few spilled values)
+template <int OCC>      // waves per SIMD the register allocation aims at (2; 3 spills into scratch and is 1.8x slower: measured)
 __global__ __launch_bounds__(64 * SP_WAVES, OCC) void schur_pairs_kernel(mm_ba_problem pb, const double *__restrict__ camtab,
                                                                     const ChunkDesc *__restrict__ desc,
                                                                     const double *__restrict__ pts,
@@ -617,6 +617,12 @@ __global__ __launch_bounds__(64 * SP_WAVES, OCC) void schur_pairs_kernel(mm_ba_p
     }
 }
 
+
+// (Round 4, tried and dropped: a PERSISTENT variant of this kernel in which a wave walks a sequence of chunks and requests the
+// next chunks' descriptors, camera tables, point indices and first point / C^-1 while it works on the current one.  It
+// needs ~40 more registers than the 218 used here; with the 256 that two waves per SIMD leave, the compiler spills ~45
+// values around every chunk and the kernel ran at 320-350 us against 222 us for this one (tools/bench_schur.py shape).
+// Three waves per SIMD (168 registers, 55 values in scratch) took 411 us.)
 // marks a camera slab without any segment as complete (its rows only hold what schur_diag_fill wrote)
 __global__ void slab_flag_kernel(int32_t *flags, int s) {
     __hip_atomic_store(flags + s, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -755,7 +761,7 @@ extern "C" size_t mm_ba_schur_workspace_bytes(const mm_ba_problem *pb) {
 }
 
 namespace {
-// MM_SCHUR_PAIRS=ref: the round-3 pair kernel (full evaluator per observation); default: the lean one
+// MM_SCHUR_PAIRS=ref: the round-3 pair kernel (full evaluator per observation, index chain); default: the lean one
 bool schur_pairs_lean() {
     static const bool lean = [] {
         const char *e = getenv("MM_SCHUR_PAIRS");
@@ -763,19 +769,9 @@ bool schur_pairs_lean() {
     }();
     return lean;
 }
-int schur_pairs_occ() {
-    static const int occ = [] {
-        const char *e = getenv("MM_SCHUR_OCC");
-        return e ? atoi(e) : 2;
-    }();
-    return occ;
-}
 #define MM_LAUNCH_PAIRS(ctx, grid, pbv, camtab_, desc_, ...)                                                             \
     do {                                                                                                                 \
-        if (schur_pairs_lean() && schur_pairs_occ() == 3)                                                                \
-            MM_LAUNCH(ctx, "schur_pairs_kernel", schur_pairs_kernel<3>, grid, dim3(64 * SP_WAVES), 0, pbv, camtab_,      \
-                      (const ChunkDesc *)(desc_), __VA_ARGS__);                                                          \
-        else if (schur_pairs_lean())                                                                                     \
+        if (schur_pairs_lean())                                                                                          \
             MM_LAUNCH(ctx, "schur_pairs_kernel", schur_pairs_kernel<2>, grid, dim3(64 * SP_WAVES), 0, pbv, camtab_,      \
                       (const ChunkDesc *)(desc_), __VA_ARGS__);                                                          \
         else                                                                                                             \
