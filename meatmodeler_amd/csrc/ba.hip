@@ -17,11 +17,18 @@
 // are bitwise reproducible; only the Schur scatter into S uses f64 atomics.
 #include "ba_eval.h"
 
+// (Round 4, tried and dropped for the sweeps of this file: the "lean" evaluator of ba_eval.h -- projection and Jacobians
+// from per-camera matrices P = K R, q = K t and the right Jacobian J_r, ~64 instead of ~200 f64 instructions per
+// observation.  The sweeps are bound by their gathers, not by arithmetic: the lean table is 21 doubles per camera and
+// lane against 11 here, and every sweep got SLOWER -- Jacobian product 24 -> 34 us, residual 13 -> 18, back-substitution
+// 22 -> 32, point blocks 68 -> 80 us at 1.63 M observations.  The Schur pair kernel, where the two cameras of a chunk
+// are wave-uniform scalars, keeps it.)
+
 namespace {
 
 // ---- residual + cost ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ba_residual_kernel(mm_ba_problem pb, const double *__restrict__ cams,
-                                                          const double *__restrict__ pts, const double *__restrict__ ctab, double *__restrict__ res,
+                                                          const double *__restrict__ pts, const CamCoef *__restrict__ ctab, double *__restrict__ res,
                                                           double *__restrict__ partial) {
     __shared__ double sm[4];
     __shared__ double Ks[9];
@@ -31,7 +38,8 @@ __global__ __launch_bounds__(256) void ba_residual_kernel(mm_ba_problem pb, cons
     for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < pb.O; o += (int64_t)gridDim.x * 256) {
         Proj pr;
         const int f = pb.fi[o];
-        lean_eval_tab<false, false>(ctab + (size_t)f * CAMTAB2, pts + (size_t)pb.pi[o] * 3, Ks, pb.obs[2 * o], pb.obs[2 * o + 1], pr);
+        ba_eval_cc<false, false>(cams + (size_t)f * 6, ctab[f],
+                                 pts + (size_t)pb.pi[o] * 3, Ks, pb.obs[2 * o], pb.obs[2 * o + 1], pr);
         if (res) {
             res[2 * o] = pr.r0;
             res[2 * o + 1] = pr.r1;
@@ -77,7 +85,7 @@ __global__ __launch_bounds__(256) void sum_partials_publish_kernel(const double 
 
 // ---- analytic Jacobian blocks (parity surface) --------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ba_jacobian_kernel(mm_ba_problem pb, const double *__restrict__ cams,
-                                                          const double *__restrict__ pts, const double *__restrict__ ctab, double *__restrict__ Jc,
+                                                          const double *__restrict__ pts, const CamCoef *__restrict__ ctab, double *__restrict__ Jc,
                                                           double *__restrict__ Jp) {
     __shared__ double Ks[9];
     if (threadIdx.x < 9) Ks[threadIdx.x] = pb.K[threadIdx.x];
@@ -86,7 +94,8 @@ __global__ __launch_bounds__(256) void ba_jacobian_kernel(mm_ba_problem pb, cons
     if (o >= pb.O) return;
     Proj pr;
     const int f = pb.fi[o];
-    lean_eval_tab<true, true>(ctab + (size_t)f * CAMTAB2, pts + (size_t)pb.pi[o] * 3, Ks, pb.obs[2 * o], pb.obs[2 * o + 1], pr);
+    ba_eval_cc<true, true>(cams + (size_t)f * 6, ctab[f],
+                           pts + (size_t)pb.pi[o] * 3, Ks, pb.obs[2 * o], pb.obs[2 * o + 1], pr);
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
         Jc[o * 12 + k] = pr.Jc[0][k];
@@ -99,35 +108,53 @@ __global__ __launch_bounds__(256) void ba_jacobian_kernel(mm_ba_problem pb, cons
     }
 }
 
-// ---- point blocks: C[P,6] (upper triangle) and gp[P,3]; one thread per point, its observations are contiguous ------
+// ---- point blocks: C[P,6] (upper triangle) and gp[P,3]; FOUR lanes per point over its (contiguous) observations --------
+// (One thread per point waits for the waves that own the longest tracks -- 4 observations on average, up to the band width
+// (88 at C3): 68 us against 24 us for the Jacobian product over the same observations.  Four lanes stride over a point's
+// observations and add up in a fixed butterfly: deterministic, tracks of <= 4 observations in one trip.)
+constexpr int PB_LANES = 4;
 __global__ __launch_bounds__(256) void ba_point_blocks_kernel(mm_ba_problem pb, const double *__restrict__ cams,
-                                                              const double *__restrict__ pts, const double *__restrict__ ctab, double *__restrict__ C,
+                                                              const double *__restrict__ pts, const CamCoef *__restrict__ ctab, double *__restrict__ C,
                                                               double *__restrict__ gp) {
     __shared__ double Ks[9];
     if (threadIdx.x < 9) Ks[threadIdx.x] = pb.K[threadIdx.x];
     __syncthreads();
-    int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= pb.P) return;
-    double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0, g0 = 0, g1 = 0, g2 = 0;
-    const double *Xp = pts + (size_t)p * 3;
-    for (int e = pb.pt_ptr[p]; e < pb.pt_ptr[p + 1]; ++e) {
-        int o = pb.pt_obs[e];
-        Proj pr;
-        const int f = pb.fi[o];
-        lean_eval_tab<false, true>(ctab + (size_t)f * CAMTAB2, Xp, Ks,
-                                pb.obs[2 * (size_t)o], pb.obs[2 * (size_t)o + 1], pr);
+    const int sub = threadIdx.x & (PB_LANES - 1);
+    const int p = blockIdx.x * (256 / PB_LANES) + (threadIdx.x / PB_LANES);
+    const bool live = p < pb.P;      // (no early return: the shuffles below are executed by whole waves)
+    double c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // c00 c01 c02 c11 c12 c22 g0 g1 g2
+    if (live) {
+        const double *Xp = pts + (size_t)p * 3;
+        const int e_end = pb.pt_ptr[p + 1];
+        for (int e = pb.pt_ptr[p] + sub; e < e_end; e += PB_LANES) {
+            const int o = pb.pt_obs[e];
+            Proj pr;
+            const int f = pb.fi[o];
+            ba_eval_cc<false, true>(cams + (size_t)f * 6, ctab[f], Xp, Ks, pb.obs[2 * (size_t)o], pb.obs[2 * (size_t)o + 1], pr);
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const double j0 = pr.Jp[m][0], j1 = pr.Jp[m][1], j2 = pr.Jp[m][2];
-            const double r = m == 0 ? pr.r0 : pr.r1;
-            c00 += j0 * j0; c01 += j0 * j1; c02 += j0 * j2;
-            c11 += j1 * j1; c12 += j1 * j2; c22 += j2 * j2;
-            g0 += j0 * r; g1 += j1 * r; g2 += j2 * r;
+            for (int m = 0; m < 2; ++m) {
+                const double j0 = pr.Jp[m][0], j1 = pr.Jp[m][1], j2 = pr.Jp[m][2];
+                const double r = m == 0 ? pr.r0 : pr.r1;
+                c[0] += j0 * j0; c[1] += j0 * j1; c[2] += j0 * j2;
+                c[3] += j1 * j1; c[4] += j1 * j2; c[5] += j2 * j2;
+                c[6] += j0 * r; c[7] += j1 * r; c[8] += j2 * r;
+            }
         }
     }
-    double *Cp = C + (size_t)p * 6;
-    Cp[0] = c00; Cp[1] = c01; Cp[2] = c02; Cp[3] = c11; Cp[4] = c12; Cp[5] = c22;
-    gp[(size_t)p * 3] = g0; gp[(size_t)p * 3 + 1] = g1; gp[(size_t)p * 3 + 2] = g2;
+#pragma unroll
+    for (int off = 1; off < PB_LANES; off <<= 1) {
+        double t[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) t[q] = __shfl_xor(c[q], off, 64);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) c[q] += t[q];      // (a + b and b + a are the same double: all four lanes hold the same sums)
+    }
+    if (live && sub == 0) {
+        double *Cp = C + (size_t)p * 6;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) Cp[q] = c[q];
+        gp[(size_t)p * 3] = c[6]; gp[(size_t)p * 3 + 1] = c[7]; gp[(size_t)p * 3 + 2] = c[8];
+    }
 }
 
 // ---- camera blocks: B[F,6,6] and gc[F,6]; one workgroup per camera over its (gathered) observations -----------------
@@ -136,19 +163,20 @@ __global__ __launch_bounds__(256) void ba_camera_blocks_kernel(mm_ba_problem pb,
                                                                double *__restrict__ gc) {
     __shared__ double smn[4 * 27];
     __shared__ double Ks[9];
-    __shared__ double trow[CAMTAB2];
+    __shared__ double cs[6];
     const int f = blockIdx.x;
     if (threadIdx.x < 9) Ks[threadIdx.x] = pb.K[threadIdx.x];
-    if (threadIdx.x == 0) cam_table2_row(cams + (size_t)f * 6, pb.K, trow);      // (the same values as the sweeps' table)
+    if (threadIdx.x < 6) cs[threadIdx.x] = cams[(size_t)f * 6 + threadIdx.x];
     __syncthreads();
+    const CamCoef ccf = cam_coef_of(cs);
     double acc[27];
 #pragma unroll
     for (int i = 0; i < 27; ++i) acc[i] = 0;
     for (int e = pb.cam_ptr[f] + threadIdx.x; e < pb.cam_ptr[f + 1]; e += 256) {
         int o = pb.cam_obs[e];
         Proj pr;
-        lean_eval_tab<true, false>(trow, pts + (size_t)pb.pi[o] * 3, Ks, pb.obs[2 * (size_t)o], pb.obs[2 * (size_t)o + 1],
-                                   pr);
+        ba_eval_cc<true, false>(cs, ccf, pts + (size_t)pb.pi[o] * 3, Ks, pb.obs[2 * (size_t)o], pb.obs[2 * (size_t)o + 1],
+                                pr);
         int t = 0;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
@@ -178,7 +206,7 @@ __global__ __launch_bounds__(256) void ba_camera_blocks_kernel(mm_ba_problem pb,
 
 // ---- out = Jc wc[fi] + Jp wp[pi] ----------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ba_jvp_kernel(mm_ba_problem pb, const double *__restrict__ cams,
-                                                     const double *__restrict__ pts, const double *__restrict__ ctab, const double *__restrict__ wc,
+                                                     const double *__restrict__ pts, const CamCoef *__restrict__ ctab, const double *__restrict__ wc,
                                                      const double *__restrict__ wp, double *__restrict__ out) {
     __shared__ double Ks[9];
     if (threadIdx.x < 9) Ks[threadIdx.x] = pb.K[threadIdx.x];
@@ -187,7 +215,8 @@ __global__ __launch_bounds__(256) void ba_jvp_kernel(mm_ba_problem pb, const dou
     if (o >= pb.O) return;
     const int f = pb.fi[o], p = pb.pi[o];
     Proj pr;
-    lean_eval_tab<true, true>(ctab + (size_t)f * CAMTAB2, pts + (size_t)p * 3, Ks, pb.obs[2 * o], pb.obs[2 * o + 1], pr);
+    ba_eval_cc<true, true>(cams + (size_t)f * 6, ctab[f],
+                           pts + (size_t)p * 3, Ks, pb.obs[2 * o], pb.obs[2 * o + 1], pr);
     double y0 = 0, y1 = 0;
     if (wc) {
 #pragma unroll
@@ -215,7 +244,7 @@ __global__ __launch_bounds__(256) void ba_jvp_kernel(mm_ba_problem pb, const dou
 // two vector passes less per iteration.  Deterministic: fixed tree per workgroup, then one small launch adds the
 // per-workgroup partials in index order.
 __global__ __launch_bounds__(256) void ba_jvp_dots_kernel(mm_ba_problem pb, const double *__restrict__ cams,
-                                                          const double *__restrict__ pts, const double *__restrict__ ctab, const double *__restrict__ wc,
+                                                          const double *__restrict__ pts, const CamCoef *__restrict__ ctab, const double *__restrict__ wc,
                                                           const double *__restrict__ wp, double *__restrict__ out,
                                                           const double *__restrict__ other, double *__restrict__ partial) {
     __shared__ double Ks[9];
@@ -227,7 +256,8 @@ __global__ __launch_bounds__(256) void ba_jvp_dots_kernel(mm_ba_problem pb, cons
     for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < pb.O; o += (int64_t)gridDim.x * 256) {
         const int f = pb.fi[o], p = pb.pi[o];
         Proj pr;
-        lean_eval_tab<true, true>(ctab + (size_t)f * CAMTAB2, pts + (size_t)p * 3, Ks, pb.obs[2 * o], pb.obs[2 * o + 1], pr);
+        ba_eval_cc<true, true>(cams + (size_t)f * 6, ctab[f],
+                               pts + (size_t)p * 3, Ks, pb.obs[2 * o], pb.obs[2 * o + 1], pr);
         double y0 = 0, y1 = 0;
         if (wc) {
 #pragma unroll
@@ -280,7 +310,7 @@ __global__ __launch_bounds__(256) void jvp_rows_kernel(const double *__restrict_
 
 // ---- back-substitution: dp = Cinv (gp - sum_o Jp_o^T (Jc_o dc[f_o])) ------------------------------------------------
 __global__ __launch_bounds__(256) void ba_backsub_kernel(mm_ba_problem pb, const double *__restrict__ cams,
-                                                         const double *__restrict__ pts, const double *__restrict__ ctab,
+                                                         const double *__restrict__ pts, const CamCoef *__restrict__ ctab,
                                                          const double *__restrict__ Cinv, const double *__restrict__ gp,
                                                          const double *__restrict__ dc, double *__restrict__ dp) {
     __shared__ double Ks[9];
@@ -294,7 +324,7 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(mm_ba_problem pb, const
         int o = pb.pt_obs[e];
         int f = pb.fi[o];
         Proj pr;
-        lean_eval_tab<true, true>(ctab + (size_t)f * CAMTAB2, Xp, Ks,
+        ba_eval_cc<true, true>(cams + (size_t)f * 6, ctab[f], Xp, Ks,
                                pb.obs[2 * (size_t)o], pb.obs[2 * (size_t)o + 1], pr);
         double s0 = 0, s1 = 0;
 #pragma unroll
@@ -319,7 +349,7 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(mm_ba_problem pb, const
 // 3-vector Jp^T (Jc dc) into a scratch array in CSR-by-point order, pass 2 adds each point's rows in that order (a fixed
 // order: deterministic) and applies Cinv.
 __global__ __launch_bounds__(256) void ba_backsub_obs_kernel(mm_ba_problem pb, const double *__restrict__ cams,
-                                                             const double *__restrict__ pts, const double *__restrict__ ctab,
+                                                             const double *__restrict__ pts, const CamCoef *__restrict__ ctab,
                                                              const double *__restrict__ dc, double *__restrict__ T) {
     __shared__ double Ks[9];
     if (threadIdx.x < 9) Ks[threadIdx.x] = pb.K[threadIdx.x];
@@ -329,7 +359,7 @@ __global__ __launch_bounds__(256) void ba_backsub_obs_kernel(mm_ba_problem pb, c
     const int o = pb.pt_obs[e];
     const int f = pb.fi[o], p = pb.pi[o];
     Proj pr;
-    lean_eval_tab<true, true>(ctab + (size_t)f * CAMTAB2, pts + (size_t)p * 3, Ks, pb.obs[2 * (size_t)o],
+    ba_eval_cc<true, true>(cams + (size_t)f * 6, ctab[f], pts + (size_t)p * 3, Ks, pb.obs[2 * (size_t)o],
                            pb.obs[2 * (size_t)o + 1], pr);
     double s0 = 0, s1 = 0;
 #pragma unroll
@@ -363,10 +393,9 @@ __global__ __launch_bounds__(256) void ba_backsub_points_kernel(mm_ba_problem pb
 // ---- rotation coefficients of every camera, once per parameter vector ------------------------------------------------
 // (Every workgroup of every sweep used to fill its own LDS copy: two sincos per thread -- more arithmetic than the
 // observations it then processed -- and 40 KB of LDS.  Now: one small launch per NEW camera vector, gathers from L2.)
-__global__ __launch_bounds__(256) void cam_coef_kernel(const double *__restrict__ cams, int F, const double *__restrict__ K,
-                                                       double *__restrict__ tab) {
+__global__ __launch_bounds__(256) void cam_coef_kernel(const double *__restrict__ cams, int F, CamCoef *__restrict__ tab) {
     const int f = blockIdx.x * 256 + threadIdx.x;
-    if (f < F) cam_table2_row(cams + (size_t)f * 6, K, tab + (size_t)f * CAMTAB2);
+    if (f < F) tab[f] = cam_coef_of(cams + (size_t)f * 6);
 }
 
 int check_pb(mm_ctx *ctx, const mm_ba_problem *pb, const char *who) {
@@ -403,20 +432,19 @@ __global__ void trf_damping_kernel(const double *__restrict__ gh2, const double 
 // The table lives in the context.  `cam_tab_for` remembers which camera vector it was computed from; a caller that
 // knows the vector has not changed since (the library's own trust-region loop, trf.hip) keeps it valid with
 // mm_cam_table_hold() and the sweeps then skip the launch.  Everybody else gets a fresh table per call.
-int mm_cam_coef_table(mm_ctx *ctx, const double *cams, int F, const double *K, const void **tab_out) {
+int mm_cam_coef_table(mm_ctx *ctx, const double *cams, int F, const void **tab_out) {
     if (F > ctx->cam_tab_cap) {
         if (ctx->cam_tab) (void)hipFree(ctx->cam_tab);
         ctx->cam_tab = nullptr;
         ctx->cam_tab_cap = 0;
         const int cap = F < 1024 ? 1024 : F + F / 2;
-        MM_HIP(ctx, hipMalloc(&ctx->cam_tab, (size_t)cap * CAMTAB2 * sizeof(double)));
+        MM_HIP(ctx, hipMalloc(&ctx->cam_tab, (size_t)cap * sizeof(CamCoef)));
         ctx->cam_tab_cap = cap;
         ctx->cam_tab_for = nullptr;
     }
-    if (!(ctx->cam_tab_hold && ctx->cam_tab_for == cams && ctx->cam_tab_F == F && ctx->cam_tab_K == K)) {
+    if (!(ctx->cam_tab_hold && ctx->cam_tab_for == cams && ctx->cam_tab_F == F)) {
         if (F > 0)
-            MM_LAUNCH(ctx, "cam_coef_kernel", cam_coef_kernel, dim3((F + 255) / 256), dim3(256), 0, cams, F, K, (double *)ctx->cam_tab);
-        ctx->cam_tab_K = K;
+            MM_LAUNCH(ctx, "cam_coef_kernel", cam_coef_kernel, dim3((F + 255) / 256), dim3(256), 0, cams, F, (CamCoef *)ctx->cam_tab);
         ctx->cam_tab_for = cams;
         ctx->cam_tab_F = F;
     }
@@ -434,12 +462,12 @@ int mm_ba_residual_publish(mm_ctx *ctx, const mm_ba_problem *pb, const double *c
                            size_t ws_bytes, double *board, int cost_slot, int count, void *host_board, unsigned long long seq);
 
 #define MM_CAM_TABLE(ctx, pb, cams)                                               \
-    const double *ctab = nullptr;                                                 \
+    const CamCoef *ctab = nullptr;                                                \
     do {                                                                          \
         const void *t_ = nullptr;                                                 \
-        int rc_ = mm_cam_coef_table(ctx, cams, (pb)->F, (pb)->K, &t_);            \
+        int rc_ = mm_cam_coef_table(ctx, cams, (pb)->F, &t_);                     \
         if (rc_) return rc_;                                                      \
-        ctab = (const double *)t_;                                                \
+        ctab = (const CamCoef *)t_;                                               \
     } while (0)
 
 extern "C" {
@@ -479,7 +507,8 @@ int mm_ba_normal_eq(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, co
         if (!pb->pt_ptr || !pb->pt_obs) return mm_fail(ctx, MM_ERR_ARG, "mm_ba_normal_eq: point CSR missing");
         if (pb->P > 0) {
             MM_CAM_TABLE(ctx, pb, cams);
-            MM_LAUNCH(ctx, "ba_point_blocks_kernel", ba_point_blocks_kernel, dim3((pb->P + 255) / 256), dim3(256), 0, *pb, cams, pts, ctab, C, gp);
+            MM_LAUNCH(ctx, "ba_point_blocks_kernel", ba_point_blocks_kernel, dim3((pb->P + 256 / PB_LANES - 1) / (256 / PB_LANES)), dim3(256), 0,
+                      *pb, cams, pts, ctab, C, gp);
         }
     }
     if (B) {

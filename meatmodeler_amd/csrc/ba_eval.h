@@ -156,7 +156,7 @@ __device__ __forceinline__ void ba_eval_vals(const CamVals &cv, const double *__
     }
 }
 
-// ---- the lean evaluator (round 4) ---------------------------------------------------------------------------------------
+// ---- the lean evaluator's camera table (round 4; used by the Schur pair kernel, schur.hip) ---------------------------------
 // Everything a sweep needs of an observation follows from per-CAMERA matrices, tabulated once per camera vector:
 //   u = P X + q           P = K R (3 x 3), q = K t                       (9 FMA)
 //   p = u[:2] / u[2], residual = p - obs
@@ -166,7 +166,9 @@ __device__ __forceinline__ void ba_eval_vals(const CamVals &cv, const double *__
 // with J_r = a I - b [r]x + e r r^T the right Jacobian of SO(3): d (R X) / d r = -R [X]x J_r, hence
 // d proj / d r = M R (-[X]x) J_r = -Jp [X]x J_r (a = sin th / th, b = (1 - cos th) / th^2, e = (1 - a) / th^2).
 // ~64 f64 instructions per observation instead of the ~200 of ba_eval_vals (which differentiates the Rodrigues formula
-// term by term); the same function up to rounding (tests: golden G3 at 1e-10, central differences).
+// term by term); the same function up to rounding.  It pays where the camera is wave-uniform (the pair kernel: P, q in
+// scalar registers); the per-observation sweeps of ba.hip gather their camera per lane and were slower with the 21-double
+// row than with the 11 doubles ba_eval_cc reads (measured, see ba.hip).
 constexpr int CAMTAB2 = 24;      // doubles per camera: P[9] q[3] Jr[9] + 3 padding (16-byte rows)
 __device__ __forceinline__ void cam_table2_row(const double *__restrict__ c, const double *__restrict__ K, double *__restrict__ t) {
     const double rx = c[0], ry = c[1], rz = c[2];
@@ -189,39 +191,6 @@ __device__ __forceinline__ void cam_table2_row(const double *__restrict__ c, con
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) t[12 + 3 * i + j] = (i == j ? k.a : 0.0) - k.b * hat[i][j] + e * rr[i] * rr[j];
     t[21] = t[22] = t[23] = 0.0;
-}
-
-// t: the camera's table row (global memory per lane, or an LDS copy when the whole workgroup works on one camera)
-template <bool WANT_JC, bool WANT_JP>
-__device__ __forceinline__ void lean_eval_tab(const double *__restrict__ t, const double *__restrict__ Xp,
-                                              const double *__restrict__ K, double ox, double oy, Proj &o) {
-    const double X0 = Xp[0], X1 = Xp[1], X2 = Xp[2];
-    const double P6 = t[6], P7 = t[7], P8 = t[8];
-    const double u0 = fma(t[0], X0, fma(t[1], X1, fma(t[2], X2, t[9])));
-    const double u1 = fma(t[3], X0, fma(t[4], X1, fma(t[5], X2, t[10])));
-    const double u2 = fma(P6, X0, fma(P7, X1, fma(P8, X2, t[11])));
-    const double iz = 1.0 / u2;
-    const double p0 = u0 * iz, p1 = u1 * iz;
-    o.r0 = p0 - ox;
-    o.r1 = p1 - oy;
-    if (!WANT_JC && !WANT_JP) return;
-    const double p[2] = {p0, p1};
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const double j0 = fma(-p[m], P6, t[3 * m]) * iz, j1 = fma(-p[m], P7, t[3 * m + 1]) * iz, j2 = fma(-p[m], P8, t[3 * m + 2]) * iz;
-        if (WANT_JP) {
-            o.Jp[m][0] = j0;
-            o.Jp[m][1] = j1;
-            o.Jp[m][2] = j2;
-        }
-        if (WANT_JC) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) o.Jc[m][3 + k] = fma(-p[m], K[6 + k], K[3 * m + k]) * iz;
-            const double g0 = X1 * j2 - X2 * j1, g1 = X2 * j0 - X0 * j2, g2 = X0 * j1 - X1 * j0;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) o.Jc[m][k] = fma(g0, t[12 + k], fma(g1, t[15 + k], g2 * t[18 + k]));
-        }
-    }
 }
 
 template <bool WANT_JC, bool WANT_JP>

@@ -46,7 +46,7 @@ struct mm_ctx {
     // rotation coefficients of the cameras the BA sweeps were last called with (ba.hip: mm_cam_coef_table)
     void *cam_tab = nullptr;
     int cam_tab_cap = 0, cam_tab_F = 0;
-    const double *cam_tab_for = nullptr, *cam_tab_K = nullptr;
+    const double *cam_tab_for = nullptr;
     bool cam_tab_hold = false;
     // pinned, device-visible host mailbox of mm_ba_trf (trf.hip): the trial-step scalars are written into it by a kernel
     // and the host spins on its sequence number instead of paying a copy + stream synchronisation per trial step
@@ -63,7 +63,7 @@ struct mm_stream_swap {
 };
 
 // ba.hip: per-camera rotation coefficients shared by the sweeps (see there)
-int mm_cam_coef_table(mm_ctx *ctx, const double *cams, int F, const double *K, const void **tab_out);
+int mm_cam_coef_table(mm_ctx *ctx, const double *cams, int F, const void **tab_out);
 void mm_cam_table_hold(mm_ctx *ctx, bool on);       // on: the table stays valid for the same camera pointer until ...
 void mm_cam_table_invalidate(mm_ctx *ctx);          // ... the caller says the vector behind it changed
 
