@@ -58,6 +58,9 @@ def parse():
                          "over --ba-streams streams per GPU; sequential = every window starts from its predecessor's result)")
     ap.add_argument("--ba-streams", type=int, default=8,
                     help="wavefront schedule: windows in flight per GPU (one HIP stream + host thread each)")
+    ap.add_argument("--ba-batched", type=int, default=1,
+                    help="wavefront schedule: 1 = all windows of a pass in ONE lock-step solve (mm_ba_trf_batched), 0 = one solve "
+                         "per window on --ba-streams streams")
     ap.add_argument("--verbose", type=int, default=0)
     ap.add_argument("--no-profile", action="store_true", help="no per-launch HIP events in the timed steps")
     return ap.parse_args()
@@ -198,7 +201,7 @@ def main():
             o["windows"] = pipe.adjust_windows(o, K, ext, window=a.ba_window, stride=a.ba_stride or max(1, a.ba_window // 2),
                                                ftol=1e-4, timers=timers, dist=d,
                                                order=a.ba_order or "wavefront",
-                                               streams=a.ba_streams)["windows"]
+                                               streams=a.ba_streams, batched=bool(a.ba_batched))["windows"]
             return o
         return pipe.run(frames, K, ext, ba=not a.no_ba, ftol=1e-4, verbose=a.verbose, dist=d, timers=timers)
 
@@ -392,6 +395,7 @@ def main():
             "sliding_window_ba": None if "windows" not in out else {
                 "window": a.ba_window, "stride": a.ba_stride or max(1, a.ba_window // 2), "windows": len(out["windows"]),
                 "order": a.ba_order or "wavefront", "streams": a.ba_streams,
+                "batched": bool(a.ba_batched) and (a.ba_order or "wavefront") == "wavefront",
                 "ms": stage_ms["ba_windows"], "nfev_total": int(sum(w["nfev"] for w in out["windows"])),
                 "observations_total": int(sum(w["observations"] for w in out["windows"])),
                 "residual_evals_per_s": sum(w["observations"] * w["nfev"] for w in out["windows"]) /

@@ -62,6 +62,9 @@ int mm_ctx_sync(mm_ctx *ctx); /* (sync) hipStreamSynchronize on the context stre
  *     doubling), 0 serial (asked for with MM_LINK_VARIANT=serial, or the safety valve: the parallel formulation's
  *     fixed-point pass over key points with coincident coordinates exceeded its work budget), -1 none yet. */
 #define MM_CTL_LINK_LAST_VARIANT 6
+/*   MM_CTL_BATCH_LAST: problems the last mm_ba_trf_batched on this context advanced in lock-step (0: all were solved one by
+ *     one), -1 none yet. */
+#define MM_CTL_BATCH_LAST 7
 long long mm_ctx_control(mm_ctx *ctx, int what, long long value);
 /* HIP-event timing on the context stream (bench.py's roofline leg). */
 int mm_timer_create(mm_ctx *ctx, void **timer_out);
@@ -364,6 +367,22 @@ typedef struct mm_dist {
 size_t mm_ba_trf_dist_workspace_bytes(const mm_ba_problem *pb, int half_bandwidth);
 int mm_ba_trf_dist(mm_ctx *ctx, const mm_ba_problem *pb, double *cams, double *pts, const mm_trf_params *prm,
                    mm_trf_report *report, mm_trf_row *log, int log_cap, void *ws, size_t ws_bytes, const mm_dist *dist);
+/* SEVERAL INDEPENDENT PROBLEMS IN LOCK-STEP (the sliding-window adjustment; hook at reference
+ * processor.py:395-408: the windows of one colour of the wavefront schedule share no camera).  Every kernel of mm_ba_trf's loop
+ * is launched once per round for all problems (blockIdx.y = problem; per-problem grids and bodies identical to the
+ * single-problem kernels), the host reads one 16-double mailbox per problem and round and takes each problem's accept /
+ * reject / terminate decision exactly as mm_ba_trf does: cams[p] / pts[p] / reports[p] come out BIT-IDENTICAL to n_prob calls
+ * of mm_ba_trf.  A reduced system that is not positive definite is retried with 100x the damping inside the batch, as
+ * mm_ba_trf does; a problem whose factorisation was abandoned (info = -1) or that stays indefinite after six raises is
+ * solved by mm_ba_trf itself after the batch, from its initial point (solved_alone[p] = 1; may be NULL);
+ * if a problem cannot be batched at all (no co-observation pair list, reduced system outside the single-launch
+ * factorisation, n_prob == 1) the call solves them one after the other.
+ * pbs / cams / pts / ws / ws_bytes: HOST arrays of n_prob entries; ws[p] >= mm_ba_trf_batched_workspace_bytes(pbs[p]),
+ * 256-byte aligned.  Problems must not share buffers.  (sync) */
+size_t mm_ba_trf_batched_workspace_bytes(const mm_ba_problem *pb);
+int mm_ba_trf_batched(mm_ctx *ctx, int n_prob, const mm_ba_problem *const *pbs, double *const *cams /*dev, in/out*/,
+                      double *const *pts /*dev, in/out*/, const mm_trf_params *prm, mm_trf_report *reports /*host [n_prob]*/,
+                      void *const *ws /*dev*/, const size_t *ws_bytes, int32_t *solved_alone /*host [n_prob] | NULL*/);
 /* SPD solve A x = b by blocked Cholesky (f64 MFMA trailing updates).  A [n,n] row-major, lower triangle is
  * overwritten by L; b [nrhs,n] is overwritten by x.  half_bandwidth: A[i][j] == 0 whenever i - j > half_bandwidth
  * (pass n for a dense matrix); the factorisation and the substitutions skip blocks outside the band.

@@ -132,6 +132,9 @@ SIGNATURES = {
     "mm_ba_trf_workspace_bytes": (C.c_size_t, [C.POINTER(BAProblem)]),
     "mm_ba_trf": (C.c_int, [vp, C.POINTER(BAProblem), vp, vp, C.POINTER(TrfParams), C.POINTER(TrfReport),
                             C.POINTER(TrfRow), C.c_int, vp, C.c_size_t]),
+    "mm_ba_trf_batched_workspace_bytes": (C.c_size_t, [C.POINTER(BAProblem)]),
+    "mm_ba_trf_batched": (C.c_int, [vp, C.c_int, C.POINTER(C.POINTER(BAProblem)), C.POINTER(vp), C.POINTER(vp),
+                                    C.POINTER(TrfParams), C.POINTER(TrfReport), C.POINTER(vp), C.POINTER(C.c_size_t), c_i32p]),
     "mm_ba_trf_dist_workspace_bytes": (C.c_size_t, [C.POINTER(BAProblem), C.c_int]),
     "mm_ba_trf_dist": (C.c_int, [vp, C.POINTER(BAProblem), vp, vp, C.POINTER(TrfParams), C.POINTER(TrfReport),
                                  C.POINTER(TrfRow), C.c_int, vp, C.c_size_t, C.POINTER(Dist)]),
@@ -191,11 +194,12 @@ class Context:
 
     CTL_CHOL_FORCE_ABANDON, CTL_CHOL_LAST_PATH, CTL_CHOL_RESERVED, CTL_CU_COUNT, CTL_CHOL_AVOID_FUSED = 1, 2, 3, 4, 5
     CTL_LINK_LAST_VARIANT = 6
+    CTL_BATCH_LAST = 7
 
     def control(self, what, value=0):
         """mm_ctx_control: knobs / queries of the context (see include/meatmodeler.h)."""
         r = int(lib.mm_ctx_control(self.h, int(what), int(value)))
-        if r < -1 or (r == -1 and what not in (self.CTL_CHOL_LAST_PATH, self.CTL_LINK_LAST_VARIANT)):
+        if r < -1 or (r == -1 and what not in (self.CTL_CHOL_LAST_PATH, self.CTL_LINK_LAST_VARIANT, self.CTL_BATCH_LAST)):
             self.check(r, "mm_ctx_control")
         return r
 

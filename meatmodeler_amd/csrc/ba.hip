@@ -27,15 +27,15 @@
 namespace {
 
 // ---- residual + cost ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ba_residual_kernel(mm_ba_problem pb, const double *__restrict__ cams,
+__device__ __forceinline__ void ba_residual_body(mm_ba_problem pb, const double *__restrict__ cams,
                                                           const double *__restrict__ pts, const CamCoef *__restrict__ ctab, double *__restrict__ res,
-                                                          double *__restrict__ partial) {
+                                                          double *__restrict__ partial, const unsigned bx, const unsigned gx) {
     __shared__ double sm[4];
     __shared__ double Ks[9];
     if (threadIdx.x < 9) Ks[threadIdx.x] = pb.K[threadIdx.x];
     __syncthreads();
     double acc = 0;
-    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < pb.O; o += (int64_t)gridDim.x * 256) {
+    for (int64_t o = (int64_t)bx * 256 + threadIdx.x; o < pb.O; o += (int64_t)gx * 256) {
         Proj pr;
         const int f = pb.fi[o];
         ba_eval_cc<false, false>(cams + (size_t)f * 6, ctab[f],
@@ -47,8 +47,11 @@ __global__ __launch_bounds__(256) void ba_residual_kernel(mm_ba_problem pb, cons
         acc += pr.r0 * pr.r0 + pr.r1 * pr.r1;
     }
     double t = block_sum<256>(acc, sm);
-    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+    if (threadIdx.x == 0) partial[bx] = t;
 }
+__global__ __launch_bounds__(256) void ba_residual_kernel(mm_ba_problem pb, const double *__restrict__ cams,
+                                                          const double *__restrict__ pts, const CamCoef *__restrict__ ctab, double *__restrict__ res,
+                                                          double *__restrict__ partial) { ba_residual_body(pb, cams, pts, ctab, res, partial, blockIdx.x, gridDim.x); }
 
 __global__ __launch_bounds__(256) void sum_partials_kernel(const double *__restrict__ partial, int n,
                                                            double *__restrict__ out) {
@@ -66,9 +69,9 @@ struct MMHostBoard {
     double v[16];
     unsigned long long seq;
 };
-__global__ __launch_bounds__(256) void sum_partials_publish_kernel(const double *__restrict__ partial, int n,
+__device__ __forceinline__ void sum_partials_publish_body(const double *__restrict__ partial, int n,
                                                                    double *__restrict__ board, int cost_slot, int count,
-                                                                   MMHostBoard *hb, unsigned long long seq) {
+                                                                   MMHostBoard *hb, unsigned long long seq, const unsigned bx, const unsigned gx) {
     __shared__ double sm[4];
     double acc = 0;
     for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
@@ -82,6 +85,9 @@ __global__ __launch_bounds__(256) void sum_partials_publish_kernel(const double 
         if (threadIdx.x == 0) __hip_atomic_store(&hb->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
+__global__ __launch_bounds__(256) void sum_partials_publish_kernel(const double *__restrict__ partial, int n,
+                                                                   double *__restrict__ board, int cost_slot, int count,
+                                                                   MMHostBoard *hb, unsigned long long seq) { sum_partials_publish_body(partial, n, board, cost_slot, count, hb, seq, blockIdx.x, gridDim.x); }
 
 // ---- analytic Jacobian blocks (parity surface) --------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ba_jacobian_kernel(mm_ba_problem pb, const double *__restrict__ cams,
@@ -113,14 +119,14 @@ __global__ __launch_bounds__(256) void ba_jacobian_kernel(mm_ba_problem pb, cons
 // (88 at C3): 68 us against 24 us for the Jacobian product over the same observations.  Four lanes stride over a point's
 // observations and add up in a fixed butterfly: deterministic, tracks of <= 4 observations in one trip.)
 constexpr int PB_LANES = 4;
-__global__ __launch_bounds__(256) void ba_point_blocks_kernel(mm_ba_problem pb, const double *__restrict__ cams,
+__device__ __forceinline__ void ba_point_blocks_body(mm_ba_problem pb, const double *__restrict__ cams,
                                                               const double *__restrict__ pts, const CamCoef *__restrict__ ctab, double *__restrict__ C,
-                                                              double *__restrict__ gp) {
+                                                              double *__restrict__ gp, const unsigned bx, const unsigned gx) {
     __shared__ double Ks[9];
     if (threadIdx.x < 9) Ks[threadIdx.x] = pb.K[threadIdx.x];
     __syncthreads();
     const int sub = threadIdx.x & (PB_LANES - 1);
-    const int p = blockIdx.x * (256 / PB_LANES) + (threadIdx.x / PB_LANES);
+    const int p = bx * (256 / PB_LANES) + (threadIdx.x / PB_LANES);
     const bool live = p < pb.P;      // (no early return: the shuffles below are executed by whole waves)
     double c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // c00 c01 c02 c11 c12 c22 g0 g1 g2
     if (live) {
@@ -156,15 +162,18 @@ __global__ __launch_bounds__(256) void ba_point_blocks_kernel(mm_ba_problem pb, 
         gp[(size_t)p * 3] = c[6]; gp[(size_t)p * 3 + 1] = c[7]; gp[(size_t)p * 3 + 2] = c[8];
     }
 }
+__global__ __launch_bounds__(256) void ba_point_blocks_kernel(mm_ba_problem pb, const double *__restrict__ cams,
+                                                              const double *__restrict__ pts, const CamCoef *__restrict__ ctab, double *__restrict__ C,
+                                                              double *__restrict__ gp) { ba_point_blocks_body(pb, cams, pts, ctab, C, gp, blockIdx.x, gridDim.x); }
 
 // ---- camera blocks: B[F,6,6] and gc[F,6]; one workgroup per camera over its (gathered) observations -----------------
-__global__ __launch_bounds__(256) void ba_camera_blocks_kernel(mm_ba_problem pb, const double *__restrict__ cams,
+__device__ __forceinline__ void ba_camera_blocks_body(mm_ba_problem pb, const double *__restrict__ cams,
                                                                const double *__restrict__ pts, double *__restrict__ B,
-                                                               double *__restrict__ gc) {
+                                                               double *__restrict__ gc, const unsigned bx, const unsigned gx) {
     __shared__ double smn[4 * 27];
     __shared__ double Ks[9];
     __shared__ double cs[6];
-    const int f = blockIdx.x;
+    const int f = bx;
     if (threadIdx.x < 9) Ks[threadIdx.x] = pb.K[threadIdx.x];
     if (threadIdx.x < 6) cs[threadIdx.x] = cams[(size_t)f * 6 + threadIdx.x];
     __syncthreads();
@@ -203,6 +212,9 @@ __global__ __launch_bounds__(256) void ba_camera_blocks_kernel(mm_ba_problem pb,
         }
     }
 }
+__global__ __launch_bounds__(256) void ba_camera_blocks_kernel(mm_ba_problem pb, const double *__restrict__ cams,
+                                                               const double *__restrict__ pts, double *__restrict__ B,
+                                                               double *__restrict__ gc) { ba_camera_blocks_body(pb, cams, pts, B, gc, blockIdx.x, gridDim.x); }
 
 // ---- out = Jc wc[fi] + Jp wp[pi] ----------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ba_jvp_kernel(mm_ba_problem pb, const double *__restrict__ cams,
@@ -243,17 +255,17 @@ __global__ __launch_bounds__(256) void ba_jvp_kernel(mm_ba_problem pb, const dou
 // needs exactly these sums right after each of its two Jacobian products (|J d g_h|^2; <J s2, J d g_h>, |J s2|^2):
 // two vector passes less per iteration.  Deterministic: fixed tree per workgroup, then one small launch adds the
 // per-workgroup partials in index order.
-__global__ __launch_bounds__(256) void ba_jvp_dots_kernel(mm_ba_problem pb, const double *__restrict__ cams,
+__device__ __forceinline__ void ba_jvp_dots_body(mm_ba_problem pb, const double *__restrict__ cams,
                                                           const double *__restrict__ pts, const CamCoef *__restrict__ ctab, const double *__restrict__ wc,
                                                           const double *__restrict__ wp, double *__restrict__ out,
-                                                          const double *__restrict__ other, double *__restrict__ partial) {
+                                                          const double *__restrict__ other, double *__restrict__ partial, const unsigned bx, const unsigned gx) {
     __shared__ double Ks[9];
     __shared__ double sm[(256 / 64) * 2];
     if (threadIdx.x < 9) Ks[threadIdx.x] = pb.K[threadIdx.x];
     __syncthreads();
     // (grid-stride: at most JVP_MAX_WG workgroups, so the follow-up launch adds a few hundred partials, not thousands)
     double acc[2] = {0.0, 0.0};
-    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < pb.O; o += (int64_t)gridDim.x * 256) {
+    for (int64_t o = (int64_t)bx * 256 + threadIdx.x; o < pb.O; o += (int64_t)gx * 256) {
         const int f = pb.fi[o], p = pb.pi[o];
         Proj pr;
         ba_eval_cc<true, true>(cams + (size_t)f * 6, ctab[f],
@@ -283,14 +295,18 @@ __global__ __launch_bounds__(256) void ba_jvp_dots_kernel(mm_ba_problem pb, cons
     }
     block_sum_n<2, 256>(acc, sm);
     if (threadIdx.x == 0) {
-        partial[2 * (size_t)blockIdx.x] = acc[0];
-        partial[2 * (size_t)blockIdx.x + 1] = acc[1];
+        partial[2 * (size_t)bx] = acc[0];
+        partial[2 * (size_t)bx + 1] = acc[1];
     }
 }
+__global__ __launch_bounds__(256) void ba_jvp_dots_kernel(mm_ba_problem pb, const double *__restrict__ cams,
+                                                          const double *__restrict__ pts, const CamCoef *__restrict__ ctab, const double *__restrict__ wc,
+                                                          const double *__restrict__ wp, double *__restrict__ out,
+                                                          const double *__restrict__ other, double *__restrict__ partial) { ba_jvp_dots_body(pb, cams, pts, ctab, wc, wp, out, other, partial, blockIdx.x, gridDim.x); }
 
 // adds the per-workgroup partials of ba_jvp_dots_kernel in index order (one workgroup; a shared arrival counter costs
 // ~11 ns per workgroup on 6 k workgroups -- more than this launch)
-__global__ __launch_bounds__(256) void jvp_rows_kernel(const double *__restrict__ partial, unsigned n_wg, double *__restrict__ rows) {
+__device__ __forceinline__ void jvp_rows_body(const double *__restrict__ partial, unsigned n_wg, double *__restrict__ rows, const unsigned bx, const unsigned gx) {
     __shared__ double sm[(256 / 64) * 2];
     double acc[2] = {0.0, 0.0};
     for (unsigned g = threadIdx.x; g < n_wg; g += 256) {
@@ -307,6 +323,7 @@ __global__ __launch_bounds__(256) void jvp_rows_kernel(const double *__restrict_
         rows[5] = acc[1];
     }
 }
+__global__ __launch_bounds__(256) void jvp_rows_kernel(const double *__restrict__ partial, unsigned n_wg, double *__restrict__ rows) { jvp_rows_body(partial, n_wg, rows, blockIdx.x, gridDim.x); }
 
 // ---- back-substitution: dp = Cinv (gp - sum_o Jp_o^T (Jc_o dc[f_o])) ------------------------------------------------
 __global__ __launch_bounds__(256) void ba_backsub_kernel(mm_ba_problem pb, const double *__restrict__ cams,
@@ -348,13 +365,13 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(mm_ba_problem pb, const
 // (85 us at C3 against 25 us for the Jacobian product over the same observations).  Pass 1 writes every observation's
 // 3-vector Jp^T (Jc dc) into a scratch array in CSR-by-point order, pass 2 adds each point's rows in that order (a fixed
 // order: deterministic) and applies Cinv.
-__global__ __launch_bounds__(256) void ba_backsub_obs_kernel(mm_ba_problem pb, const double *__restrict__ cams,
+__device__ __forceinline__ void ba_backsub_obs_body(mm_ba_problem pb, const double *__restrict__ cams,
                                                              const double *__restrict__ pts, const CamCoef *__restrict__ ctab,
-                                                             const double *__restrict__ dc, double *__restrict__ T) {
+                                                             const double *__restrict__ dc, double *__restrict__ T, const unsigned bx, const unsigned gx) {
     __shared__ double Ks[9];
     if (threadIdx.x < 9) Ks[threadIdx.x] = pb.K[threadIdx.x];
     __syncthreads();
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t e = (int64_t)bx * 256 + threadIdx.x;
     if (e >= pb.O) return;
     const int o = pb.pt_obs[e];
     const int f = pb.fi[o], p = pb.pi[o];
@@ -372,11 +389,14 @@ __global__ __launch_bounds__(256) void ba_backsub_obs_kernel(mm_ba_problem pb, c
     T[3 * e + 1] = pr.Jp[0][1] * s0 + pr.Jp[1][1] * s1;
     T[3 * e + 2] = pr.Jp[0][2] * s0 + pr.Jp[1][2] * s1;
 }
+__global__ __launch_bounds__(256) void ba_backsub_obs_kernel(mm_ba_problem pb, const double *__restrict__ cams,
+                                                             const double *__restrict__ pts, const CamCoef *__restrict__ ctab,
+                                                             const double *__restrict__ dc, double *__restrict__ T) { ba_backsub_obs_body(pb, cams, pts, ctab, dc, T, blockIdx.x, gridDim.x); }
 
-__global__ __launch_bounds__(256) void ba_backsub_points_kernel(mm_ba_problem pb, const double *__restrict__ T,
+__device__ __forceinline__ void ba_backsub_points_body(mm_ba_problem pb, const double *__restrict__ T,
                                                                 const double *__restrict__ Cinv, const double *__restrict__ gp,
-                                                                double *__restrict__ dp) {
-    const int p = blockIdx.x * 256 + threadIdx.x;
+                                                                double *__restrict__ dp, const unsigned bx, const unsigned gx) {
+    const int p = bx * 256 + threadIdx.x;
     if (p >= pb.P) return;
     double t0 = gp[(size_t)p * 3], t1 = gp[(size_t)p * 3 + 1], t2 = gp[(size_t)p * 3 + 2];
     for (int e = pb.pt_ptr[p]; e < pb.pt_ptr[p + 1]; ++e) {
@@ -389,14 +409,18 @@ __global__ __launch_bounds__(256) void ba_backsub_points_kernel(mm_ba_problem pb
     dp[(size_t)p * 3 + 1] = c[1] * t0 + c[3] * t1 + c[4] * t2;
     dp[(size_t)p * 3 + 2] = c[2] * t0 + c[4] * t1 + c[5] * t2;
 }
+__global__ __launch_bounds__(256) void ba_backsub_points_kernel(mm_ba_problem pb, const double *__restrict__ T,
+                                                                const double *__restrict__ Cinv, const double *__restrict__ gp,
+                                                                double *__restrict__ dp) { ba_backsub_points_body(pb, T, Cinv, gp, dp, blockIdx.x, gridDim.x); }
 
 // ---- rotation coefficients of every camera, once per parameter vector ------------------------------------------------
 // (Every workgroup of every sweep used to fill its own LDS copy: two sincos per thread -- more arithmetic than the
 // observations it then processed -- and 40 KB of LDS.  Now: one small launch per NEW camera vector, gathers from L2.)
-__global__ __launch_bounds__(256) void cam_coef_kernel(const double *__restrict__ cams, int F, CamCoef *__restrict__ tab) {
-    const int f = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void cam_coef_body(const double *__restrict__ cams, int F, CamCoef *__restrict__ tab, const unsigned bx, const unsigned gx) {
+    const int f = bx * 256 + threadIdx.x;
     if (f < F) tab[f] = cam_coef_of(cams + (size_t)f * 6);
 }
+__global__ __launch_bounds__(256) void cam_coef_kernel(const double *__restrict__ cams, int F, CamCoef *__restrict__ tab) { cam_coef_body(cams, F, tab, blockIdx.x, gridDim.x); }
 
 int check_pb(mm_ctx *ctx, const mm_ba_problem *pb, const char *who) {
     if (!ctx) return MM_ERR_ARG;
@@ -412,9 +436,9 @@ constexpr int JVP_MAX_WG = 2048;      // workgroups of the Jacobian product with
 // three scalars before the reduced system can be built (SciPy trf.py:473-477 via least_squares(method='trf',
 // tr_solver='lsmr'), reference bundleAdjuster.py:180-192): with a = 0.5 |J_h g_h|^2, b = -|g_h|^2 minimise
 // t (a t + b) over [0, Delta / |g_h|]; reg = -min / Delta^2.  out = {reg, max(reg, min_damping)}.
-__global__ void trf_damping_kernel(const double *__restrict__ gh2, const double *__restrict__ d11, double Delta,
-                                   double min_damping, double *__restrict__ out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ __forceinline__ void trf_damping_body(const double *__restrict__ gh2, const double *__restrict__ d11, double Delta,
+                                                 double min_damping, double *__restrict__ out) {
+    if (threadIdx.x != 0) return;
     const double a = 0.5 * d11[0], b = -gh2[0];
     const double to_tr = Delta / sqrt(gh2[0]);
     double best = fmin(0.0, to_tr * (a * to_tr + b));
@@ -425,6 +449,82 @@ __global__ void trf_damping_kernel(const double *__restrict__ gh2, const double 
     const double reg = -best / (Delta * Delta);
     out[0] = reg;
     out[1] = fmax(reg, min_damping);
+}
+__global__ void trf_damping_kernel(const double *__restrict__ gh2, const double *__restrict__ d11, double Delta,
+                                   double min_damping, double *__restrict__ out) {
+    if (blockIdx.x != 0) return;
+    trf_damping_body(gh2, d11, Delta, min_damping, out);
+}
+
+// ---- batched wrappers (mm_ba_trf_batched): blockIdx.y picks the problem, bodies as above with the problem's own grid ------
+#define MM_BATCH_PROB(gfield)                                   \
+    const int pid = list[blockIdx.y];                           \
+    const mm_batch_prob &bp = tab[pid];                         \
+    if (blockIdx.x >= bp.gfield) return
+__global__ __launch_bounds__(256) void cam_coef_batch_kernel(const mm_batch_prob *__restrict__ tab, const int32_t *__restrict__ list, int which) {
+    MM_BATCH_PROB(g_coef);
+    cam_coef_body(which ? bp.x_new : bp.x, bp.pb.F, (CamCoef *)(which ? bp.ctab_new : bp.ctab_x), blockIdx.x, bp.g_coef);
+}
+__global__ __launch_bounds__(256) void ba_residual_batch_kernel(const mm_batch_prob *__restrict__ tab, const int32_t *__restrict__ list) {
+    MM_BATCH_PROB(g_res);
+    ba_residual_body(bp.pb, bp.x_new, bp.x_new + bp.nc, (const CamCoef *)bp.ctab_new, nullptr, bp.res_partial, blockIdx.x, bp.g_res);
+}
+__global__ __launch_bounds__(256) void sum_partials_publish_batch_kernel(const mm_batch_prob *__restrict__ tab, const int32_t *__restrict__ list,
+                                                                         const mm_batch_dyn *__restrict__ dyn) {
+    const int pid = list[blockIdx.x];
+    const mm_batch_prob &bp = tab[pid];
+    sum_partials_publish_body(bp.res_partial, (int)bp.g_res, bp.board, 14, 16, (MMHostBoard *)bp.mailbox, dyn[pid].seq, 0, 1);
+}
+// rows (<= 16 doubles at `src_off` doubles behind r0 ... here: r0 itself) of the listed problems into their mailboxes
+__global__ __launch_bounds__(64) void publish_r0_batch_kernel(const mm_batch_prob *__restrict__ tab, const int32_t *__restrict__ list,
+                                                              const mm_batch_dyn *__restrict__ dyn) {
+    const int pid = list[blockIdx.x];
+    const mm_batch_prob &bp = tab[pid];
+    MMHostBoard *hb = (MMHostBoard *)bp.mailbox;
+    if (threadIdx.x < 6) hb->v[threadIdx.x] = bp.r0[threadIdx.x];
+    __threadfence_system();
+    __builtin_amdgcn_wave_barrier();
+    if (threadIdx.x == 0) __hip_atomic_store(&hb->seq, dyn[pid].seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ __launch_bounds__(256) void ba_jvp_dots_batch_kernel(const mm_batch_prob *__restrict__ tab, const int32_t *__restrict__ list, int second) {
+    MM_BATCH_PROB(g_jvp);
+    // first product of an iteration: u1 = J (d g_h); second: Jq2 = J s2 with <Jq2, u1>
+    const double *w = second ? bp.s2 : bp.ghs;
+    ba_jvp_dots_body(bp.pb, bp.x, bp.x + bp.nc, (const CamCoef *)bp.ctab_x, w, w + bp.nc, second ? bp.Jq2 : bp.u1,
+                     second ? bp.u1 : nullptr, bp.jvp_partial, blockIdx.x, bp.g_jvp);
+}
+__global__ __launch_bounds__(256) void jvp_rows_batch_kernel(const mm_batch_prob *__restrict__ tab, const int32_t *__restrict__ list, int second) {
+    const mm_batch_prob &bp = tab[list[blockIdx.x]];
+    jvp_rows_body(bp.jvp_partial, bp.g_jvp, second ? bp.bs : bp.d11, 0, 1);
+}
+__global__ void trf_damping_batch_kernel(const mm_batch_prob *__restrict__ tab, const int32_t *__restrict__ list,
+                                         const mm_batch_dyn *__restrict__ dyn) {
+    const int pid = list[blockIdx.x];
+    const mm_batch_prob &bp = tab[pid];
+    trf_damping_body(bp.r0 + 2, bp.d11 + 2, dyn[pid].Delta, dyn[pid].min_damping, bp.damp);
+}
+// a retry of the reduced solve with raised damping: damp[1] <- the host's value (mm_ba_trf writes it with a copy)
+__global__ void set_reg_batch_kernel(const mm_batch_prob *__restrict__ tab, const int32_t *__restrict__ list,
+                                     const mm_batch_dyn *__restrict__ dyn) {
+    const int pid = list[blockIdx.x];
+    if (threadIdx.x == 0) tab[pid].damp[1] = dyn[pid].reg;
+}
+__global__ __launch_bounds__(256) void ba_backsub_obs_batch_kernel(const mm_batch_prob *__restrict__ tab, const int32_t *__restrict__ list) {
+    MM_BATCH_PROB(g_obs);
+    ba_backsub_obs_body(bp.pb, bp.x, bp.x + bp.nc, (const CamCoef *)bp.ctab_x, bp.v, bp.backsub_T, blockIdx.x, bp.g_obs);
+}
+__global__ __launch_bounds__(256) void ba_backsub_points_batch_kernel(const mm_batch_prob *__restrict__ tab, const int32_t *__restrict__ list) {
+    MM_BATCH_PROB(g_pts);
+    ba_backsub_points_body(bp.pb, bp.backsub_T, bp.Cinv, bp.g + bp.nc, bp.dp, blockIdx.x, bp.g_pts);
+}
+__global__ __launch_bounds__(256) void ba_point_blocks_batch_kernel(const mm_batch_prob *__restrict__ tab, const int32_t *__restrict__ list) {
+    MM_BATCH_PROB(g_pblk);
+    ba_point_blocks_body(bp.pb, bp.x, bp.x + bp.nc, (const CamCoef *)bp.ctab_x, bp.C, bp.g + bp.nc, blockIdx.x, bp.g_pblk);
+}
+__global__ __launch_bounds__(256) void ba_camera_blocks_batch_kernel(const mm_batch_prob *__restrict__ tab, const int32_t *__restrict__ list) {
+    const mm_batch_prob &bp = tab[list[blockIdx.y]];
+    if ((int)blockIdx.x >= bp.pb.F) return;
+    ba_camera_blocks_body(bp.pb, bp.x, bp.x + bp.nc, bp.B, bp.g, blockIdx.x, (unsigned)bp.pb.F);
 }
 
 }  // namespace
@@ -605,3 +705,60 @@ int mm_ba_residual_publish(mm_ctx *ctx, const mm_ba_problem *pb, const double *c
     return MM_OK;
 }
 
+
+// ---- batched launches of the sweeps (mm_ba_trf_batched, trf.hip) -------------------------------------------------------------
+void mm_batch_ba_setup(mm_batch_prob *bp) {
+    const mm_ba_problem &pb = bp->pb;
+    const int64_t nb = (pb.O + 255) / 256;
+    bp->g_res = (uint32_t)(nb < 1 ? 1 : (nb > RES_BLOCKS ? RES_BLOCKS : nb));
+    bp->g_jvp = (uint32_t)(nb < JVP_MAX_WG ? (nb < 1 ? 1 : nb) : JVP_MAX_WG);
+    bp->g_pblk = (uint32_t)((pb.P + 256 / PB_LANES - 1) / (256 / PB_LANES));
+    bp->g_obs = (uint32_t)(nb < 1 ? 1 : nb);
+    bp->g_pts = (uint32_t)((pb.P + 255) / 256);
+    bp->g_coef = (uint32_t)((pb.F + 255) / 256);
+}
+int mm_batch_cam_coef(mm_ctx *ctx, const mm_batch_prob *tab, const int32_t *list, int n_list, unsigned max_g, int which) {
+    if (n_list <= 0) return MM_OK;
+    MM_LAUNCH(ctx, "cam_coef_kernel", cam_coef_batch_kernel, dim3(max_g, (unsigned)n_list), dim3(256), 0, tab, list, which);
+    return MM_OK;
+}
+int mm_batch_jvp_dots(mm_ctx *ctx, const mm_batch_prob *tab, const int32_t *list, int n_list, unsigned max_g, int second) {
+    if (n_list <= 0) return MM_OK;
+    MM_LAUNCH(ctx, "ba_jvp_kernel", ba_jvp_dots_batch_kernel, dim3(max_g, (unsigned)n_list), dim3(256), 0, tab, list, second);
+    MM_LAUNCH(ctx, "jvp_rows_kernel", jvp_rows_batch_kernel, dim3((unsigned)n_list), dim3(256), 0, tab, list, second);
+    return MM_OK;
+}
+int mm_batch_damping(mm_ctx *ctx, const mm_batch_prob *tab, const int32_t *list, int n_list, const mm_batch_dyn *dyn) {
+    if (n_list <= 0) return MM_OK;
+    MM_LAUNCH(ctx, "trf_damping_kernel", trf_damping_batch_kernel, dim3((unsigned)n_list), dim3(64), 0, tab, list, dyn);
+    return MM_OK;
+}
+int mm_batch_set_reg(mm_ctx *ctx, const mm_batch_prob *tab, const int32_t *list, int n_list, const mm_batch_dyn *dyn) {
+    if (n_list <= 0) return MM_OK;
+    MM_LAUNCH(ctx, "set_reg_kernel", set_reg_batch_kernel, dim3((unsigned)n_list), dim3(64), 0, tab, list, dyn);
+    return MM_OK;
+}
+int mm_batch_backsub(mm_ctx *ctx, const mm_batch_prob *tab, const int32_t *list, int n_list, unsigned max_g_obs, unsigned max_g_pts) {
+    if (n_list <= 0) return MM_OK;
+    MM_LAUNCH(ctx, "ba_backsub_kernel", ba_backsub_obs_batch_kernel, dim3(max_g_obs, (unsigned)n_list), dim3(256), 0, tab, list);
+    MM_LAUNCH(ctx, "ba_backsub_points_kernel", ba_backsub_points_batch_kernel, dim3(max_g_pts, (unsigned)n_list), dim3(256), 0, tab, list);
+    return MM_OK;
+}
+int mm_batch_residual_publish(mm_ctx *ctx, const mm_batch_prob *tab, const int32_t *list, int n_list, unsigned max_g,
+                              const mm_batch_dyn *dyn) {
+    if (n_list <= 0) return MM_OK;
+    MM_LAUNCH(ctx, "ba_residual_kernel", ba_residual_batch_kernel, dim3(max_g, (unsigned)n_list), dim3(256), 0, tab, list);
+    MM_LAUNCH(ctx, "sum_partials_kernel", sum_partials_publish_batch_kernel, dim3((unsigned)n_list), dim3(256), 0, tab, list, dyn);
+    return MM_OK;
+}
+int mm_batch_normal_eq(mm_ctx *ctx, const mm_batch_prob *tab, const int32_t *list, int n_list, unsigned max_g_pblk, unsigned max_F) {
+    if (n_list <= 0) return MM_OK;
+    MM_LAUNCH(ctx, "ba_point_blocks_kernel", ba_point_blocks_batch_kernel, dim3(max_g_pblk, (unsigned)n_list), dim3(256), 0, tab, list);
+    MM_LAUNCH(ctx, "ba_camera_blocks_kernel", ba_camera_blocks_batch_kernel, dim3(max_F, (unsigned)n_list), dim3(256), 0, tab, list);
+    return MM_OK;
+}
+int mm_batch_publish_rows(mm_ctx *ctx, const mm_batch_prob *tab, const int32_t *list, int n_list, const mm_batch_dyn *dyn) {
+    if (n_list <= 0) return MM_OK;
+    MM_LAUNCH(ctx, "board_publish_kernel", publish_r0_batch_kernel, dim3((unsigned)n_list), dim3(64), 0, tab, list, dyn);
+    return MM_OK;
+}

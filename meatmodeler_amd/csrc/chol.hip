@@ -285,57 +285,96 @@ struct NoPub {
     __device__ void drain() const {}
     __device__ void raise_sub_flag() const {}
 };
+// Round 4: the factorisation is ONE wave's chain (wave 0: panel, its own rank-16k update of the next panel's live rows,
+// panel, ...), the other three waves trail it -- diagonal inverses, streaming the finished blocks out -- released panel by
+// panel through a counter in LDS instead of workgroup barriers.  The phase trace of round 3 showed every panel phase with
+// helpers taking 2.6-2.9 us against 1.9 us for the first one, which wave 0 runs alone: six barriers per block made the
+// chain wait for the helpers' global stores.  (The update of a 16-row tile is the same MFMA sequence whichever wave runs
+// it: results unchanged bit for bit.)
+template <int PB>
+__device__ __forceinline__ void panel16_update_own(double (*M)[NB + 1]) {      // wave 0 alone; no barrier
+    constexpr int c0 = PB * 16;
+    const int lane = lane_id();
+    const int lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int w = PB; w < 4; ++w) {
+        double4_t acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < c0 / 4; ++ks) {
+            const double av = M[16 * w + lr][4 * ks + lk];
+            const double bv = M[c0 + lr][4 * ks + lk];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) M[16 * w + (lane >> 4) + 4 * i][c0 + (lane & 15)] -= acc[i];
+    }
+    wave_lds_sync();
+}
+__device__ __forceinline__ void lds_counter_wait(volatile int *c, int target) {
+    while (*c < target) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void lds_counter_set(volatile int *c, int value) {      // by one wave, after its LDS writes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane_id() == 0) *c = value;
+}
 template <class Pub = NoPub>
 __device__ __forceinline__ void factor_block_lds(double (*M)[NB + 1], double (*X)[NB + 1], double *R, int k0, int &bad,
                                                  Pub pub = Pub(), int trace_row = -1) {
+    __shared__ int s_panels, s_xzero;      // panels finished by wave 0; helper waves that have cleared their share of X
     const int w = wave_id();
+    if (thread_id() == 0) {
+        s_panels = 0;
+        s_xzero = 0;
+    }
+    __syncthreads();
+    volatile int *panels = &s_panels, *xzero = &s_xzero;
     if (w == 0) {
         panel16_factor_dpp<0>(M, X, R);
-    } else {
-        for (int e = thread_id() - 64; e < NB * NB; e += 192) X[e / NB][e % NB] = 0.0;
-    }
-    __syncthreads();
-    MM_TRACE_ROW(trace_row, 10);
-    panel16_update<1>(M);
-    MM_TRACE_ROW(trace_row, 11);
-    if (w == 2) pub.l(0);   // (after the update: wave 2 is idle from here, and its stores stay off wave 0's path)
-    if (w == 3) {
-        pub.bulk(0);
-        pub.bulk(1);
-    }
-    if (w == 0) panel16_factor_dpp<1>(M, X, R);
-    if (w == 1) {
-        inv_diag16(M, X, R, 0);
-        pub.x(0);
-    }
-    __syncthreads();
-    MM_TRACE_ROW(trace_row, 12);
-    panel16_update<2>(M);
-    if (w == 2) pub.l(1);
-    if (w == 3) pub.bulk(2);
-    if (w == 0) panel16_factor_dpp<2>(M, X, R);
-    if (w == 1) {
-        inv_diag16(M, X, R, 1);
-        pub.x(1);
-    }
-    __syncthreads();
-    MM_TRACE_ROW(trace_row, 13);
-    panel16_update<3>(M);
-    MM_TRACE_ROW(trace_row, 14);
-    if (w == 3) {      // (only wave 3 has stored the copy: its own drain suffices)
-        pub.drain();
-        pub.raise_sub_flag();
-    }
-    if (w == 2) pub.l(2);
-    if (w == 0) {
+        wave_lds_sync();
+        lds_counter_set(panels, 1);
+        MM_TRACE_ROW(trace_row, 10);
+        panel16_update_own<1>(M);
+        MM_TRACE_ROW(trace_row, 11);
+        panel16_factor_dpp<1>(M, X, R);
+        wave_lds_sync();
+        lds_counter_set(panels, 2);
+        MM_TRACE_ROW(trace_row, 12);
+        panel16_update_own<2>(M);
+        panel16_factor_dpp<2>(M, X, R);
+        wave_lds_sync();
+        lds_counter_set(panels, 3);
+        MM_TRACE_ROW(trace_row, 13);
+        panel16_update_own<3>(M);
+        MM_TRACE_ROW(trace_row, 14);
         panel16_factor_dpp<3>(M, X, R);
         wave_lds_sync();
-        inv_diag16(M, X, R, 3);      // the one inverse on the chain: half a microsecond
+        lds_counter_wait(xzero, 3);      // (long true: X is cleared while the first panel is factored)
+        inv_diag16(M, X, R, 3);          // the one inverse on the chain: half a microsecond
         pub.x(3);
-    }
-    if (w == 1) {
-        inv_diag16(M, X, R, 2);
-        pub.x(2);
+    } else {
+        for (int e = thread_id() - 64; e < NB * NB; e += 192) X[e / NB][e % NB] = 0.0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane_id() == 0) atomicAdd(&s_xzero, 1);
+        if (w == 1) {
+            lds_counter_wait(xzero, 3);
+            for (int k = 0; k < 3; ++k) {
+                lds_counter_wait(panels, k + 1);
+                inv_diag16(M, X, R, k);
+                pub.x(k);
+            }
+        } else if (w == 2) {
+            for (int k = 0; k < 3; ++k) {
+                lds_counter_wait(panels, k + 1);
+                pub.l(k);
+            }
+        } else {
+            pub.bulk(0);      // (the copy of L_{r,r-1} it streams out was final before the factorisation started)
+            pub.bulk(1);
+            pub.bulk(2);
+            pub.drain();
+            pub.raise_sub_flag();
+        }
     }
     __syncthreads();
     if (w == 1) bad = block_first_bad(M, k0);
@@ -1151,11 +1190,11 @@ __device__ __forceinline__ size_t tw_side_flags(int nblk, int W) { return 2 * (s
 // two, so the forward solve costs no extra time.  (Two-ended: the rows of M receive contributions from both sides.)
 
 template <int MODE>
-__global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, TwGeom g, double *Linv,
+__device__ __forceinline__ void chol_band_fused_body(double *A, TwGeom g, double *Linv,
                                                               int32_t *__restrict__ flags, int32_t *__restrict__ info,
                                                               const double *b_fwd, double *y,
                                                               double *contrib, double *lpub, double *spub,
-                                                              const int32_t *slab_ready, int cams_per_slab, int n_cams) {
+                                                              const int32_t *slab_ready, int cams_per_slab, int n_cams, const unsigned bx) {
     // these waves form a latency chain; when the reduced system is being built by a concurrent launch they share their
     // SIMDs with its waves, so ask the instruction arbiter to prefer them
     __builtin_amdgcn_s_setprio(3);
@@ -1173,7 +1212,7 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, TwGeom 
     __shared__ int s_ok;
     const int bwb = g.bwb, W = bwb + 1, nblk = g.nblk, n = g.n;
     const int G = W + bwb * (bwb - 1) / 2;  // workgroups per side
-    const int side = (int)blockIdx.x / G, lid = (int)blockIdx.x % G;  // side 2: the pre-accumulators of M x M
+    const int side = (int)bx / G, lid = (int)bx % G;  // side 2: the pre-accumulators of M x M
     const bool tw = g.b > 0;
     const int nrows = side == 0 ? (tw ? g.a + g.m : nblk) : g.b + g.m;  // block rows this side touches
     const int ncols = side == 0 ? nrows : g.b;                         // block columns it eliminates
@@ -1539,6 +1578,28 @@ __global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, TwGeom 
         __syncthreads();  // M / X are overwritten by the next row's tiles
     }
 }
+template <int MODE>
+__global__ __launch_bounds__(256) void chol_band_fused_kernel(double *A, TwGeom g, double *Linv,
+                                                              int32_t *__restrict__ flags, int32_t *__restrict__ info,
+                                                              const double *b_fwd, double *y,
+                                                              double *contrib, double *lpub, double *spub,
+                                                              const int32_t *slab_ready, int cams_per_slab, int n_cams) {
+    chol_band_fused_body<MODE>(A, g, Linv, flags, info, b_fwd, y, contrib, lpub, spub, slab_ready, cams_per_slab, n_cams, blockIdx.x);
+}
+__device__ __forceinline__ TwGeom batch_geom(const mm_batch_prob &bp) {
+    return TwGeom{bp.chol_n, bp.chol_nblk, bp.chol_bwb, bp.chol_a, bp.chol_m, bp.chol_b, bp.chol_pad};
+}
+// batched (mm_ba_trf_batched): blockIdx.y picks the problem.  Workgroups are dispatched in order of their linear index, x
+// fastest: all workgroups of the problems listed earlier are resident (or done) before a later problem's, and a workgroup
+// only ever waits for workgroups of its own problem -- so the batch makes progress with more workgroups than compute
+// units, problem by problem.  (The spins stay bounded all the same: info = -1 sends the caller to the single-problem path.)
+__global__ __launch_bounds__(256) void chol_band_fused_batch_kernel(const mm_batch_prob *__restrict__ tab, const int32_t *__restrict__ list) {
+    const mm_batch_prob &bp = tab[list[blockIdx.y]];
+    if (blockIdx.x >= bp.g_chol) return;
+    chol_band_fused_body<2>(bp.S, batch_geom(bp), bp.chol_Linv, bp.chol_flags, bp.info, bp.v, bp.chol_ytmp, bp.chol_contrib, bp.chol_lpub,
+                            bp.chol_spub, nullptr, 1, 0, blockIdx.x);
+}
+
 
 #ifdef MM_CHOL_TRACE
 extern "C" int mm_debug_chol_trace(unsigned long long *host /*[128*32]*/) {
@@ -1596,9 +1657,9 @@ __device__ __forceinline__ double poll_value(const double *p, int32_t *abort_fla
     return 0.0;
 }
 
-__global__ __launch_bounds__(256) void chol_band_bwd_kernel(double *A, TwGeom g, const double *__restrict__ Linv,
+__device__ __forceinline__ void chol_band_bwd_body(double *A, TwGeom g, const double *__restrict__ Linv,
                                                             const double *__restrict__ y, double *x, double *contrib,
-                                                            int32_t *__restrict__ abort_flag, int32_t *__restrict__ info) {
+                                                            int32_t *__restrict__ abort_flag, int32_t *__restrict__ info, const unsigned bx) {
     extern __shared__ double smem[];
     double (*T0)[LDT] = reinterpret_cast<double (*)[LDT]>(smem);
     double (*T1)[LDT] = reinterpret_cast<double (*)[LDT]>(smem + NB * LDT);
@@ -1606,7 +1667,7 @@ __global__ __launch_bounds__(256) void chol_band_bwd_kernel(double *A, TwGeom g,
     double *vec = smem + 2 * NB * LDT + 4 * NB, *vec2 = vec + NB;
     const int bwb = g.bwb, W = bwb + 1, nblk = g.nblk, n = g.n;
     const int GB = bwb >= 2 ? bwb : 1;  // workgroups per side
-    const int side = (int)blockIdx.x / GB, lid = (int)blockIdx.x % GB;
+    const int side = (int)bx / GB, lid = (int)bx % GB;
     const bool tw = g.b > 0;
     const int nrows = side == 0 ? (tw ? g.a + g.m : nblk) : g.b + g.m;
     const int ncols = side == 0 ? nrows : g.b;
@@ -1728,16 +1789,27 @@ __global__ __launch_bounds__(256) void chol_band_bwd_kernel(double *A, TwGeom g,
     }
     if (dead) MM_FUSED_ABANDON;
 }
+__global__ __launch_bounds__(256) void chol_band_bwd_kernel(double *A, TwGeom g, const double *__restrict__ Linv,
+                                                            const double *__restrict__ y, double *x, double *contrib,
+                                                            int32_t *__restrict__ abort_flag, int32_t *__restrict__ info) {
+    chol_band_bwd_body(A, g, Linv, y, x, contrib, abort_flag, info, blockIdx.x);
+}
+__global__ __launch_bounds__(256) void chol_band_bwd_batch_kernel(const mm_batch_prob *__restrict__ tab, const int32_t *__restrict__ list) {
+    const mm_batch_prob &bp = tab[list[blockIdx.y]];
+    if (blockIdx.x >= bp.g_bwd) return;
+    chol_band_bwd_body(bp.S, batch_geom(bp), bp.chol_Linv, bp.chol_ytmp, bp.v, bp.chol_contrib_bwd, bp.chol_flags, bp.info, blockIdx.x);
+}
+
 
 // one launch instead of a handful of fills per solve: info = 0, flags = 0, sentinels into the backward kernel's
 // contribution buffer, the hand-over buffer of the streamed blocks and the diagonal 16 x 16 blocks of L^-1 (what the
 // consumers of the factorisation poll on)
-__global__ __launch_bounds__(256) void chol_init_kernel(int32_t *__restrict__ info, int32_t *__restrict__ flags, size_t nflags,
+__device__ __forceinline__ void chol_init_body(int32_t *__restrict__ info, int32_t *__restrict__ flags, size_t nflags,
                                                         unsigned long long *__restrict__ sentinel_buf, size_t nsent,
                                                         unsigned long long *__restrict__ lpub, size_t nlpub,
-                                                        unsigned long long *__restrict__ Linv, size_t nblk) {
+                                                        unsigned long long *__restrict__ Linv, size_t nblk, const unsigned bx, const unsigned gx) {
     // (lpub covers both hand-over buffers: the streamed pieces of the diagonal blocks and the sub-diagonal blocks)
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+    const size_t i = (size_t)bx * 256 + threadIdx.x, stride = (size_t)gx * 256;
     if (i == 0) info[0] = 0;
     for (size_t k = i; k < nflags; k += stride) flags[k] = 0;
     for (size_t k = i; k < nsent; k += stride) sentinel_buf[k] = BWD_SENTINEL;
@@ -1747,6 +1819,27 @@ __global__ __launch_bounds__(256) void chol_init_kernel(int32_t *__restrict__ in
         Linv[b * NB * NB + (16 * d + (e >> 4)) * NB + 16 * d + (e & 15)] = STAGE_SENTINEL;
     }
 }
+__global__ __launch_bounds__(256) void chol_init_kernel(int32_t *__restrict__ info, int32_t *__restrict__ flags, size_t nflags,
+                                                        unsigned long long *__restrict__ sentinel_buf, size_t nsent,
+                                                        unsigned long long *__restrict__ lpub, size_t nlpub,
+                                                        unsigned long long *__restrict__ Linv, size_t nblk) {
+    chol_init_body(info, flags, nflags, sentinel_buf, nsent, lpub, nlpub, Linv, nblk, blockIdx.x, gridDim.x);
+}
+constexpr unsigned CHOL_INIT_GRID = 128;
+__global__ __launch_bounds__(256) void chol_init_batch_kernel(const mm_batch_prob *__restrict__ tab, const int32_t *__restrict__ list) {
+    const mm_batch_prob &bp = tab[list[blockIdx.y]];
+    chol_init_body(bp.info, bp.chol_flags, (size_t)bp.chol_nflags, (unsigned long long *)bp.chol_contrib_bwd, (size_t)bp.chol_nsent,
+                   (unsigned long long *)bp.chol_lpub, (size_t)bp.chol_nlpub, (unsigned long long *)bp.chol_Linv, (size_t)bp.chol_nblk,
+                   blockIdx.x, CHOL_INIT_GRID);
+}
+// the right-hand side buffer becomes the output of the backward substitution: filled with the sentinel it polls on (the
+// forward substitution, inside the factorisation, has consumed it by then)
+__global__ __launch_bounds__(256) void chol_fill_x_batch_kernel(const mm_batch_prob *__restrict__ tab, const int32_t *__restrict__ list) {
+    const mm_batch_prob &bp = tab[list[blockIdx.y]];
+    unsigned long long *x = (unsigned long long *)bp.v;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < bp.chol_n; i += gridDim.x * 256) x[i] = BWD_SENTINEL;
+}
+
 
 // copy the band of the lower triangle into the upper triangle for the columns side 1 eliminates: (j, i) <- (i, j) for
 // i >= row0, 0 < i - j <= hb (callers of the two-ended path that only filled the lower triangle)
@@ -2077,5 +2170,64 @@ int mm_chol_solve_gated(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int 
         }
     }
     if (fused) chol_budget_mark(ctx);
+    return MM_OK;
+}
+
+// ---- batched factorisation + substitutions (mm_ba_trf_batched, trf.hip) --------------------------------------------------------
+// The geometry and workspace layout mm_chol_solve_sym(both triangles) would use for this problem alone; fails (the caller
+// then solves the batch one problem at a time) when that would not be the single-launch path.
+int mm_batch_chol_setup(mm_ctx *ctx, mm_batch_prob *bp, void *ws, size_t ws_bytes) {
+    const int n = (int)bp->nc, hb = bp->half_bw;
+    if (!ws || ws_bytes < mm_chol_workspace_bytes(n) || (n & 1)) return mm_fail(ctx, MM_ERR_WORKSPACE, "mm_ba_trf_batched: Cholesky workspace");
+    const int nblk = (n + NB - 1) / NB;
+    long bwb_l = ((long)hb + NB - 1) / NB;
+    const int bwb = bwb_l > nblk ? nblk : (int)bwb_l;
+    const bool fused = chol_fused_mode() > 0 && nblk >= 2 && bwb >= 1 && bwb <= FUSED_MAX_BWB && (long)NB * nblk * n < (1L << 31) &&
+                       !ctx->chol_avoid_fused;
+    if (!fused) return mm_fail(ctx, MM_ERR_ARG, "mm_ba_trf_batched: a reduced system outside the single-launch factorisation");
+    TwGeom g = {n, nblk, bwb, nblk, 0, 0, nblk * NB - n};
+    if (chol_twisted_enabled() && nblk - bwb >= 4) {
+        g.m = bwb;
+        g.a = (nblk - g.m + 1) / 2;
+        g.b = nblk - g.m - g.a;
+    }
+    const int G_side = (bwb + 1) + bwb * (bwb - 1) / 2;
+    const int sides = g.b > 0 ? 2 : 1;
+    bp->g_chol = (uint32_t)(g.b > 0 ? 2 * G_side + g.m * (g.m + 1) / 2 : G_side);
+    bp->g_bwd = (uint32_t)(sides * (bwb >= 2 ? bwb : 1));
+    bp->chol_n = g.n; bp->chol_nblk = g.nblk; bp->chol_bwb = g.bwb; bp->chol_a = g.a; bp->chol_m = g.m; bp->chol_b = g.b; bp->chol_pad = g.pad;
+    double *Linv = (double *)ws;
+    double *ytmp = (double *)((char *)ws + mm_align_up((size_t)nblk * NB * NB * sizeof(double), 256));
+    int32_t *flags = (int32_t *)((char *)ytmp + mm_align_up((size_t)(n + NB) * sizeof(double), 256));
+    double *contrib = (double *)((char *)flags + mm_align_up((2 * (2 * (size_t)nblk * (FUSED_MAX_BWB + 1) + 2 * nblk) + 64 + FUSED_MAX_BWB * FUSED_MAX_BWB) * sizeof(int32_t), 256));
+    double *contrib_bwd = (double *)((char *)contrib + mm_align_up(2 * (size_t)nblk * (FUSED_MAX_BWB + 1) * NB * sizeof(double), 256));
+    double *lpub = (double *)((char *)contrib_bwd + mm_align_up(2 * (size_t)nblk * (FUSED_MAX_BWB + 1) * NB * sizeof(double), 256));
+    bp->chol_Linv = Linv;
+    bp->chol_ytmp = ytmp;
+    bp->chol_flags = flags;
+    bp->chol_contrib = contrib;
+    bp->chol_contrib_bwd = contrib_bwd;
+    bp->chol_lpub = lpub;
+    bp->chol_spub = lpub + (size_t)nblk * LPUB_BLOCK;
+    bp->chol_nflags = 1 + 2 * (2 * (size_t)nblk * (bwb + 1) + 2 * nblk) + (size_t)g.m * g.m;
+    bp->chol_nsent = (size_t)sides * nblk * (bwb + 1) * NB;
+    bp->chol_nlpub = (size_t)nblk * (LPUB_BLOCK + 2 * NB * NB);
+    return MM_OK;
+}
+int mm_batch_chol(mm_ctx *ctx, const mm_batch_prob *tab, const int32_t *list, int n_list, unsigned max_g_chol, unsigned max_g_bwd) {
+    if (n_list <= 0) return MM_OK;
+    if (!ctx->attr_chol_batch) {
+        MM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(chol_band_fused_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)FUSED_LDS_BYTES));
+        MM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(chol_band_bwd_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)BWD_LDS_BYTES));
+        ctx->attr_chol_batch = true;
+    }
+    const unsigned nl = (unsigned)n_list;
+    MM_LAUNCH(ctx, "chol_init_kernel", chol_init_batch_kernel, dim3(CHOL_INIT_GRID, nl), dim3(256), 0, tab, list);
+    MM_LAUNCH(ctx, "chol_band_fused_kernel", chol_band_fused_batch_kernel, dim3(max_g_chol, nl), dim3(256), FUSED_LDS_BYTES, tab, list);
+    MM_LAUNCH(ctx, "chol_fill_x_kernel", chol_fill_x_batch_kernel, dim3(4, nl), dim3(256), 0, tab, list);
+    MM_LAUNCH(ctx, "chol_band_bwd_kernel", chol_band_bwd_batch_kernel, dim3(max_g_bwd, nl), dim3(256), BWD_LDS_BYTES, tab, list);
+    ctx->chol_last_path = 1;
     return MM_OK;
 }

@@ -24,7 +24,7 @@ struct mm_ctx {
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // one-time kernel attributes (dynamic LDS opt-in) are per device: remembered per context, not per process
-    bool attr_chol_fused = false, attr_chol_bwd = false;
+    bool attr_chol_fused = false, attr_chol_bwd = false, attr_chol_batch = false;
     // Single-launch banded factorisation (chol.hip): its workgroups wait for each other, so ALL of them have to be
     // resident -- one per CU (512 registers per lane).  cu_count = CUs of the device; fused_wgs = workgroups this context
     // has reserved out of the process-wide budget (mm_fused_budget) for its factorisation in flight, released at the
@@ -52,6 +52,10 @@ struct mm_ctx {
     // and the host spins on its sequence number instead of paying a copy + stream synchronisation per trial step
     void *host_board = nullptr;
     unsigned long long host_board_seq = 0;
+    // mm_ba_trf_batched: device tables (batch records, per-round lists) and pinned staging + mailboxes, grown on demand
+    void *batch_dev = nullptr, *batch_host = nullptr;
+    size_t batch_dev_cap = 0, batch_host_cap = 0;
+    int batch_last = -1;      // problems the last mm_ba_trf_batched advanced in lock-step (0: all one by one), -1 none yet
 };
 
 // launches of the enclosed scope go to another stream of the context
@@ -77,6 +81,72 @@ void mm_chol_release_budget(mm_ctx *ctx);
 bool mm_chol_fused_eligible(int n, int half_bandwidth);
 int mm_chol_solve_gated(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int half_bandwidth, int32_t *info, void *ws,
                         size_t ws_bytes, const int32_t *slab_ready, int cams_per_slab, int n_cams, int sym_mode);
+
+// ---- lock-step solves of several independent problems (mm_ba_trf_batched, trf.hip) ------------------------------------------
+// ONE record per problem in device memory: every buffer of its solve (the layout of mm_ba_trf's workspace) plus the launch
+// geometry each kernel would be given if the problem were solved alone.  A batched launch is grid (max workgroups over the
+// listed problems, number of listed problems): blockIdx.y picks the problem out of a list of indices, a workgroup beyond
+// the problem's own grid leaves at once, and the body is the single-problem kernel's body with (blockIdx.x, gridDim.x)
+// replaced by (blockIdx.x, the problem's own grid) -- same slices, same reduction trees, bit-identical results.
+struct mm_batch_prob {
+    mm_ba_problem pb;
+    int64_t n, nc;      // 6 F + 3 P, 6 F
+    double *x, *x_new, *g, *si, *gh, *ghs, *gn, *q1, *w, *q2, *s1, *s2;
+    double *B, *Bd, *C, *Cd, *Cinv, *u1, *Jq2, *dp, *v, *S;
+    double *r0, *r1, *r2, *r3, *d11, *bs, *damp, *board;
+    int32_t *info;
+    void *ctab_x, *ctab_new;      // rotation coefficients of the cameras in x / x_new (ba.hip's CamCoef rows)
+    // reductions
+    double *res_partial;          // residual: RES_BLOCKS partial sums
+    unsigned *md_counter;         // fused vector passes: arrival counter + per-workgroup partials
+    double *md_partial;
+    double *jvp_partial;
+    double *backsub_T;
+    // reduced camera system (schur.hip) and its factorisation (chol.hip)
+    double *schur_partial, *schur_camtab;
+    int32_t *schur_seg_done, *schur_desc;
+    double *chol_Linv, *chol_ytmp, *chol_contrib, *chol_contrib_bwd, *chol_lpub, *chol_spub;
+    int32_t *chol_flags;
+    int32_t chol_n, chol_nblk, chol_bwb, chol_a, chol_m, chol_b, chol_pad;      // (TwGeom of chol.hip)
+    uint64_t chol_nflags, chol_nsent, chol_nlpub;
+    int32_t half_bw, chol_sym_mirror;
+    // per-kernel grids (what the single-problem launch would use)
+    uint32_t g_vec, g_res, g_jvp, g_pblk, g_obs, g_pts, g_scale, g_damp, g_prep, g_pairs, g_chol, g_bwd, g_coef, g_zero;
+    // host mailbox of this problem (pinned, device visible): 16 doubles + sequence number
+    void *mailbox;
+};
+// what changes from round to round: one record per problem, copied to the device before each round
+struct mm_batch_dyn {
+    double Delta;
+    unsigned long long seq;
+    double min_damping;      // this problem's damping floor (raised x100 when the reduced system failed AT the floor)
+    double reg;              // a retry of the reduced solve with 100x the damping: the value that replaces damp[1]
+};
+
+// batched launches of the loop's kernels (each in the translation unit of its single-problem kernel)
+int mm_batch_fused(mm_ctx *ctx, int op, const mm_batch_prob *tab, const int32_t *list, int n_list, unsigned max_g);
+unsigned mm_batch_fused_grid(int64_t n);
+int mm_batch_scale_update(mm_ctx *ctx, const mm_batch_prob *tab, const int32_t *list, int n_list, unsigned max_g);
+int mm_batch_damp(mm_ctx *ctx, const mm_batch_prob *tab, const int32_t *list, int n_list, unsigned max_g);
+int mm_batch_accept(mm_ctx *ctx, const mm_batch_prob *tab, const int32_t *list, int n_list, unsigned max_g);
+int mm_batch_step2d(mm_ctx *ctx, const mm_batch_prob *tab, const int32_t *list, int n_list, const mm_batch_dyn *dyn);
+// ba.hip
+void mm_batch_ba_setup(mm_batch_prob *bp);      // grids of the sweeps from bp->pb
+int mm_batch_cam_coef(mm_ctx *ctx, const mm_batch_prob *tab, const int32_t *list, int n_list, unsigned max_g, int which /*0: x, 1: x_new*/);
+int mm_batch_jvp_dots(mm_ctx *ctx, const mm_batch_prob *tab, const int32_t *list, int n_list, unsigned max_g, int second);
+int mm_batch_damping(mm_ctx *ctx, const mm_batch_prob *tab, const int32_t *list, int n_list, const mm_batch_dyn *dyn);
+int mm_batch_set_reg(mm_ctx *ctx, const mm_batch_prob *tab, const int32_t *list, int n_list, const mm_batch_dyn *dyn);
+int mm_batch_backsub(mm_ctx *ctx, const mm_batch_prob *tab, const int32_t *list, int n_list, unsigned max_g_obs, unsigned max_g_pts);
+int mm_batch_residual_publish(mm_ctx *ctx, const mm_batch_prob *tab, const int32_t *list, int n_list, unsigned max_g,
+                              const mm_batch_dyn *dyn);
+int mm_batch_normal_eq(mm_ctx *ctx, const mm_batch_prob *tab, const int32_t *list, int n_list, unsigned max_g_pblk, unsigned max_F);
+int mm_batch_publish_rows(mm_ctx *ctx, const mm_batch_prob *tab, const int32_t *list, int n_list, const mm_batch_dyn *dyn);
+// schur.hip / chol.hip
+int mm_batch_schur_setup(mm_ctx *ctx, mm_batch_prob *bp, void *ws_schur, size_t ws_schur_bytes);
+int mm_batch_schur(mm_ctx *ctx, const mm_batch_prob *tab, const int32_t *list, int n_list, unsigned max_g_zero, unsigned max_g_prep,
+                   unsigned max_g_pairs);
+int mm_batch_chol_setup(mm_ctx *ctx, mm_batch_prob *bp, void *ws_chol, size_t ws_chol_bytes);
+int mm_batch_chol(mm_ctx *ctx, const mm_batch_prob *tab, const int32_t *list, int n_list, unsigned max_g_chol, unsigned max_g_bwd);
 
 static inline hipEvent_t mm_prof_event(mm_ctx *c) {
     hipEvent_t e = nullptr;

@@ -32,6 +32,8 @@ void mm_ctx_destroy(mm_ctx *ctx) {
     for (auto e : ctx->pool) (void)hipEventDestroy(e);
     if (ctx->cam_tab) (void)hipFree(ctx->cam_tab);
     if (ctx->host_board) (void)hipHostFree(ctx->host_board);
+    if (ctx->batch_dev) (void)hipFree(ctx->batch_dev);
+    if (ctx->batch_host) (void)hipHostFree(ctx->batch_host);
     if (ctx->fused_ev) (void)hipEventDestroy(ctx->fused_ev);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
@@ -107,6 +109,7 @@ long long mm_ctx_control(mm_ctx *ctx, int what, long long value) {
             return prev;
         }
         case MM_CTL_LINK_LAST_VARIANT: return ctx->link_last_variant;
+        case MM_CTL_BATCH_LAST: return ctx->batch_last;
         default: return mm_fail(ctx, MM_ERR_ARG, "mm_ctx_control: unknown request %d", what);
     }
 }

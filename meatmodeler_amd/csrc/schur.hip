@@ -446,16 +446,20 @@ constexpr int SLAB2 = 32;      // doubles per wave beside the reduction slab: Jr
 struct ChunkDesc {
     int32_t i, f2, e_begin, e_end, sidx, c_first, n_ch, pad;
 };
-__device__ __forceinline__ CamPQ cam_pq_scalar(const double *__restrict__ t) {   // t uniform -> s_load
+// t uniform.  FORCE = false: plain loads (kernel arguments: the compiler proves the table read-only and emits s_load);
+// FORCE = true: the pointers come out of a batch record in memory, nothing is provable, and the values would live in 48
+// vector registers -- v_readfirstlane makes them scalars
+template <bool FORCE>
+__device__ __forceinline__ CamPQ cam_pq_scalar(const double *__restrict__ t) {
     CamPQ v;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) v.P[k] = t[k];
+    for (int k = 0; k < 9; ++k) v.P[k] = FORCE ? uniform_f64(t[k]) : t[k];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) v.q[k] = t[9 + k];
+    for (int k = 0; k < 3; ++k) v.q[k] = FORCE ? uniform_f64(t[9 + k]) : t[9 + k];
     return v;
 }
-template <int OCC>      // waves per SIMD the register allocation aims at (2; 3 spills into scratch and is 1.8x slower: measured)
-__global__ __launch_bounds__(64 * SP_WAVES, OCC) void schur_pairs_kernel(mm_ba_problem pb, const double *__restrict__ camtab,
+template <bool FORCE_UNIFORM>
+__device__ __forceinline__ void schur_pairs_body(const mm_ba_problem pb, const double *__restrict__ camtab,
                                                                     const ChunkDesc *__restrict__ desc,
                                                                     const double *__restrict__ pts,
                                                                     const double *__restrict__ Cinv,
@@ -463,19 +467,28 @@ __global__ __launch_bounds__(64 * SP_WAVES, OCC) void schur_pairs_kernel(mm_ba_p
                                                                     double *partial, const double *__restrict__ Bd,
                                                                     const double *__restrict__ gc, double *S, double *v,
                                                                     int32_t *seg_done, SlabSync slabs, unsigned wg_begin,
-                                                                    unsigned wg_total) {
+                                                                    unsigned wg_total, const unsigned bx) {
     __shared__ double Ks[9];
     __shared__ double red[SP_WAVES][21 * RED_LD];
     __shared__ double jrs[SP_WAVES][SLAB2];
     if (threadIdx.x < 9) Ks[threadIdx.x] = pb.K[threadIdx.x];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const unsigned gpos = blockIdx.x + wg_begin;
+    const unsigned gpos = bx + wg_begin;
     const unsigned wg = (gpos & 1) ? wg_total - 1 - (gpos >> 1) : (gpos >> 1);
     const int64_t c = (int64_t)wg * SP_WAVES + wv;
     const bool live = c < pb.n_chunks;
     ChunkDesc cd = {};
     if (live) cd = desc[c];      // (uniform address: one scalar load)
+    if (FORCE_UNIFORM) {
+        cd.i = __builtin_amdgcn_readfirstlane(cd.i);
+        cd.f2 = __builtin_amdgcn_readfirstlane(cd.f2);
+        cd.e_begin = __builtin_amdgcn_readfirstlane(cd.e_begin);
+        cd.e_end = __builtin_amdgcn_readfirstlane(cd.e_end);
+        cd.sidx = __builtin_amdgcn_readfirstlane(cd.sidx);
+        cd.c_first = __builtin_amdgcn_readfirstlane(cd.c_first);
+        cd.n_ch = __builtin_amdgcn_readfirstlane(cd.n_ch);
+    }
     const int i = cd.i, f2 = cd.f2, d = cd.i - cd.f2, sidx = cd.sidx;
     const int e_begin = cd.e_begin, e_end = cd.e_end;
     // second hop, all at once: the two cameras' tables (scalar P, q; J_r through the wave's LDS slab) and the first trip's
@@ -495,17 +508,25 @@ __global__ __launch_bounds__(64 * SP_WAVES, OCC) void schur_pairs_kernel(mm_ba_p
     }
     __syncthreads();      // (Ks; the wave's own slab would only need a wave barrier)
     if (!live) return;    // wave-uniform; no workgroup barriers below
-    const CamPQ cp_i = cam_pq_scalar(camtab + (size_t)i * CAMTAB2), cp_2 = cam_pq_scalar(camtab + (size_t)f2 * CAMTAB2);
+    const CamPQ cp_i = cam_pq_scalar<FORCE_UNIFORM>(camtab + (size_t)i * CAMTAB2), cp_2 = cam_pq_scalar<FORCE_UNIFORM>(camtab + (size_t)f2 * CAMTAB2);
     const double *Jr_i = jrs[wv], *Jr_2 = jrs[wv] + 16;
     double acc[42];
 #pragma unroll
     for (int q = 0; q < 42; ++q) acc[q] = 0.0;
     // (the point of a pair is all the kernel gathers by: the observed coordinates are not needed)
-    auto pair_body = [&](int p, bool self) {
-        const double *Xp = pts + (size_t)p * 3;
-        const double X0 = Xp[0], X1 = Xp[1], X2 = Xp[2];
-        const double *ci = Cinv + (size_t)p * 6;
-        const double q00 = ci[0], q01 = ci[1], q02 = ci[2], q11 = ci[3], q12 = ci[4], q22 = ci[5];
+    auto load_xc = [&](int p, double (&x)[9]) {      // the point and its C^-1 (upper triangle)
+        if (p >= 0) {
+            const double *Xp = pts + (size_t)p * 3, *ci = Cinv + (size_t)p * 6;
+            x[0] = Xp[0];
+            x[1] = Xp[1];
+            x[2] = Xp[2];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) x[3 + q] = ci[q];
+        }
+    };
+    auto pair_body = [&](int p, bool self, const double (&x)[9]) {
+        const double X0 = x[0], X1 = x[1], X2 = x[2];
+        const double q00 = x[3], q01 = x[4], q02 = x[5], q11 = x[6], q12 = x[7], q22 = x[8];
         LeanJ a;
         lean_eval(cp_i, Ks, Jr_i, X0, X1, X2, a);
         // E_o C^-1 E_o2^T = Jc_o^T (Jp_o C^-1 Jp_o2^T) Jc_o2 through the 2 x 2 middle factor
@@ -554,15 +575,32 @@ __global__ __launch_bounds__(64 * SP_WAVES, OCC) void schur_pairs_kernel(mm_ba_p
 #pragma unroll
             for (int b = 0; b < 6; ++b) acc[q * 6 + b] += a.Jc[0][q] * T[0][b] + a.Jc[1][q] * T[1][b];
     };
-    // software pipeline over the trips of the chunk: the NEXT pair's point index is requested before the current pair is
-    // worked on (a chunk holds at most 256 pairs = four trips, longer ones for other callers)
-    for (; e - lane < e_end; e += 64) {      // (wave-uniform trip count)
-        const int p = p_next;
-        const bool self = self_next;
+    // software pipeline over the trips of the chunk, two deep: the point index of trip t + 2 and the point / C^-1 of trip
+    // t + 1 are requested before the arithmetic of trip t starts, so that a trip waits for neither of its two dependent
+    // gathers (the kernel is bound by exactly those latencies at two waves per SIMD)
+    double xc[9];
+    load_xc(p_next, xc);
+    int p_cur = p_next;
+    bool self_cur = self_next;
+    {
         const int en = e + 64;
         p_next = en < e_end ? point_of(en) : -1;
         self_next = en < e_end && self_of(en);
-        if (p >= 0) pair_body(p, self);
+    }
+#pragma clang loop unroll(disable)
+    for (; e - lane < e_end; e += 64) {      // (wave-uniform trip count)
+        double xn[9];
+        load_xc(p_next, xn);
+        const int p_nn_e = e + 128;
+        const int p_nn = p_nn_e < e_end ? point_of(p_nn_e) : -1;
+        const bool self_nn = p_nn_e < e_end && self_of(p_nn_e);
+        if (p_cur >= 0) pair_body(p_cur, self_cur, xc);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) xc[q] = xn[q];
+        p_cur = p_next;
+        self_cur = self_next;
+        p_next = p_nn;
+        self_next = self_nn;
     }
     double tot0, tot1;
     wave_reduce_42(acc, red[wv], lane, tot0, tot1);
@@ -590,6 +628,11 @@ __global__ __launch_bounds__(64 * SP_WAVES, OCC) void schur_pairs_kernel(mm_ba_p
         }
     }
     if (!writer) return;
+    // (Where the time of this kernel goes, by ablation on the tools/bench_schur.py shape, 225 us in all: the bare skeleton --
+    // one wave per chunk, descriptor -> tables / point index -> point / C^-1 -- 108 us; arithmetic +45; the 42-value
+    // reduction +34; these stores +38 as write-through agent-scope stores.  Nobody reads S before the launch ends unless a
+    // concurrent factorisation consumes it slab by slab: plain stores otherwise.)
+    const bool through = slabs.ready != nullptr;
     if (lane < 21) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -598,11 +641,20 @@ __global__ __launch_bounds__(64 * SP_WAVES, OCC) void schur_pairs_kernel(mm_ba_p
             if (q < 36) {
                 double val = -sum;
                 if (d == 0) val += Bd[(size_t)i * 36 + q];
-                __hip_atomic_store(S + ((size_t)i * 6 + q / 6) * n + (size_t)f2 * 6 + q % 6, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (d != 0)
-                    __hip_atomic_store(S + ((size_t)f2 * 6 + q % 6) * n + (size_t)i * 6 + q / 6, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                double *dst = S + ((size_t)i * 6 + q / 6) * n + (size_t)f2 * 6 + q % 6;
+                double *mir = S + ((size_t)f2 * 6 + q % 6) * n + (size_t)i * 6 + q / 6;
+                if (through) {
+                    __hip_atomic_store(dst, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (d != 0) __hip_atomic_store(mir, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    *dst = val;
+                    if (d != 0) *mir = val;
+                }
             } else if (d == 0) {
-                __hip_atomic_store(v + (size_t)i * 6 + (q - 36), gc[(size_t)i * 6 + (q - 36)] - sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                double *dst = v + (size_t)i * 6 + (q - 36);
+                const double val = gc[(size_t)i * 6 + (q - 36)] - sum;
+                if (through) __hip_atomic_store(dst, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else *dst = val;
             }
         }
     }
@@ -616,6 +668,34 @@ __global__ __launch_bounds__(64 * SP_WAVES, OCC) void schur_pairs_kernel(mm_ba_p
         }
     }
 }
+template <int OCC>      // waves per SIMD the register allocation aims at (2; 3 spills into scratch and is 1.8x slower: measured)
+__global__ __launch_bounds__(64 * SP_WAVES, OCC) void schur_pairs_kernel(mm_ba_problem pb, const double *__restrict__ camtab,
+                                                                    const ChunkDesc *__restrict__ desc,
+                                                                    const double *__restrict__ pts,
+                                                                    const double *__restrict__ Cinv,
+                                                                    const double *__restrict__ gp,
+                                                                    double *partial, const double *__restrict__ Bd,
+                                                                    const double *__restrict__ gc, double *S, double *v,
+                                                                    int32_t *seg_done, SlabSync slabs, unsigned wg_begin,
+                                                                    unsigned wg_total) {
+    schur_pairs_body<false>(pb, camtab, desc, pts, Cinv, gp, partial, Bd, gc, S, v, seg_done, slabs, wg_begin, wg_total, blockIdx.x);
+}
+// batched (mm_ba_trf_batched): blockIdx.y picks the problem
+__global__ __launch_bounds__(256) void zero_batch_kernel(const mm_batch_prob *__restrict__ tab, const int32_t *__restrict__ list) {
+    const mm_batch_prob &bp = tab[list[blockIdx.y]];
+    if (blockIdx.x >= bp.g_zero) return;
+    double2 *S2 = reinterpret_cast<double2 *>(bp.S);      // (nc is even: nc * nc doubles = nc * nc / 2 pairs)
+    const int64_t n2 = bp.nc * bp.nc / 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (int64_t)bp.g_zero * 256) S2[i] = make_double2(0.0, 0.0);
+}
+__global__ __launch_bounds__(64 * SP_WAVES, 2) void schur_pairs_batch_kernel(const mm_batch_prob *__restrict__ tab, const int32_t *__restrict__ list) {
+    const mm_batch_prob &bp = tab[list[blockIdx.y]];
+    if (blockIdx.x >= bp.g_pairs) return;
+    SlabSync none = {};
+    schur_pairs_body<true>(bp.pb, bp.schur_camtab, (const ChunkDesc *)bp.schur_desc, bp.x + bp.nc, bp.Cinv, bp.g + bp.nc, bp.schur_partial, bp.Bd,
+                     bp.g, bp.S, bp.v, bp.schur_seg_done, none, 0u, bp.g_pairs, blockIdx.x);
+}
+
 
 
 // (Round 4, tried and dropped: a PERSISTENT variant of this kernel in which a wave walks a sequence of chunks and requests the
@@ -641,15 +721,15 @@ __global__ void schur_diag_fill_kernel(mm_ba_problem pb, const double *__restric
 // point_inverse + schur_diag_fill + cam_table in ONE launch (the banded build's three small preparation steps: each was a
 // launch of a few microseconds in front of every build).  Workgroup b: the points 256 b .., camera b's diagonal block if it
 // has no observation, the table rows of cameras 256 b .. (and its share of the finished-chunk counters).
-__global__ __launch_bounds__(256) void schur_prepare_kernel(mm_ba_problem pb, const double *__restrict__ cams,
+__device__ __forceinline__ void schur_prepare_body(mm_ba_problem pb, const double *__restrict__ cams,
                                                             const double *__restrict__ Bd, const double *__restrict__ Cd,
                                                             const double *__restrict__ gc, double *__restrict__ Cinv,
                                                             double *__restrict__ S, double *__restrict__ v,
                                                             double *__restrict__ tab, int32_t *__restrict__ seg_done, bool lean,
-                                                            int32_t *__restrict__ desc /* [n_chunks][8] or NULL */) {
-    const int b = blockIdx.x, tid = threadIdx.x;
-    for (int64_t k = (int64_t)b * 256 + tid; k < pb.n_seg; k += (int64_t)gridDim.x * 256) seg_done[k] = 0;
-    if (desc) write_chunk_desc(pb, desc, (int64_t)b * 256 + tid, (int64_t)gridDim.x * 256);
+                                                            int32_t *__restrict__ desc /* [n_chunks][8] or NULL */, const unsigned bx, const unsigned gx) {
+    const int b = (int)bx, tid = threadIdx.x;
+    for (int64_t k = (int64_t)b * 256 + tid; k < pb.n_seg; k += (int64_t)gx * 256) seg_done[k] = 0;
+    if (desc) write_chunk_desc(pb, desc, (int64_t)b * 256 + tid, (int64_t)gx * 256);
     const int f = b * 256 + tid;
     if (f < pb.F) {
         const double *c = cams + (size_t)f * 6;
@@ -687,6 +767,21 @@ __global__ __launch_bounds__(256) void schur_prepare_kernel(mm_ba_problem pb, co
         o[5] = (a * e - bq * bq) * id;
     }
 }
+__global__ __launch_bounds__(256) void schur_prepare_kernel(mm_ba_problem pb, const double *__restrict__ cams,
+                                                            const double *__restrict__ Bd, const double *__restrict__ Cd,
+                                                            const double *__restrict__ gc, double *__restrict__ Cinv,
+                                                            double *__restrict__ S, double *__restrict__ v,
+                                                            double *__restrict__ tab, int32_t *__restrict__ seg_done, bool lean,
+                                                            int32_t *__restrict__ desc) {
+    schur_prepare_body(pb, cams, Bd, Cd, gc, Cinv, S, v, tab, seg_done, lean, desc, blockIdx.x, gridDim.x);
+}
+__global__ __launch_bounds__(256) void schur_prepare_batch_kernel(const mm_batch_prob *__restrict__ tab, const int32_t *__restrict__ list) {
+    const mm_batch_prob &bp = tab[list[blockIdx.y]];
+    if (blockIdx.x >= bp.g_prep) return;
+    schur_prepare_body(bp.pb, bp.x, bp.Bd, bp.Cd, bp.g, bp.Cinv, bp.S, bp.v, bp.schur_camtab, bp.schur_seg_done, true, bp.schur_desc,
+                       blockIdx.x, bp.g_prep);
+}
+
 
 // ---- device-side construction of the co-observation pair list ------------------------------------------------------
 // cnt[o] = number of observations o2 of the same point with camera(o2) <= camera(o); span = max camera distance.
@@ -907,5 +1002,33 @@ extern "C" int mm_ba_schur_solve(mm_ctx *ctx, const mm_ba_problem *pb, const dou
     MM_LAUNCH_PAIRS(ctx, dim3(wg_total - wg_first), *pb, (const double *)w.camtab, w.desc, pts, (const double *)Cinv, gp, w.partial, Bd, gc, S, v,
                     w.seg_done, slabs, wg_first, wg_total);
     MM_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    return MM_OK;
+}
+
+// ---- batched build of the reduced camera systems (mm_ba_trf_batched, trf.hip) ------------------------------------------------
+int mm_batch_schur_setup(mm_ctx *ctx, mm_batch_prob *bp, void *ws_schur, size_t ws_schur_bytes) {
+    const mm_ba_problem *pb = &bp->pb;
+    if (!(pb->n_seg > 0 && pb->n_chunks > 0 && pb->seg_ids && pb->seg_chunk_ptr && pb->chunk_seg && pb->chunk_begin && pb->chunk_end &&
+          pb->pair_o && pb->pair_o2 && pb->pair_p) || pb->P <= 0)
+        return mm_fail(ctx, MM_ERR_ARG, "mm_ba_trf_batched: a problem without a co-observation pair list");
+    if (!ws_schur || ws_schur_bytes < mm_ba_schur_workspace_bytes(pb)) return mm_fail(ctx, MM_ERR_WORKSPACE, "mm_ba_trf_batched: Schur workspace");
+    const SchurWs w = carve_schur_ws(pb, ws_schur);
+    bp->schur_partial = w.partial;
+    bp->schur_camtab = w.camtab;
+    bp->schur_seg_done = w.seg_done;
+    bp->schur_desc = w.desc;
+    bp->g_prep = (uint32_t)((pb->P + 255) / 256 > pb->F ? (pb->P + 255) / 256 : pb->F);
+    bp->g_pairs = (uint32_t)((pb->n_chunks + SP_WAVES - 1) / SP_WAVES);
+    const int64_t n2 = bp->nc * bp->nc / 2;
+    const int64_t gz = (n2 + 2047) / 2048;
+    bp->g_zero = (uint32_t)(gz < 1 ? 1 : (gz > 1024 ? 1024 : gz));
+    return MM_OK;
+}
+int mm_batch_schur(mm_ctx *ctx, const mm_batch_prob *tab, const int32_t *list, int n_list, unsigned max_g_zero, unsigned max_g_prep,
+                   unsigned max_g_pairs) {
+    if (n_list <= 0) return MM_OK;
+    MM_LAUNCH(ctx, "schur_zero_kernel", zero_batch_kernel, dim3(max_g_zero, (unsigned)n_list), dim3(256), 0, tab, list);
+    MM_LAUNCH(ctx, "schur_prepare_kernel", schur_prepare_batch_kernel, dim3(max_g_prep, (unsigned)n_list), dim3(256), 0, tab, list);
+    MM_LAUNCH(ctx, "schur_pairs_kernel", schur_pairs_batch_kernel, dim3(max_g_pairs, (unsigned)n_list), dim3(64 * SP_WAVES), 0, tab, list);
     return MM_OK;
 }

@@ -11,6 +11,8 @@
 // allocation, no second stream unless the overlapped build is requested.
 #include "mm_common.h"
 #include <chrono>
+#include <vector>
+#include <algorithm>
 #include <initializer_list>
 #include <utility>
 #include <cmath>
@@ -595,4 +597,361 @@ extern "C" int mm_ba_trf_dist(mm_ctx *ctx, const mm_ba_problem *pb, double *cams
                               mm_trf_report *rep, mm_trf_row *log, int log_cap, void *ws, size_t ws_bytes, const mm_dist *dist) {
     if (!dist) return mm_fail(ctx, MM_ERR_ARG, "mm_ba_trf_dist: null communicator description");
     return trf_run(ctx, pb, cams, pts, prm, rep, log, log_cap, ws, ws_bytes, dist);
+}
+
+
+// ---- several independent problems in lock-step: mm_ba_trf_batched -------------------------------------------------------------
+// The sliding-window adjustment (hook processor.py:395-408) solves dozens of small problems -- 50
+// cameras, ~75 k points -- whose kernels keep a fraction of the chip busy for a few microseconds each: one such solve is
+// bound by the latency of its ~28 launches per evaluation (0.29 ms), and running them on 8 streams gains 3x at most (more
+// streams or hardware queues make it worse: measured).  Here ALL problems advance together: every kernel of the loop is
+// launched once per round with blockIdx.y = problem (bodies and per-problem grids identical to the single-problem kernels:
+// bit-identical iterates), the host reads one mailbox per problem and round and takes each problem's accept / reject /
+// terminate decision exactly as mm_ba_trf does.  A round costs about what one evaluation of one problem costs.
+// A reduced system that is not positive definite is retried with 100x the damping inside the batch, as mm_ba_trf does (on
+// outlier-laden matches that is an everyday event).  A problem whose factorisation was abandoned, or that stays indefinite
+// after six raises, is taken out of the batch and solved by mm_ba_trf itself afterwards, from its initial point: every
+// result equals the one mm_ba_trf alone would have produced.
+namespace {
+struct BState {
+    int phase;      // 0 body + trial, 1 trial only, 2 final gradient norm, 3 done, 4 solve alone afterwards,
+                    // 5 reduced solve again with 100x the damping (+ trial)
+    double Delta, cost, cost0, x_norm, step_norm, actual, g_norm, alpha, min_damping, reg;
+    int nfev, njev, iteration, termination, attempt;
+    long max_nfev;
+    unsigned long long seq;
+};
+struct BHostBoard {
+    double v[16];
+    unsigned long long seq;
+    unsigned long long pad[7];      // 192 bytes: mailboxes of different problems never share a cache line
+};
+size_t batch_tables_bytes(const mm_ba_problem *pb) { return 2 * mm_align_up((size_t)pb->F * 5 * sizeof(double), 256); }
+}  // namespace
+
+extern "C" size_t mm_ba_trf_batched_workspace_bytes(const mm_ba_problem *pb) {
+    if (!pb || pb->F < 0 || pb->P < 0 || pb->O < 0) return 0;
+    return carve_trf(pb, nullptr).total + batch_tables_bytes(pb);
+}
+
+extern "C" int mm_ba_trf_batched(mm_ctx *ctx, int n_prob, const mm_ba_problem *const *pbs, double *const *cams, double *const *pts,
+                                 const mm_trf_params *prm, mm_trf_report *reports, void *const *ws, const size_t *ws_bytes,
+                                 int32_t *solved_alone) {
+    if (!ctx) return MM_ERR_ARG;
+    if (n_prob < 0 || (n_prob > 0 && (!pbs || !cams || !pts || !prm || !reports || !ws || !ws_bytes)))
+        return mm_fail(ctx, MM_ERR_ARG, "mm_ba_trf_batched: bad argument");
+    if (n_prob == 0) return MM_OK;
+    hipStream_t st = ctx->stream;
+    for (int p = 0; p < n_prob; ++p) {
+        const mm_ba_problem *pb = pbs[p];
+        if (!pb || !cams[p] || !pts[p] || pb->F <= 0 || pb->P < 0 || pb->O < 0 || !pb->K)
+            return mm_fail(ctx, MM_ERR_ARG, "mm_ba_trf_batched: bad problem %d", p);
+        if (!ws[p] || ws_bytes[p] < mm_ba_trf_batched_workspace_bytes(pb) || ((uintptr_t)ws[p] & 255))
+            return mm_fail(ctx, MM_ERR_WORKSPACE, "mm_ba_trf_batched: workspace of problem %d too small or misaligned", p);
+        if (solved_alone) solved_alone[p] = 0;
+    }
+    auto solve_alone = [&](int p) -> int {
+        if (solved_alone) solved_alone[p] = 1;
+        return trf_run(ctx, pbs[p], cams[p], pts[p], prm, &reports[p], nullptr, 0, ws[p], ws_bytes[p], nullptr);
+    };
+    // ---- the batch records; a problem the batched kernels cannot take sends the whole call down the one-by-one road ----
+    std::vector<mm_batch_prob> tab((size_t)n_prob);
+    std::vector<TrfWs> tws((size_t)n_prob);
+    bool batchable = n_prob > 1;
+    for (int p = 0; p < n_prob && batchable; ++p) {
+        const mm_ba_problem *pb = pbs[p];
+        const TrfWs t = carve_trf(pb, ws[p]);
+        tws[p] = t;
+        mm_batch_prob &b = tab[p];
+        memset(&b, 0, sizeof(b));
+        b.pb = *pb;
+        b.nc = 6 * (int64_t)pb->F;
+        b.n = b.nc + 3 * (int64_t)pb->P;
+        b.x = t.x; b.x_new = t.x_new; b.g = t.g; b.si = t.si; b.gh = t.gh; b.ghs = t.ghs; b.gn = t.gn; b.q1 = t.q1; b.w = t.w;
+        b.q2 = t.q2; b.s1 = t.s1; b.s2 = t.s2;
+        b.B = t.B; b.Bd = t.Bd; b.C = t.C; b.Cd = t.Cd; b.Cinv = t.Cinv; b.u1 = t.u1; b.Jq2 = t.Jq2; b.dp = t.dp; b.v = t.v; b.S = t.S;
+        b.r0 = t.r0; b.r1 = t.r1; b.r2 = t.r2; b.r3 = t.r3; b.d11 = t.d11; b.bs = t.bs; b.damp = t.damp; b.board = t.board;
+        b.info = t.info;
+        char *extra = (char *)ws[p] + t.total;
+        b.ctab_x = extra;
+        b.ctab_new = extra + mm_align_up((size_t)pb->F * 5 * sizeof(double), 256);
+        b.res_partial = (double *)t.ws_res;
+        b.md_counter = (unsigned *)t.ws_md;
+        b.md_partial = (double *)((char *)t.ws_md + 256);
+        b.jvp_partial = (double *)((char *)t.ws_jvp + 256);
+        b.backsub_T = (double *)t.ws_back;
+        b.half_bw = 6 * pb->cam_span + 5;
+        b.g_vec = mm_batch_fused_grid(b.n);
+        b.g_scale = (uint32_t)((b.n + 255) / 256);
+        b.g_damp = (uint32_t)(((int64_t)pb->F * 36 + (int64_t)pb->P * 6 + 255) / 256);
+        mm_batch_ba_setup(&b);
+        if (pb->O <= 0 || pb->P <= 0 || mm_batch_schur_setup(ctx, &b, t.ws_schur, t.ws_schur_b) != MM_OK ||
+            mm_batch_chol_setup(ctx, &b, t.ws_chol, t.ws_chol_b) != MM_OK)
+            batchable = false;
+    }
+    ctx->batch_last = batchable ? n_prob : 0;
+    if (!batchable) {
+        if (getenv("MM_BATCH_DEBUG")) fprintf(stderr, "mm_ba_trf_batched: %d problems one by one (%s)\n", n_prob, n_prob > 1 ? ctx->err : "a single problem");
+        for (int p = 0; p < n_prob; ++p) TRF_CALL(solve_alone(p));
+        return MM_OK;
+    }
+    // ---- device / pinned staging (kept by the context) ----
+    const size_t tab_b = mm_align_up((size_t)n_prob * sizeof(mm_batch_prob), 256), dyn_b = mm_align_up((size_t)n_prob * sizeof(mm_batch_dyn), 256);
+    const size_t list_b = mm_align_up((size_t)n_prob * sizeof(int32_t), 256);
+    constexpr int N_LISTS = 7;      // fused0 | final | body (new iteration) | trial | body (all) | retry | accept
+    const size_t dev_need = tab_b + dyn_b + N_LISTS * list_b;
+    const size_t host_need = dyn_b + N_LISTS * list_b + (size_t)n_prob * sizeof(BHostBoard) + (size_t)n_prob * 4 * sizeof(double);
+    if (ctx->batch_dev_cap < dev_need) {
+        if (ctx->batch_dev) (void)hipFree(ctx->batch_dev);
+        ctx->batch_dev = nullptr;
+        ctx->batch_dev_cap = 0;
+        MM_HIP(ctx, hipMalloc(&ctx->batch_dev, dev_need));
+        ctx->batch_dev_cap = dev_need;
+    }
+    if (ctx->batch_host_cap < host_need) {
+        if (ctx->batch_host) (void)hipHostFree(ctx->batch_host);
+        ctx->batch_host = nullptr;
+        ctx->batch_host_cap = 0;
+        MM_HIP(ctx, hipHostMalloc(&ctx->batch_host, host_need, hipHostMallocDefault));
+        ctx->batch_host_cap = host_need;
+    }
+    char *dbase = (char *)ctx->batch_dev, *hbase = (char *)ctx->batch_host;
+    mm_batch_prob *d_tab = (mm_batch_prob *)dbase;
+    mm_batch_dyn *d_dyn = (mm_batch_dyn *)(dbase + tab_b);
+    int32_t *d_list[N_LISTS];
+    for (int q = 0; q < N_LISTS; ++q) d_list[q] = (int32_t *)(dbase + tab_b + dyn_b + q * list_b);
+    mm_batch_dyn *h_dyn = (mm_batch_dyn *)hbase;
+    int32_t *h_list[N_LISTS];
+    for (int q = 0; q < N_LISTS; ++q) h_list[q] = (int32_t *)(hbase + dyn_b + q * list_b);
+    BHostBoard *mail = (BHostBoard *)(hbase + dyn_b + N_LISTS * list_b);
+    double *h_init = (double *)(mail + n_prob);      // per problem: cost2, |x si|^2 (3 doubles)
+    memset(mail, 0, (size_t)n_prob * sizeof(BHostBoard));
+    for (int p = 0; p < n_prob; ++p) tab[p].mailbox = &mail[p];
+    MM_HIP(ctx, hipMemcpyAsync(d_tab, tab.data(), (size_t)n_prob * sizeof(mm_batch_prob), hipMemcpyHostToDevice, st));
+    // ---- prologue, problem by problem with the single-problem calls (initial cost, normal equations, scale, Delta0) ----
+    for (int p = 0; p < n_prob; ++p) {
+        const mm_ba_problem *pb = pbs[p];
+        const TrfWs &t = tws[p];
+        const int64_t nc = tab[p].nc, n = tab[p].n;
+        MM_HIP(ctx, hipMemsetAsync(t.ws_md, 0, t.ws_md_b, st));
+        MM_HIP(ctx, hipMemsetAsync(t.ws_jvp, 0, t.ws_jvp_b, st));
+        MM_HIP(ctx, hipMemcpyAsync(t.x, cams[p], (size_t)nc * sizeof(double), hipMemcpyDeviceToDevice, st));
+        MM_HIP(ctx, hipMemcpyAsync(t.x + nc, pts[p], (size_t)3 * pb->P * sizeof(double), hipMemcpyDeviceToDevice, st));
+        TRF_CALL(mm_ba_residual(ctx, pb, t.x, t.x + nc, nullptr, t.cost2, t.ws_res, t.ws_res_b));
+        TRF_CALL(mm_ba_normal_eq(ctx, pb, t.x, t.x + nc, t.B, t.g, t.C, t.g + nc));
+        TRF_CALL(mm_ba_scale_update(ctx, pb->F, pb->P, t.B, t.C, t.si, 1));
+        hipLaunchKernelGGL(vec_mul_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double *)t.x, (const double *)t.si, t.w, n);
+        const double *pa[1] = {t.w}, *pbv[1] = {t.w};
+        TRF_CALL(mm_multi_dot(ctx, 1, pa, pbv, n, nc, t.rowsx, t.ws_md, t.ws_md_b));
+        MM_HIP(ctx, hipMemcpyAsync(h_init + 4 * p, t.cost2, sizeof(double), hipMemcpyDeviceToHost, st));
+        MM_HIP(ctx, hipMemcpyAsync(h_init + 4 * p + 1, t.rowsx, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
+    MM_HIP(ctx, hipStreamSynchronize(st));
+    std::vector<BState> S((size_t)n_prob);
+    for (int p = 0; p < n_prob; ++p) {
+        BState &s_ = S[p];
+        s_ = BState{};
+        s_.cost = s_.cost0 = 0.5 * h_init[4 * p];
+        if (!std::isfinite(s_.cost)) {
+            reports[p].status = -2;
+            return mm_fail(ctx, MM_ERR_NUMERIC, "mm_ba_trf_batched: residuals of problem %d are not finite in the initial point", p);
+        }
+        s_.Delta = std::sqrt(h_init[4 * p + 3]);
+        if (s_.Delta == 0) s_.Delta = 1.0;
+        s_.max_nfev = prm->max_nfev > 0 ? prm->max_nfev : (long)tab[p].n * 100;
+        s_.nfev = s_.njev = 1;
+        s_.termination = -100;
+        s_.step_norm = s_.actual = s_.g_norm = NAN;
+        s_.phase = 0;
+        s_.min_damping = prm->min_damping > 0 ? prm->min_damping : 1e-9;
+    }
+    // every problem's rotation coefficients at its starting point
+    auto upload_lists = [&]() -> int {
+        MM_HIP(ctx, hipMemcpyAsync(d_dyn, h_dyn, (size_t)n_prob * sizeof(mm_batch_dyn), hipMemcpyHostToDevice, st));
+        MM_HIP(ctx, hipMemcpyAsync(d_list[0], h_list[0], (N_LISTS - 1) * list_b, hipMemcpyHostToDevice, st));
+        return MM_OK;
+    };
+    auto max_of = [&](const int32_t *list, int cnt, uint32_t mm_batch_prob::*field) {
+        uint32_t m = 1;
+        for (int q = 0; q < cnt; ++q) m = std::max(m, tab[list[q]].*field);
+        return m;
+    };
+    {
+        for (int p = 0; p < n_prob; ++p) h_list[2][p] = p;
+        TRF_CALL(upload_lists());
+        TRF_CALL(mm_batch_cam_coef(ctx, d_tab, d_list[2], n_prob, max_of(h_list[2], n_prob, &mm_batch_prob::g_coef), 0));
+    }
+    auto wait_mail = [&](int p, unsigned long long seq) -> int {
+        BHostBoard *hb = &mail[p];
+        const auto t0 = std::chrono::steady_clock::now();
+        unsigned long spins = 0;
+        while (__atomic_load_n(&hb->seq, __ATOMIC_ACQUIRE) != seq) {
+            __builtin_ia32_pause();
+            if ((++spins & 0xFFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
+                MM_HIP(ctx, hipStreamSynchronize(st));
+                if (__atomic_load_n(&hb->seq, __ATOMIC_ACQUIRE) != seq)
+                    return mm_fail(ctx, MM_ERR_HIP, "mm_ba_trf_batched: the scalars of problem %d never arrived", p);
+            }
+        }
+        return MM_OK;
+    };
+    // ---- rounds ----
+    for (;;) {
+        int n_f0 = 0, n_final = 0, n_body = 0, n_trial = 0, n_all = 0, n_retry = 0;
+        for (int p = 0; p < n_prob; ++p) {
+            BState &s_ = S[p];
+            if (s_.phase == 3 || s_.phase == 4) continue;
+            h_dyn[p].Delta = s_.Delta;
+            h_dyn[p].seq = ++s_.seq;
+            h_dyn[p].min_damping = s_.min_damping;
+            h_dyn[p].reg = s_.reg;
+            if (s_.phase == 0 || s_.phase == 2) h_list[0][n_f0++] = p;
+            if (s_.phase == 2) h_list[1][n_final++] = p;
+            if (s_.phase == 0) h_list[2][n_body++] = p;
+            if (s_.phase != 2) h_list[3][n_trial++] = p;
+            if (s_.phase == 0 || s_.phase == 5) h_list[4][n_all++] = p;
+            if (s_.phase == 5) h_list[5][n_retry++] = p;
+        }
+        if (n_f0 + n_trial == 0) break;
+        TRF_CALL(upload_lists());
+        TRF_CALL(mm_batch_fused(ctx, 0, d_tab, d_list[0], n_f0, max_of(h_list[0], n_f0, &mm_batch_prob::g_vec)));
+        TRF_CALL(mm_batch_publish_rows(ctx, d_tab, d_list[1], n_final, d_dyn));
+        if (n_body) {
+            TRF_CALL(mm_batch_jvp_dots(ctx, d_tab, d_list[2], n_body, max_of(h_list[2], n_body, &mm_batch_prob::g_jvp), 0));
+            TRF_CALL(mm_batch_damping(ctx, d_tab, d_list[2], n_body, d_dyn));
+        }
+        TRF_CALL(mm_batch_set_reg(ctx, d_tab, d_list[5], n_retry, d_dyn));
+        if (n_all) {
+            const int32_t *L = d_list[4];
+            const int32_t *H = h_list[4];
+            const uint32_t gv = max_of(H, n_all, &mm_batch_prob::g_vec);
+            TRF_CALL(mm_batch_damp(ctx, d_tab, L, n_all, max_of(H, n_all, &mm_batch_prob::g_damp)));
+            TRF_CALL(mm_batch_schur(ctx, d_tab, L, n_all, max_of(H, n_all, &mm_batch_prob::g_zero), max_of(H, n_all, &mm_batch_prob::g_prep),
+                                    max_of(H, n_all, &mm_batch_prob::g_pairs)));
+            TRF_CALL(mm_batch_chol(ctx, d_tab, L, n_all, max_of(H, n_all, &mm_batch_prob::g_chol), max_of(H, n_all, &mm_batch_prob::g_bwd)));
+            TRF_CALL(mm_batch_backsub(ctx, d_tab, L, n_all, max_of(H, n_all, &mm_batch_prob::g_obs), max_of(H, n_all, &mm_batch_prob::g_pts)));
+            TRF_CALL(mm_batch_fused(ctx, 1, d_tab, L, n_all, gv));
+            TRF_CALL(mm_batch_fused(ctx, 2, d_tab, L, n_all, gv));
+            TRF_CALL(mm_batch_fused(ctx, 3, d_tab, L, n_all, gv));
+            TRF_CALL(mm_batch_jvp_dots(ctx, d_tab, L, n_all, max_of(H, n_all, &mm_batch_prob::g_jvp), 1));
+        }
+        if (n_trial) {
+            const int32_t *L = d_list[3];
+            TRF_CALL(mm_batch_step2d(ctx, d_tab, L, n_trial, d_dyn));
+            TRF_CALL(mm_batch_fused(ctx, 5, d_tab, L, n_trial, max_of(h_list[3], n_trial, &mm_batch_prob::g_vec)));
+            TRF_CALL(mm_batch_cam_coef(ctx, d_tab, L, n_trial, max_of(h_list[3], n_trial, &mm_batch_prob::g_coef), 1));
+            TRF_CALL(mm_batch_residual_publish(ctx, d_tab, L, n_trial, max_of(h_list[3], n_trial, &mm_batch_prob::g_res), d_dyn));
+        }
+        // ---- the host side of the round: every listed problem's decision, exactly as trf_run takes it ----
+        int n_accept = 0;
+        for (int q = 0; q < n_final; ++q) {
+            const int p = h_list[1][q];
+            BState &s_ = S[p];
+            // (a final problem is also in no other mailbox-writing list this round: its publish carries this round's seq)
+            TRF_CALL(wait_mail(p, s_.seq));
+            s_.g_norm = ((volatile double *)mail[p].v)[5];
+            s_.phase = 3;
+        }
+        for (int q = 0; q < n_trial; ++q) {
+            const int p = h_list[3][q];
+            BState &s_ = S[p];
+            TRF_CALL(wait_mail(p, s_.seq));
+            double host[16];
+            for (int i = 0; i < 16; ++i) host[i] = ((volatile double *)mail[p].v)[i];
+            if (s_.phase == 0 || s_.phase == 5) {      // first trial point of an iteration (or of a retry with raised damping)
+                const int inf = (int)host[6];
+                if (inf < 0) {      // the factorisation was abandoned: off the common road
+                    s_.phase = 4;
+                    continue;
+                }
+                if (inf > 0) {      // not positive definite at this damping: 100x, as mm_ba_trf (the trial point is dropped)
+                    if (++s_.attempt >= 6) {
+                        s_.phase = 4;      // (mm_ba_trf will report the failure)
+                        continue;
+                    }
+                    if (host[13] <= s_.min_damping * (1.0 + 1e-12)) s_.min_damping *= 100.0;
+                    s_.reg = host[13] * 100.0;
+                    s_.phase = 5;
+                    continue;
+                }
+                s_.attempt = 0;
+                s_.g_norm = host[10];
+                if (s_.g_norm < prm->gtol) {      // (checked before the step is used; the trial point is dropped)
+                    s_.termination = 1;
+                    s_.phase = 3;
+                    continue;
+                }
+                s_.x_norm = std::sqrt(host[9]);
+                s_.actual = -1.0;
+            }
+            const double predicted = host[2], step_h_norm = host[3], step_norm_dev = host[4];
+            const double cost_new = 0.5 * host[14];
+            ++s_.nfev;
+            bool again = false;      // another trial step of the same iteration
+            if (!std::isfinite(cost_new)) {
+                s_.Delta = 0.25 * step_h_norm;
+                again = s_.nfev < s_.max_nfev;
+            } else {
+                s_.actual = s_.cost - cost_new;
+                double Delta_new = s_.Delta, ratio;
+                update_tr_radius(Delta_new, s_.actual, predicted, step_h_norm, step_h_norm > 0.95 * s_.Delta, ratio);
+                s_.step_norm = step_norm_dev;
+                s_.termination = check_termination(s_.actual, s_.cost, s_.step_norm, s_.x_norm, ratio, prm->ftol, prm->xtol);
+                if (s_.termination == -100) {
+                    s_.alpha *= s_.Delta / Delta_new;
+                    s_.Delta = Delta_new;
+                    again = s_.actual <= 0 && s_.nfev < s_.max_nfev;
+                }
+            }
+            if (again) {
+                s_.phase = 1;
+                continue;
+            }
+            if (s_.actual > 0) {
+                s_.cost = cost_new;
+                ++s_.njev;
+                h_list[6][n_accept++] = p;
+            } else {
+                s_.step_norm = 0;
+                s_.actual = 0;
+            }
+            ++s_.iteration;
+            s_.phase = (s_.termination != -100 || s_.nfev == s_.max_nfev) ? 2 : 0;
+        }
+        if (n_accept) {
+            MM_HIP(ctx, hipMemcpyAsync(d_list[6], h_list[6], (size_t)n_accept * sizeof(int32_t), hipMemcpyHostToDevice, st));
+            const int32_t *L = d_list[6];
+            TRF_CALL(mm_batch_accept(ctx, d_tab, L, n_accept, max_of(h_list[6], n_accept, &mm_batch_prob::g_vec)));
+            TRF_CALL(mm_batch_normal_eq(ctx, d_tab, L, n_accept, max_of(h_list[6], n_accept, &mm_batch_prob::g_pblk),
+                                        [&] { int m = 1; for (int q = 0; q < n_accept; ++q) m = std::max(m, tab[h_list[6][q]].pb.F); return (unsigned)m; }()));
+            TRF_CALL(mm_batch_scale_update(ctx, d_tab, L, n_accept, max_of(h_list[6], n_accept, &mm_batch_prob::g_scale)));
+        }
+    }
+    // ---- results ----
+    for (int p = 0; p < n_prob; ++p) {
+        BState &s_ = S[p];
+        if (s_.phase != 3) continue;
+        const int64_t nc = tab[p].nc;
+        MM_HIP(ctx, hipMemcpyAsync(cams[p], tws[p].x, (size_t)nc * sizeof(double), hipMemcpyDeviceToDevice, st));
+        MM_HIP(ctx, hipMemcpyAsync(pts[p], tws[p].x + nc, (size_t)3 * pbs[p]->P * sizeof(double), hipMemcpyDeviceToDevice, st));
+        mm_trf_report &r = reports[p];
+        r.cost0 = s_.cost0;
+        r.cost = s_.cost;
+        r.optimality = s_.g_norm;
+        r.nfev = s_.nfev;
+        r.njev = s_.njev;
+        r.status = s_.termination == -100 ? 0 : s_.termination;
+        r.iterations = s_.iteration;
+        r.log_rows = 0;
+        r.min_damping = s_.min_damping;
+        r.chol_fallbacks = 0;
+        r.collectives = 0;
+    }
+    MM_HIP(ctx, hipStreamSynchronize(st));
+    for (int p = 0; p < n_prob; ++p)
+        if (S[p].phase == 4) {
+            --ctx->batch_last;
+            TRF_CALL(solve_alone(p));
+        }
+    return MM_OK;
 }

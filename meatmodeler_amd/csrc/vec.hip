@@ -192,10 +192,11 @@ __device__ __forceinline__ void fused_elem(const FusedArgs &a, int64_t i, int64_
     }
 }
 
+// (body shared by the single-problem kernel and the batched one: bx / gx stand for blockIdx.x / gridDim.x)
 template <int OP>
-__global__ __launch_bounds__(MD_THREADS) void fused_vec_kernel(FusedArgs args, int64_t n, int64_t split,
-                                                               double *__restrict__ partial, unsigned *__restrict__ counter,
-                                                               double *__restrict__ out) {
+__device__ __forceinline__ void fused_vec_body(const FusedArgs &args, int64_t n, int64_t split, double *__restrict__ partial,
+                                               unsigned *__restrict__ counter, double *__restrict__ out, const unsigned bx,
+                                               const unsigned gx) {
     constexpr int K = FusedTraits<OP>::K;
     constexpr int NA = 2 * K + 2;            // sums (camera, point) + the two maxima
     __shared__ double sm[(MD_THREADS / 64) * (NA > 0 ? NA : 1)];
@@ -203,8 +204,8 @@ __global__ __launch_bounds__(MD_THREADS) void fused_vec_kernel(FusedArgs args, i
     double acc[NA];
 #pragma unroll
     for (int q = 0; q < NA; ++q) acc[q] = 0.0;
-    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
-    const int64_t lo = per * blockIdx.x, hi = min(n, lo + per);
+    const int64_t per = (n + gx - 1) / gx;
+    const int64_t lo = per * bx, hi = min(n, lo + per);
     for (int64_t i = lo + threadIdx.x; i < hi; i += MD_THREADS) {
         double p[FV_MAXK] = {0, 0, 0, 0, 0}, mx = 0.0;
         fused_elem<OP>(args, i, split, p, mx);
@@ -241,16 +242,16 @@ __global__ __launch_bounds__(MD_THREADS) void fused_vec_kernel(FusedArgs args, i
         acc[2 * K + 1] = b1;
 #pragma unroll
         for (int q = 0; q < NA; ++q)
-            __hip_atomic_store(partial + (size_t)blockIdx.x * NA + q, acc[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(partial + (size_t)bx * NA + q, acc[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        s_last = atomicAdd(counter, 1u) == gridDim.x - 1;
+        s_last = atomicAdd(counter, 1u) == gx - 1;
     }
     __syncthreads();
     if (!s_last) return;
 #pragma unroll
     for (int q = 0; q < NA; ++q) acc[q] = 0.0;
     double g0 = 0.0, g1 = 0.0;
-    for (unsigned g = threadIdx.x; g < gridDim.x; g += MD_THREADS) {
+    for (unsigned g = threadIdx.x; g < gx; g += MD_THREADS) {
 #pragma unroll
         for (int q = 0; q < 2 * K; ++q)
             acc[q] += __hip_atomic_load(partial + (size_t)g * NA + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -291,9 +292,43 @@ __global__ __launch_bounds__(MD_THREADS) void fused_vec_kernel(FusedArgs args, i
 }
 
 template <int OP>
-int launch_fused(mm_ctx *ctx, const FusedArgs &args, int64_t n, int64_t split, double *partial, unsigned *counter, double *out) {
+__global__ __launch_bounds__(MD_THREADS) void fused_vec_kernel(FusedArgs args, int64_t n, int64_t split,
+                                                               double *__restrict__ partial, unsigned *__restrict__ counter,
+                                                               double *__restrict__ out) {
+    fused_vec_body<OP>(args, n, split, partial, counter, out, blockIdx.x, gridDim.x);
+}
+
+// the passes of mm_ba_trf's loop on the buffers of a batch record (operands as trf.hip passes them)
+template <int OP>
+__global__ __launch_bounds__(MD_THREADS) void fused_vec_batch_kernel(const mm_batch_prob *__restrict__ tab, const int32_t *__restrict__ list) {
+    const mm_batch_prob &bp = tab[list[blockIdx.y]];
+    if (blockIdx.x >= bp.g_vec) return;
+    FusedArgs a = {};
+    double *rows = nullptr;
+    if constexpr (OP == 0) {
+        a.in[0] = bp.g; a.in[1] = bp.si; a.out[0] = bp.gh; a.out[1] = bp.ghs; rows = bp.r0;
+    } else if constexpr (OP == 1) {
+        a.in[0] = bp.v; a.in[1] = bp.dp; a.in[2] = bp.si; a.in[3] = bp.gh; a.out[0] = bp.gn; a.out[1] = bp.q1;
+        a.scalar[0] = bp.r0 + 2; rows = bp.r1;
+    } else if constexpr (OP == 2) {
+        a.in[0] = bp.gn; a.in[1] = bp.q1; a.out[0] = bp.w; a.scalar[0] = bp.r1 + 2; rows = bp.r2;
+    } else if constexpr (OP == 3) {
+        a.in[0] = bp.w; a.in[1] = bp.q1; a.in[2] = bp.si; a.in[3] = bp.gh; a.in[4] = bp.x;
+        a.out[0] = bp.q2; a.out[1] = bp.s1; a.out[2] = bp.s2; a.scalar[0] = bp.r2 + 2; rows = bp.r3;
+    } else {
+        static_assert(OP == 5, "ops 0-3 and 5 are the ones the loop issues");
+        a.in[0] = bp.x; a.in[1] = bp.s1; a.in[2] = bp.s2; a.out[0] = bp.x_new; a.scalar[0] = bp.board;
+    }
+    fused_vec_body<OP>(a, bp.n, bp.nc, bp.md_partial, bp.md_counter, rows, blockIdx.x, bp.g_vec);
+}
+
+inline int fused_grid_of(int64_t n) {
     int64_t g = (n + 4 * MD_THREADS - 1) / (4 * MD_THREADS);
-    const int grid = (int)(g < 1 ? 1 : (g > MD_GRID ? MD_GRID : g));
+    return (int)(g < 1 ? 1 : (g > MD_GRID ? MD_GRID : g));
+}
+template <int OP>
+int launch_fused(mm_ctx *ctx, const FusedArgs &args, int64_t n, int64_t split, double *partial, unsigned *counter, double *out) {
+    const int grid = fused_grid_of(n);
     MM_LAUNCH(ctx, "fused_vec_kernel", fused_vec_kernel<OP>, dim3(grid), dim3(MD_THREADS), 0, args, n, split, partial, counter, out);
     return MM_OK;
 }
@@ -346,10 +381,10 @@ extern "C" int mm_trf_fused(mm_ctx *ctx, int op, const double *const *in, double
 // B [F,6,6] and of the packed point blocks C [P,6] (xx,xy,xz,yy,yz,zz); first call: zeros become 1, later calls: running
 // maximum with the previous value.  One launch instead of diagonal / index / cat / sqrt / maximum.
 namespace {
-__global__ __launch_bounds__(256) void ba_scale_update_kernel(int64_t nc, int64_t n, const double *__restrict__ B,
-                                                              const double *__restrict__ C, double *__restrict__ si,
-                                                              int first) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void ba_scale_update_body(int64_t nc, int64_t n, const double *__restrict__ B,
+                                                     const double *__restrict__ C, double *__restrict__ si, int first,
+                                                     const unsigned bx) {
+    const int64_t i = (int64_t)bx * 256 + threadIdx.x;
     if (i >= n) return;
     double d;
     if (i < nc) {
@@ -367,12 +402,22 @@ __global__ __launch_bounds__(256) void ba_scale_update_kernel(int64_t nc, int64_
     si[i] = v;
 }
 
+__global__ __launch_bounds__(256) void ba_scale_update_kernel(int64_t nc, int64_t n, const double *__restrict__ B,
+                                                              const double *__restrict__ C, double *__restrict__ si,
+                                                              int first) {
+    ba_scale_update_body(nc, n, B, C, si, first, blockIdx.x);
+}
+__global__ __launch_bounds__(256) void ba_scale_update_batch_kernel(const mm_batch_prob *__restrict__ tab, const int32_t *__restrict__ list) {
+    const mm_batch_prob &bp = tab[list[blockIdx.y]];
+    if (blockIdx.x >= bp.g_scale) return;
+    ba_scale_update_body(bp.nc, bp.n, bp.B, bp.C, bp.si, 0, blockIdx.x);
+}
+
 // damped blocks  Bd = B + reg diag(si_c^2),  Cd = C + reg diag(si_p^2)  (reg read from device memory)
-__global__ __launch_bounds__(256) void ba_damp_kernel(int64_t F, int64_t P, const double *__restrict__ B,
-                                                      const double *__restrict__ C, const double *__restrict__ si,
-                                                      const double *__restrict__ reg_p, double *__restrict__ Bd,
-                                                      double *__restrict__ Cd) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void ba_damp_body(int64_t F, int64_t P, const double *__restrict__ B, const double *__restrict__ C,
+                                             const double *__restrict__ si, const double *__restrict__ reg_p,
+                                             double *__restrict__ Bd, double *__restrict__ Cd, const unsigned bx) {
+    const int64_t i = (int64_t)bx * 256 + threadIdx.x;
     const double reg = reg_p[0];
     const int64_t nb = F * 36;
     if (i < nb) {
@@ -392,6 +437,27 @@ __global__ __launch_bounds__(256) void ba_damp_kernel(int64_t F, int64_t P, cons
         }
         Cd[j] = v;
     }
+}
+__global__ __launch_bounds__(256) void ba_damp_kernel(int64_t F, int64_t P, const double *__restrict__ B,
+                                                      const double *__restrict__ C, const double *__restrict__ si,
+                                                      const double *__restrict__ reg_p, double *__restrict__ Bd,
+                                                      double *__restrict__ Cd) {
+    ba_damp_body(F, P, B, C, si, reg_p, Bd, Cd, blockIdx.x);
+}
+__global__ __launch_bounds__(256) void ba_damp_batch_kernel(const mm_batch_prob *__restrict__ tab, const int32_t *__restrict__ list) {
+    const mm_batch_prob &bp = tab[list[blockIdx.y]];
+    if (blockIdx.x >= bp.g_damp) return;
+    ba_damp_body(bp.pb.F, bp.pb.P, bp.B, bp.C, bp.si, bp.damp + 1, bp.Bd, bp.Cd, blockIdx.x);
+}
+// an accepted trial point becomes the iterate: x <- x_new, and the cameras' rotation coefficients with it (40 bytes per camera)
+__global__ __launch_bounds__(256) void batch_accept_kernel(const mm_batch_prob *__restrict__ tab, const int32_t *__restrict__ list) {
+    const mm_batch_prob &bp = tab[list[blockIdx.y]];
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < bp.n; i += stride) bp.x[i] = bp.x_new[i];
+    const int64_t nt = (int64_t)bp.pb.F * 5;
+    double *tx = (double *)bp.ctab_x;
+    const double *tn = (const double *)bp.ctab_new;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nt; i += stride) tx[i] = tn[i];
 }
 }  // namespace
 
@@ -437,7 +503,7 @@ __device__ __forceinline__ double model_2d(double b00, double b01, double b11, d
     return 0.5 * (p0 * (b00 * p0 + b01 * p1) + p1 * (b01 * p0 + b11 * p1)) + (g0 * p0 + g1 * p1);
 }
 
-__global__ __launch_bounds__(64) void trf_step2d_kernel(Step2dIn in, double Delta, double *__restrict__ board) {
+__device__ __forceinline__ void trf_step2d_body(const Step2dIn &in, double Delta, double *__restrict__ board) {
     const int lane = threadIdx.x;
     const double gh2 = in.r0[2], gmax = in.r0[5], d11 = in.d11[2], gn2 = in.r1[5], wn2 = in.r2[2];
     double n11 = in.r3[2], n12 = in.r3[5], n22 = in.r3[8], g2 = in.r3[11];
@@ -540,7 +606,53 @@ __global__ __launch_bounds__(64) void trf_step2d_kernel(Step2dIn in, double Delt
         board[13] = in.reg[0];
     }
 }
+__global__ __launch_bounds__(64) void trf_step2d_kernel(Step2dIn in, double Delta, double *__restrict__ board) {
+    trf_step2d_body(in, Delta, board);
+}
+__global__ __launch_bounds__(64) void trf_step2d_batch_kernel(const mm_batch_prob *__restrict__ tab, const int32_t *__restrict__ list,
+                                                              const mm_batch_dyn *__restrict__ dyn) {
+    const int pid = list[blockIdx.x];
+    const mm_batch_prob &bp = tab[pid];
+    const Step2dIn in = {bp.r0, bp.d11, bp.r1, bp.r2, bp.r3, bp.bs, bp.damp + 1, bp.info};
+    trf_step2d_body(in, dyn[pid].Delta, bp.board);
+}
 }  // namespace
+
+// ---- batched launches (mm_ba_trf_batched, trf.hip): grid = (largest per-problem grid, problems listed) ----------------------
+int mm_batch_fused(mm_ctx *ctx, int op, const mm_batch_prob *tab, const int32_t *list, int n_list, unsigned max_g) {
+    if (n_list <= 0) return MM_OK;
+    const dim3 grid(max_g, (unsigned)n_list);
+    switch (op) {
+        case 0: MM_LAUNCH(ctx, "fused_vec_kernel", fused_vec_batch_kernel<0>, grid, dim3(MD_THREADS), 0, tab, list); break;
+        case 1: MM_LAUNCH(ctx, "fused_vec_kernel", fused_vec_batch_kernel<1>, grid, dim3(MD_THREADS), 0, tab, list); break;
+        case 2: MM_LAUNCH(ctx, "fused_vec_kernel", fused_vec_batch_kernel<2>, grid, dim3(MD_THREADS), 0, tab, list); break;
+        case 3: MM_LAUNCH(ctx, "fused_vec_kernel", fused_vec_batch_kernel<3>, grid, dim3(MD_THREADS), 0, tab, list); break;
+        case 5: MM_LAUNCH(ctx, "fused_vec_kernel", fused_vec_batch_kernel<5>, grid, dim3(MD_THREADS), 0, tab, list); break;
+        default: return mm_fail(ctx, MM_ERR_ARG, "mm_batch_fused: op %d", op);
+    }
+    return MM_OK;
+}
+unsigned mm_batch_fused_grid(int64_t n) { return (unsigned)fused_grid_of(n); }
+int mm_batch_scale_update(mm_ctx *ctx, const mm_batch_prob *tab, const int32_t *list, int n_list, unsigned max_g) {
+    if (n_list <= 0) return MM_OK;
+    MM_LAUNCH(ctx, "ba_scale_update_kernel", ba_scale_update_batch_kernel, dim3(max_g, (unsigned)n_list), dim3(256), 0, tab, list);
+    return MM_OK;
+}
+int mm_batch_damp(mm_ctx *ctx, const mm_batch_prob *tab, const int32_t *list, int n_list, unsigned max_g) {
+    if (n_list <= 0) return MM_OK;
+    MM_LAUNCH(ctx, "ba_damp_kernel", ba_damp_batch_kernel, dim3(max_g, (unsigned)n_list), dim3(256), 0, tab, list);
+    return MM_OK;
+}
+int mm_batch_accept(mm_ctx *ctx, const mm_batch_prob *tab, const int32_t *list, int n_list, unsigned max_g) {
+    if (n_list <= 0) return MM_OK;
+    MM_LAUNCH(ctx, "batch_accept_kernel", batch_accept_kernel, dim3(max_g, (unsigned)n_list), dim3(256), 0, tab, list);
+    return MM_OK;
+}
+int mm_batch_step2d(mm_ctx *ctx, const mm_batch_prob *tab, const int32_t *list, int n_list, const mm_batch_dyn *dyn) {
+    if (n_list <= 0) return MM_OK;
+    MM_LAUNCH(ctx, "trf_step2d_kernel", trf_step2d_batch_kernel, dim3((unsigned)n_list), dim3(64), 0, tab, list, dyn);
+    return MM_OK;
+}
 
 extern "C" int mm_trf_step2d(mm_ctx *ctx, const double *r0, const double *d11, const double *r1, const double *r2, const double *r3,
                              const double *bs, const double *reg, const int32_t *info, double Delta, double *board) {

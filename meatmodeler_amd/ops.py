@@ -577,6 +577,40 @@ class BADevice:
         return dp
 
 
+def trf_solve_batched(problems, cams_list, pts_list, ftol, xtol, gtol, max_nfev=None, min_damping=1e-9, ctx=None):
+    """mm_ba_trf_batched: several independent problems (BADevice objects on one device) advanced in lock-step -- every
+    kernel of the trust-region loop once per round for all of them.  cams_list[p] [F_p,6] / pts_list[p] [P_p,3] are
+    updated in place; results are bit-identical to BADevice.trf_solve problem by problem.
+    -> (list of reports, list of bool "was solved alone after the batch")."""
+    n = len(problems)
+    if n == 0:
+        return [], []
+    ctx = ctx or problems[0].ctx
+    dev = problems[0].device
+    pbs = (C.POINTER(_lib.BAProblem) * n)()
+    cams_p, pts_p, ws_p = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_void_p * n)()
+    ws_b = (C.c_size_t * n)()
+    keep = []
+    for k, (pb, cm, pt) in enumerate(zip(problems, cams_list, pts_list)):
+        for t in (cm, pt):
+            assert t.dtype == torch.float64 and t.is_contiguous() and t.device == dev
+        assert pb.device == dev
+        need = lib.mm_ba_trf_batched_workspace_bytes(C.byref(pb.pb))
+        if getattr(pb, "_trf_ws", None) is None or pb._trf_ws.numel() < need:
+            pb._trf_ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        pbs[k] = C.pointer(pb.pb)
+        cams_p[k], pts_p[k], ws_p[k], ws_b[k] = cm.data_ptr(), pt.data_ptr(), pb._trf_ws.data_ptr(), pb._trf_ws.numel()
+        keep.append(pb._trf_ws)
+    prm = _lib.TrfParams(ftol, xtol, gtol, min_damping, int(max_nfev) if max_nfev else 0)
+    reps = (_lib.TrfReport * n)()
+    alone = (C.c_int32 * n)()
+    rc = lib.mm_ba_trf_batched(ctx.h, n, pbs, cams_p, pts_p, C.byref(prm), reps, ws_p, ws_b, alone)
+    if rc and any(r.status == -2 for r in reps):
+        raise ValueError("Residuals are not finite in the initial point.")
+    ctx.check(rc, "mm_ba_trf_batched")
+    return list(reps), [bool(a) for a in alone]
+
+
 class MultiDot:
     """[<a, b> for (a, b) in pairs] in one launch (mm_multi_dot): returns a device tensor [k, 3] =
     (sum over i < split, sum over i >= split, total).  Holds the zero-initialised workspace."""

@@ -134,7 +134,7 @@ class ClipPipeline:
         return inside & (last_frame <= hi - 2)
 
     def adjust_windows(self, out, K, extrinsics, window=50, stride=25, ftol=1e-4, verbose=0, timers=None, dist=None,
-                       order="sequential", streams=1):
+                       order="sequential", streams=1, batched=False):
         """Incremental bundle adjustment over a sliding window of keyframes: the reference keeps this step as a
         commented hook (processor.py:395-408: after a keyframe whose tracks were popped, `managePoints(popped_tracks)`
         + `adjustPoints` over everything so far); bounding it to the last `window` keyframes is what makes the
@@ -157,6 +157,10 @@ class ClipPipeline:
         same un-sharded code on the same inputs).  It is a different -- equally valid -- schedule than "sequential".
         streams > 1 (wavefront only): that many windows of a pass are in flight on this GPU at once, one HIP stream and
         one host thread each; the result does not depend on it either.
+        batched = True (wavefront only; supersedes `streams`): ALL windows of a pass that this rank owns advance in
+        lock-step through mm_ba_trf_batched -- every kernel of the trust-region loop is launched once per round for all of
+        them, so a pass costs about as many evaluations as its slowest window needs instead of the sum over its windows.
+        Bit-identical to solving the windows one at a time.
 
         `out` is the result of `run(..., ba=False)`.  -> dict(cams [F,6] device, points [T,3] device, windows=[...])."""
         d = self.device
@@ -167,7 +171,7 @@ class ClipPipeline:
             raise ValueError("order must be 'sequential' or 'wavefront'")
         if order == "wavefront":
             return self._adjust_windows_wavefront(out, K, extrinsics, window, stride, ftol, verbose, timers, allreduce,
-                                                  world, rank, streams)
+                                                  world, rank, streams, batched)
         F = int(np.asarray(extrinsics).shape[0])
         tp, of_, ok = out["track_ptr_dev"], out["obs_frame_dev"], out["obs_kp_dev"]
         xy = out["xy_dev"]
@@ -239,7 +243,7 @@ class ClipPipeline:
         return sel, fi, pi, coords, P, int(fi.numel())
 
     def _adjust_windows_wavefront(self, out, K, extrinsics, window, stride, ftol, verbose, timers, allreduce, world, rank,
-                                  streams=1):
+                                  streams=1, batched=False):
         d = self.device
         F = int(np.asarray(extrinsics).shape[0])
         tp, of_ = out["track_ptr_dev"], out["obs_frame_dev"]
@@ -306,7 +310,30 @@ class ClipPipeline:
             cam_mask = torch.zeros(F, dtype=torch.float64, device=d)
             pt_mask = torch.zeros(T, dtype=torch.float64, device=d)
             state = (cams, pts, cams_upd, cam_mask, pts_upd, pt_mask)
-            if n_streams > 1 and len(mine) > 1:
+            if batched and len(mine) > 1:
+                # every window of the pass through ONE lock-step solve (mm_ba_trf_batched)
+                items = []
+                for k in mine:
+                    lo, hi = wins[k]
+                    sel, fi, pi, coords, P, O = self._window_problem(out, first_f, last_f, lens_all, tp64, lo, hi, F)
+                    if P == 0:
+                        continue
+                    pb = ops.BADevice(K, fi, pi, coords, hi - lo, P, d, self.ctx)
+                    items.append((k, sel, pb, cams[lo:hi].contiguous(), pts[sel].contiguous(), P, O))
+                reps, _ = ops.trf_solve_batched([it[2] for it in items], [it[3] for it in items], [it[4] for it in items],
+                                                ftol, 1e-8, 1e-8, ctx=self.ctx)
+                rows, ks = [], []
+                for (k, sel, pb, cw, pw, P, O), rep in zip(items, reps):
+                    lo, hi = wins[k]
+                    cams_upd[lo:hi] = cw
+                    cam_mask[lo:hi] = 1.0
+                    pts_upd[sel] = pw
+                    pt_mask[sel] = 1.0
+                    rows.append([P, O, rep.nfev, rep.status, rep.cost])
+                    ks.append(k)
+                if ks:
+                    table[torch.tensor(ks, device=d)] = torch.tensor(rows, dtype=torch.float64, device=d)
+            elif n_streams > 1 and len(mine) > 1:
                 torch.cuda.current_stream(d).synchronize()        # the pass's inputs are complete
                 with ThreadPoolExecutor(max_workers=n_streams) as pool:
                     for f_ in [pool.submit(solve_window_on_slot, k, *state) for k in mine]:

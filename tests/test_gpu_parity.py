@@ -1488,6 +1488,11 @@ def test_wavefront_windows_in_flight_on_several_streams_equal_one_at_a_time():
     assert len(one["windows"]) >= 6 and max(w["colour"] for w in one["windows"]) == 1
     assert one["windows"] == four["windows"]
     assert torch.equal(one["cams"], four["cams"]) and torch.equal(one["points"], four["points"])
+    # (batched = True on 4-camera windows: reduced systems smaller than two Cholesky blocks are solved one by one inside
+    # mm_ba_trf_batched -- same result; the lock-step path proper is tested on larger windows below)
+    bat = pipe.adjust_windows(out, K, ext, window=W, stride=S, order="wavefront", batched=True)
+    assert one["windows"] == bat["windows"]
+    assert torch.equal(one["cams"], bat["cams"]) and torch.equal(one["points"], bat["points"])
 
 
 def test_flatten_tracks_device_equals_manage_points(golden_dir):
@@ -1593,6 +1598,67 @@ def test_c5_shape_4k_windows_on_one_gpu():
     res1 = pipe.adjust_windows(out, K, ext, window=W, stride=W // 2, order="wavefront", streams=1)
     assert res1["windows"] == res2["windows"]
     assert torch.equal(res1["cams"], res2["cams"]) and torch.equal(res1["points"], res2["points"])
+    # ... and so does advancing all windows of a pass in lock-step (mm_ba_trf_batched)
+    res3 = pipe.adjust_windows(out, K, ext, window=W, stride=W // 2, order="wavefront", batched=True)
+    assert res1["windows"] == res3["windows"]
+    assert torch.equal(res1["cams"], res3["cams"]) and torch.equal(res1["points"], res3["points"])
+
+
+def test_trf_batched_equals_one_problem_at_a_time():
+    """mm_ba_trf_batched: independent problems of different sizes advanced in lock-step -- one launch of
+    every kernel per round with blockIdx.y = problem -- against mm_ba_trf on each of them alone: identical cameras and
+    points bit for bit, identical nfev / njev / status / iterations / cost / optimality.  The problems differ in size, in
+    how many evaluations they need (a tight and a loose tolerance would not fit one call, so the spread comes from noise
+    and outliers), in whether they stop on max_nfev, and one of them has observations no trial step improves at first."""
+    _needs_single_launch_chol()
+    _needs_library_driver()
+    ctx = default_context()
+    specs = [(24, 900, 6, 1, 0.5), (40, 2000, 6, 2, 1.0), (30, 1200, 5, 3, 3.0), (50, 4000, 8, 4, 0.3), (26, 700, 4, 5, 8.0),
+             (120, 3000, 6, 6, 0.7)]
+    probs, x0 = [], []
+    for F, P, L, seed, noise in specs:
+        pr = synth.make_ba_problem(F, P, L, seed=seed)
+        rng = np.random.default_rng(seed)
+        obs = pr["obs"] + rng.normal(0, noise, pr["obs"].shape)
+        if seed == 5:      # gross outliers: rejected trial steps, many evaluations
+            bad = rng.choice(len(obs), size=len(obs) // 50, replace=False)
+            obs[bad] += rng.normal(0, 200.0, (len(bad), 2))
+        with np.errstate(all="ignore"):
+            cams0 = bundleAdjuster.frameParameters(pr["ext"]).reshape(F, 6)
+        probs.append(ops.BADevice(pr["K"], pr["fi"], pr["pi"], obs, F, P, DEV, ctx))
+        x0.append((dev(cams0), dev(pr["pts0"].copy())))
+    for max_nfev in (None, 7):
+        alone = []
+        for pb, (c0, p0) in zip(probs, x0):
+            c, p_ = c0.clone(), p0.clone()
+            rep, _ = pb.trf_solve(c, p_, 1e-6, 1e-8, 1e-8, max_nfev=max_nfev)
+            alone.append((c, p_, rep))
+        cb, pbs_ = [c.clone() for c, _ in x0], [p_.clone() for _, p_ in x0]
+        reps, solved_alone = ops.trf_solve_batched(probs, cb, pbs_, 1e-6, 1e-8, 1e-8, max_nfev=max_nfev, ctx=ctx)
+        assert sum(solved_alone) <= 1      # (a problem whose reduced system needs a second damping leaves the batch: allowed)
+        nf = []
+        for (c, p_, rep), c2, p2, rep2 in zip(alone, cb, pbs_, reps):
+            assert (rep.nfev, rep.njev, rep.status, rep.iterations) == (rep2.nfev, rep2.njev, rep2.status, rep2.iterations)
+            assert rep.cost == rep2.cost and rep.cost0 == rep2.cost0 and rep.optimality == rep2.optimality
+            assert torch.equal(c, c2) and torch.equal(p_, p2)
+            nf.append(rep.nfev)
+        if max_nfev is None:
+            assert len(set(nf)) > 1 and all(r.status > 0 for r in reps)      # (the lock-step had problems finishing early)
+        else:
+            assert all(r.nfev <= 7 for r in reps) and any(r.status == 0 for r in reps)
+    # a problem the batched kernels cannot take (10 cameras: the reduced system is smaller than two Cholesky blocks) sends
+    # the call down the one-by-one road: same results, flagged
+    pr = synth.make_ba_problem(10, 500, 5, seed=9)
+    with np.errstate(all="ignore"):
+        cams0 = bundleAdjuster.frameParameters(pr["ext"]).reshape(10, 6)
+    small = ops.BADevice(pr["K"], pr["fi"], pr["pi"], pr["obs"], 10, 500, DEV, ctx)
+    c_s, p_s = dev(cams0), dev(pr["pts0"].copy())
+    c_a, p_a = c_s.clone(), p_s.clone()
+    rep_a, _ = small.trf_solve(c_a, p_a, 1e-6, 1e-8, 1e-8)
+    cb, pbs_ = [x0[0][0].clone(), c_s.clone()], [x0[0][1].clone(), p_s.clone()]
+    reps, solved_alone = ops.trf_solve_batched([probs[0], small], cb, pbs_, 1e-6, 1e-8, 1e-8, ctx=ctx)
+    assert solved_alone == [True, True] and ctx.control(ctx.CTL_BATCH_LAST) == 0
+    assert torch.equal(cb[1], c_a) and torch.equal(pbs_[1], p_a) and reps[1].nfev == rep_a.nfev and reps[1].cost == rep_a.cost
 
 
 def test_clip_pipeline_c2_shape_match_and_triangulate():
