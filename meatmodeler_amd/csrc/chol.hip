@@ -122,6 +122,13 @@ __device__ __forceinline__ void dpp_update_cols(double (&a)[16], double (&sh)[16
         dpp_update_cols<Q, J + 1>(a, sh, slq, lq);
     }
 }
+// (Round 4, tried and dropped: issuing column Q + 1's pivot chain -- broadcast, v_rsq_f64, refinement, scaling: ten
+// dependent instructions -- one by one BETWEEN the independent v_fmac_f64_dpp pairs of column Q's update, every instruction a
+// volatile asm statement in hand-written order.  Bit-identical factors, and not a microsecond gained (0.679 ms per
+// factor + solve at n = 3000 either way): the panel is bound by the NUMBER of f64 / DPP instructions a lone wave can issue
+// (one per ~8 cycles), not by the latency of the pivot chain.  Likewise the third-order refinement below (5 instead of 9
+// instructions per pivot) moved nothing measurable.  What would: half the FMAs, i.e. no shadow copy -- which f64 DPP,
+// with row_newbcast as its only broadcast, does not offer.)
 template <int Q>
 __device__ __forceinline__ void dpp_column(double (&a)[16], double (&sh)[16], double &rvec, int t) {
     const double piv = mov_bcast<Q>(sh[Q]);
@@ -1644,6 +1651,18 @@ __device__ __forceinline__ double tile_matvec_t(const double (*T)[LDT], const do
     __syncthreads();
     return (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
 }
+// The same product straight from the registers a tile was prefetched into (tile_prefetch / tile_prefetch_dense: element
+// threadIdx.x + 256 q = row (threadIdx.x >> 6) + 4 q, column threadIdx.x & 63): thread (g, c) adds the rows g, g + 4, ... of
+// column c -- the tile never goes through LDS (16 stores + 16 loads per thread and a barrier less per product; round 4).
+__device__ __forceinline__ double reg_matvec_t(const double (&pre)[16], const double *v, double (*part)[NB]) {
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    double s = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s += pre[q] * v[g + 4 * q];
+    part[g][c] = s;
+    __syncthreads();
+    return (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+}
 // poll one double until it is no longer the sentinel (bounded); *failed is set if the wait is abandoned
 __device__ __forceinline__ double poll_value(const double *p, int32_t *abort_flag, int &failed) {
     for (long it = 0; it < SPIN_LIMIT; ++it) {
@@ -1661,8 +1680,7 @@ __device__ __forceinline__ void chol_band_bwd_body(double *A, TwGeom g, const do
                                                             const double *__restrict__ y, double *x, double *contrib,
                                                             int32_t *__restrict__ abort_flag, int32_t *__restrict__ info, const unsigned bx) {
     extern __shared__ double smem[];
-    double (*T0)[LDT] = reinterpret_cast<double (*)[LDT]>(smem);
-    double (*T1)[LDT] = reinterpret_cast<double (*)[LDT]>(smem + NB * LDT);
+    double (*T1)[LDT] = reinterpret_cast<double (*)[LDT]>(smem + NB * LDT);      // (side 1's prologue only)
     double (*part)[NB] = reinterpret_cast<double (*)[NB]>(smem + 2 * NB * LDT);
     double *vec = smem + 2 * NB * LDT + 4 * NB, *vec2 = vec + NB;
     const int bwb = g.bwb, W = bwb + 1, nblk = g.nblk, n = g.n;
@@ -1702,9 +1720,6 @@ __device__ __forceinline__ void chol_band_bwd_body(double *A, TwGeom g, const do
                     cv[dd] = __hip_atomic_load(cslot(k, dd) + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
         auto step = [&](int k, double (&p0)[16], double (&p1)[16]) {
-            tile_commit(T0, p0);
-            if (k > 0) tile_commit(T1, p1);
-            fetch(k - 2, p0, p1);
             if (threadIdx.x < NB) {
                 double rhs = yk - local;
 #pragma unroll
@@ -1720,7 +1735,7 @@ __device__ __forceinline__ void chol_band_bwd_body(double *A, TwGeom g, const do
                 dead = true;
                 return;
             }
-            const double xk = tile_matvec_t(T0, vec, part);
+            const double xk = reg_matvec_t(p0, vec, part);
             if (threadIdx.x < NB) {
                 long vi;
                 const bool ok = vpos(k, vi);
@@ -1729,8 +1744,9 @@ __device__ __forceinline__ void chol_band_bwd_body(double *A, TwGeom g, const do
             }
             request(k - 1);
             __syncthreads();
-            if (k > 0) local = tile_matvec_t(T1, vec2, part);
-            __syncthreads();  // T0 / T1 / part are rewritten by the next step
+            if (k > 0) local = reg_matvec_t(p1, vec2, part);
+            fetch(k - 2, p0, p1);      // (both register sets of this step are spent)
+            __syncthreads();  // vec / vec2 / part are rewritten by the next step
         };
         const int ktop = ncols - 1;  // first block this chain solves for
         if (ktop < 0) return;
@@ -1767,8 +1783,6 @@ __device__ __forceinline__ void chol_band_bwd_body(double *A, TwGeom g, const do
     };
     bool dead = false;
     auto step = [&](int k, double (&pp)[16]) {
-        tile_commit(T0, pp);
-        fetch(k - 2, pp);
         if (threadIdx.x < NB) {
             long vi;
             vec[threadIdx.x] = vpos(k + d, vi) ? poll_value(x + vi, abort_flag, failed) : 0.0;
@@ -1777,8 +1791,9 @@ __device__ __forceinline__ void chol_band_bwd_body(double *A, TwGeom g, const do
             dead = true;
             return;
         }
-        const double t = tile_matvec_t(T0, vec, part);
+        const double t = reg_matvec_t(pp, vec, part);
         if (threadIdx.x < NB) st_shared<2>(cslot(k, d) + threadIdx.x, t);
+        fetch(k - 2, pp);
         __syncthreads();
     };
     fetch(kfirst, pa);
