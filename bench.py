@@ -99,8 +99,10 @@ def algorithmic_work(name, cfg):
         return it * (O * (4 + 4 + 16 + 24) + Fc * 42 * 8), 0, 0
     if name == "ba_jvp_kernel":
         return 2 * it * O * (48 + 16 + 24), 0, 0
-    if name == "schur_pairs_kernel":   # per co-observation pair: 2 idx + 2 obs + point + Cinv; ~600 f64 instr-lanes
-        return it * cfg.get("n_pairs", 0) * (8 + 4 + 32 + 24 + 48), it * cfg.get("n_pairs", 0) * 600.0, 0
+    if name == "schur_pairs_kernel":
+        # per co-observation pair: point index 4 B + point 24 B + C^-1 48 B gathered; ~254 f64 instructions (two lean
+        # evaluations of 64, Z 18, the 2 x 2 middle factor 12, T 24, the block's 72 multiply-adds)
+        return it * cfg.get("n_pairs", 0) * (4 + 24 + 48), it * cfg.get("n_pairs", 0) * 254.0, 0
     if name == "schur_init_kernel":
         return it * (6 * Fc) ** 2 * 8, 0, 0
     if name == "chol_update_kernel":     # band only: per block column ~ bwb (bwb + 1) / 2 tile products of 2 * 64^3 flop
@@ -268,6 +270,10 @@ def main():
                 row["algorithmic_GBps"] = by / (per * 1e-3) / 1e9
             if lops:
                 row["valu_Tlops"] = lops / (per * 1e-3) / 1e12
+                if name == "schur_pairs_kernel":      # f64 lane-instructions: half the 32-bit issue rate
+                    row["f64_valu_frac"] = row["valu_Tlops"] / (VALU_PEAK_TLOPS / 2)
+                    row["note"] = ("bound by the latency of its dependent gathers at two waves per SIMD (236 VGPRs), not by arithmetic: "
+                                   "ablation in csrc/schur.hip")
             if fl:
                 row["mfma_f64_TFLOPs"] = fl / (per * 1e-3) / 1e12
             rows.append(row)
@@ -285,6 +291,8 @@ def main():
             row["algorithmic_GBps"] = by / (per * 1e-3) / 1e9
         if lops:
             row["valu_Tlops"] = lops / (per * 1e-3) / 1e12
+            if name == "schur_pairs_kernel":
+                row["f64_valu_frac"] = row["valu_Tlops"] / (VALU_PEAK_TLOPS / 2)
         if fl:
             row["mfma_f64_TFLOPs"] = fl / (per * 1e-3) / 1e12
         kernels.append(row)
@@ -299,7 +307,7 @@ def main():
         in_timed = dom_full["kernel"] in timed
         pmc = {}
         try:
-            pmc_file = next(f for f in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+            pmc_file = next(f for f in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
                             if os.path.exists(os.path.join(ROOT, "profiles", f)))
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))["kernels"].get(dom["kernel"], {})
         except Exception:

@@ -393,21 +393,38 @@ __global__ __launch_bounds__(256) void ba_backsub_obs_kernel(mm_ba_problem pb, c
                                                              const double *__restrict__ pts, const CamCoef *__restrict__ ctab,
                                                              const double *__restrict__ dc, double *__restrict__ T) { ba_backsub_obs_body(pb, cams, pts, ctab, dc, T, blockIdx.x, gridDim.x); }
 
+// (four lanes per point like the point blocks: rows of T that belong to one point are read by neighbouring lanes, and the
+// launch no longer waits for the threads that own the longest tracks; fixed butterfly: deterministic)
 __device__ __forceinline__ void ba_backsub_points_body(mm_ba_problem pb, const double *__restrict__ T,
                                                                 const double *__restrict__ Cinv, const double *__restrict__ gp,
                                                                 double *__restrict__ dp, const unsigned bx, const unsigned gx) {
-    const int p = bx * 256 + threadIdx.x;
-    if (p >= pb.P) return;
-    double t0 = gp[(size_t)p * 3], t1 = gp[(size_t)p * 3 + 1], t2 = gp[(size_t)p * 3 + 2];
-    for (int e = pb.pt_ptr[p]; e < pb.pt_ptr[p + 1]; ++e) {
-        t0 -= T[3 * (size_t)e];
-        t1 -= T[3 * (size_t)e + 1];
-        t2 -= T[3 * (size_t)e + 2];
+    const int sub = threadIdx.x & (PB_LANES - 1);
+    const int p = bx * (256 / PB_LANES) + (threadIdx.x / PB_LANES);
+    const bool live = p < pb.P;      // (no early return: whole waves execute the shuffles)
+    double t[3] = {0.0, 0.0, 0.0};
+    if (live) {
+        const int e_end = pb.pt_ptr[p + 1];
+        for (int e = pb.pt_ptr[p] + sub; e < e_end; e += PB_LANES) {
+            t[0] += T[3 * (size_t)e];
+            t[1] += T[3 * (size_t)e + 1];
+            t[2] += T[3 * (size_t)e + 2];
+        }
     }
-    const double *c = Cinv + (size_t)p * 6;
-    dp[(size_t)p * 3] = c[0] * t0 + c[1] * t1 + c[2] * t2;
-    dp[(size_t)p * 3 + 1] = c[1] * t0 + c[3] * t1 + c[4] * t2;
-    dp[(size_t)p * 3 + 2] = c[2] * t0 + c[4] * t1 + c[5] * t2;
+#pragma unroll
+    for (int off = 1; off < PB_LANES; off <<= 1) {
+        double u[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) u[q] = __shfl_xor(t[q], off, 64);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) t[q] += u[q];
+    }
+    if (live && sub == 0) {
+        const double t0 = gp[(size_t)p * 3] - t[0], t1 = gp[(size_t)p * 3 + 1] - t[1], t2 = gp[(size_t)p * 3 + 2] - t[2];
+        const double *c = Cinv + (size_t)p * 6;
+        dp[(size_t)p * 3] = c[0] * t0 + c[1] * t1 + c[2] * t2;
+        dp[(size_t)p * 3 + 1] = c[1] * t0 + c[3] * t1 + c[4] * t2;
+        dp[(size_t)p * 3 + 2] = c[2] * t0 + c[4] * t1 + c[5] * t2;
+    }
 }
 __global__ __launch_bounds__(256) void ba_backsub_points_kernel(mm_ba_problem pb, const double *__restrict__ T,
                                                                 const double *__restrict__ Cinv, const double *__restrict__ gp,
@@ -673,8 +690,8 @@ int mm_ba_backsub(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, cons
     if (ws && pb->O > 0) {
         MM_LAUNCH(ctx, "ba_backsub_kernel", ba_backsub_obs_kernel, dim3((unsigned)((pb->O + 255) / 256)), dim3(256), 0, *pb, cams, pts,
                   ctab, dc, (double *)ws);
-        MM_LAUNCH(ctx, "ba_backsub_points_kernel", ba_backsub_points_kernel, dim3((pb->P + 255) / 256), dim3(256), 0, *pb,
-                  (const double *)ws, Cinv, gp, dp);
+        MM_LAUNCH(ctx, "ba_backsub_points_kernel", ba_backsub_points_kernel, dim3((pb->P + 256 / PB_LANES - 1) / (256 / PB_LANES)), dim3(256), 0,
+                  *pb, (const double *)ws, Cinv, gp, dp);
         return MM_OK;
     }
     MM_LAUNCH(ctx, "ba_backsub_kernel", ba_backsub_kernel, dim3((pb->P + 255) / 256), dim3(256), 0, *pb, cams, pts, ctab, Cinv, gp, dc, dp);
@@ -714,7 +731,7 @@ void mm_batch_ba_setup(mm_batch_prob *bp) {
     bp->g_jvp = (uint32_t)(nb < JVP_MAX_WG ? (nb < 1 ? 1 : nb) : JVP_MAX_WG);
     bp->g_pblk = (uint32_t)((pb.P + 256 / PB_LANES - 1) / (256 / PB_LANES));
     bp->g_obs = (uint32_t)(nb < 1 ? 1 : nb);
-    bp->g_pts = (uint32_t)((pb.P + 255) / 256);
+    bp->g_pts = (uint32_t)((pb.P + 256 / PB_LANES - 1) / (256 / PB_LANES));
     bp->g_coef = (uint32_t)((pb.F + 255) / 256);
 }
 int mm_batch_cam_coef(mm_ctx *ctx, const mm_batch_prob *tab, const int32_t *list, int n_list, unsigned max_g, int which) {

@@ -2001,6 +2001,7 @@ void mm_chol_release_budget(mm_ctx *ctx) {
 
 // the solve whose grid was reserved has been enqueued completely: remember where it ends on the stream
 static void chol_budget_mark(mm_ctx *ctx) {
+    if (ctx->fused_no_event) return;
     if (!ctx->fused_ev && hipEventCreateWithFlags(&ctx->fused_ev, hipEventDisableTiming) != hipSuccess) {
         ctx->fused_ev = nullptr;
         return;

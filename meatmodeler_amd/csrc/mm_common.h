@@ -41,6 +41,9 @@ struct mm_ctx {
     // without a host synchronisation (by the owner's next reservation or by another context that finds the budget spent)
     hipEvent_t fused_ev = nullptr;
     bool fused_ev_pending = false;
+    // mm_ba_trf returns the share itself at every read-back: no event needed there (recording one costs a ~6 us bubble
+    // behind every solve: measured in the kernel trace)
+    bool fused_no_event = false;
     // link.hip: formulation the last mm_link_tracks_device took (1 parallel, 0 serial -- asked for, or the safety valve), -1 none
     int link_last_variant = -1;
     // rotation coefficients of the cameras the BA sweeps were last called with (ba.hip: mm_cam_coef_table)

@@ -277,8 +277,10 @@ static int trf_run(mm_ctx *ctx, const mm_ba_problem *pb, double *cams, double *p
     // the launch-per-column factorisation; the context's setting is restored on the way out, its budget share returned
     struct FusedGuard {
         mm_ctx *c;
-        bool saved, saved_strict;
-        FusedGuard(mm_ctx *ctx, bool sharded) : c(ctx), saved(ctx->chol_avoid_fused), saved_strict(ctx->chol_strict_budget) {
+        bool saved, saved_strict, saved_no_event;
+        FusedGuard(mm_ctx *ctx, bool sharded)
+            : c(ctx), saved(ctx->chol_avoid_fused), saved_strict(ctx->chol_strict_budget), saved_no_event(ctx->fused_no_event) {
+            c->fused_no_event = true;      // (the share goes back at every read-back of this loop)
             // sharded: no rank-local choice of the factorisation path (a full budget reports info = -1 instead, and the
             // "a rank's factorisation was abandoned" flag of the trial-cost exchange moves all ranks together)
             if (sharded) c->chol_strict_budget = true;
@@ -286,6 +288,7 @@ static int trf_run(mm_ctx *ctx, const mm_ba_problem *pb, double *cams, double *p
         ~FusedGuard() {
             c->chol_avoid_fused = saved;
             c->chol_strict_budget = saved_strict;
+            c->fused_no_event = saved_no_event;
             mm_chol_release_budget(c);
         }
     } fused_guard(ctx, dist != nullptr);
