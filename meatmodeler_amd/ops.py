@@ -303,7 +303,8 @@ class BADevice:
                 seg_ids, counts = torch.unique_consecutive(key_s, return_counts=True)
                 seg_hi = torch.cumsum(counts, 0)
                 seg_lo = seg_hi - counts
-                CH = 256                                             # pairs per chunk (one wave, four lane strides)
+                # pairs per chunk = per wave of the pair kernel (a multiple of 64: whole lane strides)
+                CH = max(64, int(os.environ.get("MM_SCHUR_CHUNK", "256")) // 64 * 64)
                 cntc = (counts + (CH - 1)) // CH
                 first_hi = torch.cumsum(cntc, 0)
                 first = first_hi - cntc
