@@ -96,6 +96,8 @@ def algorithmic_work(name, cfg):
         return nfev * O * 48, 0, 0                      # idx 8 + obs 16 + point 24 (cameras stay in L2)
     if name in ("ba_point_blocks_kernel", "ba_backsub_kernel"):
         return it * (O * 28 + P * (24 + 72)), 0, 0
+    if name == "ba_normal_eq_kernel":      # point blocks + camera blocks in one launch
+        return it * (O * 28 + P * (24 + 72) + O * (4 + 4 + 16 + 24) + Fc * 42 * 8), 0, 0
     if name == "ba_camera_blocks_kernel":
         return it * (O * (4 + 4 + 16 + 24) + Fc * 42 * 8), 0, 0
     if name == "ba_jvp_kernel":

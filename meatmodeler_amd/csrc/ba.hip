@@ -216,6 +216,17 @@ __global__ __launch_bounds__(256) void ba_camera_blocks_kernel(mm_ba_problem pb,
                                                                const double *__restrict__ pts, double *__restrict__ B,
                                                                double *__restrict__ gc) { ba_camera_blocks_body(pb, cams, pts, B, gc, blockIdx.x, gridDim.x); }
 
+// ---- both block sweeps in ONE launch (round 4) ----------------------------------------------------------------------------
+// The two are independent and neither fills the chip (one workgroup per camera walking ~3 k observations; four lanes per
+// point): one after the other 44 + 43 us at C3, side by side about the longer of the two.  Workgroups [0, F) take the
+// cameras (the long-running ones first), the rest the points; bodies unchanged.
+__global__ __launch_bounds__(256) void ba_normal_eq_kernel(mm_ba_problem pb, const double *__restrict__ cams, const double *__restrict__ pts,
+                                                           const CamCoef *__restrict__ ctab, double *__restrict__ B, double *__restrict__ gc,
+                                                           double *__restrict__ C, double *__restrict__ gp) {
+    if ((int)blockIdx.x < pb.F) ba_camera_blocks_body(pb, cams, pts, B, gc, blockIdx.x, (unsigned)pb.F);
+    else ba_point_blocks_body(pb, cams, pts, ctab, C, gp, blockIdx.x - (unsigned)pb.F, gridDim.x - (unsigned)pb.F);
+}
+
 // ---- out = Jc wc[fi] + Jp wp[pi] ----------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ba_jvp_kernel(mm_ba_problem pb, const double *__restrict__ cams,
                                                      const double *__restrict__ pts, const CamCoef *__restrict__ ctab, const double *__restrict__ wc,
@@ -456,14 +467,7 @@ constexpr int JVP_MAX_WG = 2048;      // workgroups of the Jacobian product with
 __device__ __forceinline__ void trf_damping_body(const double *__restrict__ gh2, const double *__restrict__ d11, double Delta,
                                                  double min_damping, double *__restrict__ out) {
     if (threadIdx.x != 0) return;
-    const double a = 0.5 * d11[0], b = -gh2[0];
-    const double to_tr = Delta / sqrt(gh2[0]);
-    double best = fmin(0.0, to_tr * (a * to_tr + b));
-    if (a != 0.0) {
-        const double ext = -0.5 * b / a;
-        if (ext > 0.0 && ext < to_tr) best = fmin(best, ext * (a * ext + b));
-    }
-    const double reg = -best / (Delta * Delta);
+    const double reg = trf_damping_value(gh2[0], d11[0], Delta);
     out[0] = reg;
     out[1] = fmax(reg, min_damping);
 }
@@ -534,14 +538,12 @@ __global__ __launch_bounds__(256) void ba_backsub_points_batch_kernel(const mm_b
     MM_BATCH_PROB(g_pts);
     ba_backsub_points_body(bp.pb, bp.backsub_T, bp.Cinv, bp.g + bp.nc, bp.dp, blockIdx.x, bp.g_pts);
 }
-__global__ __launch_bounds__(256) void ba_point_blocks_batch_kernel(const mm_batch_prob *__restrict__ tab, const int32_t *__restrict__ list) {
-    MM_BATCH_PROB(g_pblk);
-    ba_point_blocks_body(bp.pb, bp.x, bp.x + bp.nc, (const CamCoef *)bp.ctab_x, bp.C, bp.g + bp.nc, blockIdx.x, bp.g_pblk);
-}
-__global__ __launch_bounds__(256) void ba_camera_blocks_batch_kernel(const mm_batch_prob *__restrict__ tab, const int32_t *__restrict__ list) {
+__global__ __launch_bounds__(256) void ba_normal_eq_batch_kernel(const mm_batch_prob *__restrict__ tab, const int32_t *__restrict__ list) {
     const mm_batch_prob &bp = tab[list[blockIdx.y]];
-    if ((int)blockIdx.x >= bp.pb.F) return;
-    ba_camera_blocks_body(bp.pb, bp.x, bp.x + bp.nc, bp.B, bp.g, blockIdx.x, (unsigned)bp.pb.F);
+    const unsigned F = (unsigned)bp.pb.F;
+    if (blockIdx.x < F) ba_camera_blocks_body(bp.pb, bp.x, bp.x + bp.nc, bp.B, bp.g, blockIdx.x, F);
+    else if (blockIdx.x - F < bp.g_pblk)
+        ba_point_blocks_body(bp.pb, bp.x, bp.x + bp.nc, (const CamCoef *)bp.ctab_x, bp.C, bp.g + bp.nc, blockIdx.x - F, bp.g_pblk);
 }
 
 }  // namespace
@@ -620,6 +622,13 @@ int mm_ba_normal_eq(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, co
     if (!cams || !pts) return mm_fail(ctx, MM_ERR_ARG, "mm_ba_normal_eq: null pointer");
     if ((B == nullptr) != (gc == nullptr) || (C == nullptr) != (gp == nullptr))
         return mm_fail(ctx, MM_ERR_ARG, "mm_ba_normal_eq: B/gc and C/gp come in pairs");
+    if (B && C && pb->P > 0 && pb->F > 0) {      // both sweeps side by side in one launch
+        if (!pb->pt_ptr || !pb->pt_obs || !pb->cam_ptr || !pb->cam_obs) return mm_fail(ctx, MM_ERR_ARG, "mm_ba_normal_eq: CSR missing");
+        MM_CAM_TABLE(ctx, pb, cams);
+        const unsigned g_pblk = (unsigned)((pb->P + 256 / PB_LANES - 1) / (256 / PB_LANES));
+        MM_LAUNCH(ctx, "ba_normal_eq_kernel", ba_normal_eq_kernel, dim3((unsigned)pb->F + g_pblk), dim3(256), 0, *pb, cams, pts, ctab, B, gc, C, gp);
+        return MM_OK;
+    }
     if (C) {
         if (!pb->pt_ptr || !pb->pt_obs) return mm_fail(ctx, MM_ERR_ARG, "mm_ba_normal_eq: point CSR missing");
         if (pb->P > 0) {
@@ -770,8 +779,7 @@ int mm_batch_residual_publish(mm_ctx *ctx, const mm_batch_prob *tab, const int32
 }
 int mm_batch_normal_eq(mm_ctx *ctx, const mm_batch_prob *tab, const int32_t *list, int n_list, unsigned max_g_pblk, unsigned max_F) {
     if (n_list <= 0) return MM_OK;
-    MM_LAUNCH(ctx, "ba_point_blocks_kernel", ba_point_blocks_batch_kernel, dim3(max_g_pblk, (unsigned)n_list), dim3(256), 0, tab, list);
-    MM_LAUNCH(ctx, "ba_camera_blocks_kernel", ba_camera_blocks_batch_kernel, dim3(max_F, (unsigned)n_list), dim3(256), 0, tab, list);
+    MM_LAUNCH(ctx, "ba_normal_eq_kernel", ba_normal_eq_batch_kernel, dim3(max_F + max_g_pblk, (unsigned)n_list), dim3(256), 0, tab, list);
     return MM_OK;
 }
 int mm_batch_publish_rows(mm_ctx *ctx, const mm_batch_prob *tab, const int32_t *list, int n_list, const mm_batch_dyn *dyn) {

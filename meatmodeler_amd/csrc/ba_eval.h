@@ -199,6 +199,20 @@ __device__ __forceinline__ void ba_eval(const double *__restrict__ cam, const do
     ba_eval_cc<WANT_JC, WANT_JP>(cam, cam_coef_of(cam), Xp, K, ox, oy, o);
 }
 
+// Regulariser of the 2-D subspace trust-region step (SciPy trf.py:473-477): with a = 0.5 |J_h g_h|^2, b = -|g_h|^2 minimise
+// t (a t + b) over [0, Delta / |g_h|]; reg = -min / Delta^2.  Shared by trf_damping_kernel (ba.hip) and the damping sweep
+// that computes it itself (vec.hip): the same expression, the same bits.
+__device__ __forceinline__ double trf_damping_value(double gh2, double d11, double Delta) {
+    const double a = 0.5 * d11, b = -gh2;
+    const double to_tr = Delta / sqrt(gh2);
+    double best = fmin(0.0, to_tr * (a * to_tr + b));
+    if (a != 0.0) {
+        const double ext = -0.5 * b / a;
+        if (ext > 0.0 && ext < to_tr) best = fmin(best, ext * (a * ext + b));
+    }
+    return -best / (Delta * Delta);
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);

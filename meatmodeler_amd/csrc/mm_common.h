@@ -78,6 +78,9 @@ void mm_cam_table_invalidate(mm_ctx *ctx);          // ... the caller says the v
 int mm_ba_residual_publish(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, const double *pts, void *ws,
                            size_t ws_bytes, double *board, int cost_slot, int count, void *host_board, unsigned long long seq);
 
+// vec.hip: mm_trf_damping + mm_ba_damp in one launch
+int mm_ba_damp_damping(mm_ctx *ctx, int F, int P, const double *B, const double *C, const double *scale_inv, const double *gh2,
+                       const double *d11, double Delta, double min_damping, double *damp_out, double *Bd, double *Cd);
 // chol.hip: give back the workgroups a context has reserved for a single-launch factorisation (call after a host sync)
 void mm_chol_release_budget(mm_ctx *ctx);
 // chol.hip internals used by the overlapped Schur + solve entry point (schur.hip)

@@ -433,7 +433,8 @@ static int trf_run(mm_ctx *ctx, const mm_ba_problem *pb, double *cams, double *p
             log_row(iteration, nfev, cost, actual, step_norm, g_norm);
             break;
         }
-        TRF_CALL(mm_trf_damping(ctx, t.r0 + 2, t.d11 + 2, Delta, min_damping, t.damp));
+        // (the damping of the iteration is computed by the first damped-blocks sweep itself: mm_trf_damping's formula, one
+        // launch less; a retry with raised damping reads damp[1] as the host left it)
         double *reg_eff = t.damp + 1;
         bool solved = false;
         auto trial = [&](double Delta_) -> int {
@@ -455,8 +456,14 @@ static int trf_run(mm_ctx *ctx, const mm_ba_problem *pb, double *cams, double *p
             TRF_CALL(exchange({{t.board + 14, 3}, {t.board + 15, 4}}));
             return read_board(t.board, 16);
         };
+        bool damping_known = false;
         for (int attempt = 0; attempt < 6 && !solved; ++attempt) {
-            TRF_CALL(mm_ba_damp(ctx, F, P, t.B, t.C, t.si, reg_eff, t.Bd, t.Cd));
+            if (!damping_known) {
+                TRF_CALL(mm_ba_damp_damping(ctx, F, P, t.B, t.C, t.si, t.r0 + 2, t.d11 + 2, Delta, min_damping, t.damp, t.Bd, t.Cd));
+                damping_known = true;
+            } else {
+                TRF_CALL(mm_ba_damp(ctx, F, P, t.B, t.C, t.si, reg_eff, t.Bd, t.Cd));
+            }
             if (!dist) {
                 TRF_CALL(mm_ba_schur_solve(ctx, pb, cams_of(x), pts_of(x), t.Bd, t.Cd, cams_of(t.g), pts_of(t.g), t.S, t.v, t.Cinv, half_bw,
                                            t.info, t.ws_schur, t.ws_schur_b, t.ws_chol, t.ws_chol_b, 0, 0, nullptr, nullptr));

@@ -12,7 +12,15 @@ namespace {
 
 constexpr int MD_MAX = 8;
 constexpr int MD_THREADS = 256;
-constexpr int MD_GRID = 512;
+constexpr int MD_GRID = 2048;      // capacity of the per-workgroup partials (workspace size); the launch uses md_grid_cap() of them
+inline int md_grid_cap() {
+    static const int cap = [] {
+        const char *e = getenv("MM_VEC_GRID");
+        const int v = e ? atoi(e) : 512;
+        return v < 1 ? 1 : (v > MD_GRID ? MD_GRID : v);
+    }();
+    return cap;
+}
 
 struct MultiDotArgs {
     const double *a[MD_MAX];
@@ -75,7 +83,7 @@ template <int K>
 int launch_multi_dot(mm_ctx *ctx, const MultiDotArgs &args, int64_t n, int64_t split, double *partial, unsigned *counter,
                      double *out) {
     int64_t g = (n + 4 * MD_THREADS - 1) / (4 * MD_THREADS);
-    const int grid = (int)(g < 1 ? 1 : (g > MD_GRID ? MD_GRID : g));
+    const int grid = (int)(g < 1 ? 1 : (g > md_grid_cap() ? md_grid_cap() : g));
     MM_LAUNCH(ctx, "multi_dot_kernel", multi_dot_kernel<K>, dim3(grid), dim3(MD_THREADS), 0, args, n, split, partial, counter, out);
     return MM_OK;
 }
@@ -399,7 +407,7 @@ __global__ __launch_bounds__(MD_THREADS) void fused_vec_batch_kernel(const mm_ba
 
 inline int fused_grid_of(int64_t n) {
     int64_t g = (n + 4 * MD_THREADS - 1) / (4 * MD_THREADS);
-    return (int)(g < 1 ? 1 : (g > MD_GRID ? MD_GRID : g));
+    return (int)(g < 1 ? 1 : (g > md_grid_cap() ? md_grid_cap() : g));
 }
 template <int OP>
 int launch_fused(mm_ctx *ctx, const FusedArgs &args, int64_t n, int64_t split, double *partial, unsigned *counter, double *out) {
@@ -493,11 +501,29 @@ __global__ __launch_bounds__(256) void ba_scale_update_batch_kernel(const mm_bat
 }
 
 // damped blocks  Bd = B + reg diag(si_c^2),  Cd = C + reg diag(si_p^2)  (reg read from device memory)
+// dmp != nullptr: the damping itself is computed here from the iteration's scalars (every thread the same value, thread 0
+// of workgroup 0 records {reg, max(reg, floor)} where trf_damping_kernel would have): one launch less per iteration
+struct DampingIn {
+    const double *gh2, *d11;
+    double Delta, min_damping;
+    double *out;
+};
 __device__ __forceinline__ void ba_damp_body(int64_t F, int64_t P, const double *__restrict__ B, const double *__restrict__ C,
                                              const double *__restrict__ si, const double *__restrict__ reg_p,
-                                             double *__restrict__ Bd, double *__restrict__ Cd, const unsigned bx) {
+                                             double *__restrict__ Bd, double *__restrict__ Cd, const unsigned bx,
+                                             const DampingIn *dmp = nullptr) {
     const int64_t i = (int64_t)bx * 256 + threadIdx.x;
-    const double reg = reg_p[0];
+    double reg;
+    if (dmp) {
+        const double r = trf_damping_value(dmp->gh2[0], dmp->d11[0], dmp->Delta);
+        reg = fmax(r, dmp->min_damping);
+        if (i == 0) {
+            dmp->out[0] = r;
+            dmp->out[1] = reg;
+        }
+    } else {
+        reg = reg_p[0];
+    }
     const int64_t nb = F * 36;
     if (i < nb) {
         const int64_t f = i / 36, e = i % 36;
@@ -528,6 +554,11 @@ __global__ __launch_bounds__(256) void ba_damp_batch_kernel(const mm_batch_prob 
     if (blockIdx.x >= bp.g_damp) return;
     ba_damp_body(bp.pb.F, bp.pb.P, bp.B, bp.C, bp.si, bp.damp + 1, bp.Bd, bp.Cd, blockIdx.x);
 }
+__global__ __launch_bounds__(256) void ba_damp_damping_kernel(int64_t F, int64_t P, const double *__restrict__ B,
+                                                              const double *__restrict__ C, const double *__restrict__ si,
+                                                              DampingIn dmp, double *__restrict__ Bd, double *__restrict__ Cd) {
+    ba_damp_body(F, P, B, C, si, nullptr, Bd, Cd, blockIdx.x, &dmp);
+}
 // an accepted trial point becomes the iterate: x <- x_new, and the cameras' rotation coefficients with it (40 bytes per camera)
 __global__ __launch_bounds__(256) void batch_accept_kernel(const mm_batch_prob *__restrict__ tab, const int32_t *__restrict__ list) {
     const mm_batch_prob &bp = tab[list[blockIdx.y]];
@@ -547,6 +578,18 @@ extern "C" int mm_ba_scale_update(mm_ctx *ctx, int F, int P, const double *B, co
     if (n == 0) return MM_OK;
     MM_LAUNCH(ctx, "ba_scale_update_kernel", ba_scale_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (int64_t)F * 6,
               n, B, C, scale_inv, first);
+    return MM_OK;
+}
+
+// mm_trf_damping + mm_ba_damp in one launch (mm_ba_trf's first attempt of an iteration): damp_out [2] receives what
+// mm_trf_damping writes
+int mm_ba_damp_damping(mm_ctx *ctx, int F, int P, const double *B, const double *C, const double *scale_inv, const double *gh2,
+                       const double *d11, double Delta, double min_damping, double *damp_out, double *Bd, double *Cd) {
+    const int64_t n = (int64_t)F * 36 + (int64_t)P * 6;
+    if (n == 0) return MM_OK;
+    DampingIn dmp = {gh2, d11, Delta, min_damping, damp_out};
+    MM_LAUNCH(ctx, "ba_damp_kernel", ba_damp_damping_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (int64_t)F, (int64_t)P, B, C,
+              scale_inv, dmp, Bd, Cd);
     return MM_OK;
 }
 
