@@ -316,7 +316,8 @@ __global__ __launch_bounds__(256) void ba_jvp_dots_kernel(mm_ba_problem pb, cons
                                                           const double *__restrict__ other, double *__restrict__ partial) { ba_jvp_dots_body(pb, cams, pts, ctab, wc, wp, out, other, partial, blockIdx.x, gridDim.x); }
 
 // adds the per-workgroup partials of ba_jvp_dots_kernel in index order (one workgroup; a shared arrival counter costs
-// ~11 ns per workgroup on 6 k workgroups -- more than this launch)
+// ~11 ns per workgroup on 6 k workgroups -- more than this launch.  Round 4 re-measured it with the 2048-workgroup cap:
+// finishing the sums in the kernel's last-arriving workgroup made the product 45 us instead of 27 + 5 for this launch.)
 __device__ __forceinline__ void jvp_rows_body(const double *__restrict__ partial, unsigned n_wg, double *__restrict__ rows, const unsigned bx, const unsigned gx) {
     __shared__ double sm[(256 / 64) * 2];
     double acc[2] = {0.0, 0.0};

@@ -340,3 +340,22 @@ def test_frame_oracle_definitions():
     flat = np.full((64, 96), 100, np.uint8)
     out = fo.clahe(flat)
     assert (out == out[0, 0]).all()
+
+
+def test_bench_launcher_refuses_without_enough_gpus():
+    """`python bench.py --gpus N` with no launcher around it starts its own ranks -- and says so loudly when the box has
+    fewer than N GPUs instead of reporting a one-GPU run as N.  On this CPU-only container: no GPU at
+    all, so both the nccl and the gloo-rehearsal form refuse before any rank is started."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                             "MM_DIST_BACKEND")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--frames", "8", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120, cwd=root)
+    assert p.returncode != 0
+    assert b"GPU(s) visible" in p.stderr or b"no GPU visible" in p.stderr
+    assert not any(ln.startswith(b"{") for ln in p.stdout.splitlines())
