@@ -702,7 +702,11 @@ __global__ __launch_bounds__(64 * SP_WAVES, 2) void schur_pairs_batch_kernel(con
 // next chunks' descriptors, camera tables, point indices and first point / C^-1 while it works on the current one.  It
 // needs ~40 more registers than the 218 used here; with the 256 that two waves per SIMD leave, the compiler spills ~45
 // values around every chunk and the kernel ran at 320-350 us against 222 us for this one (tools/bench_schur.py shape).
-// Three waves per SIMD (168 registers, 55 values in scratch) took 411 us.)
+// Three waves per SIMD (168 registers, 55 values in scratch) took 411 us.  The persistent variant rebuilt for ONE wave per
+// SIMD (289 registers, no scratch: latency to be hidden by the pipeline instead of by a second wave) took 325-373 us:
+// vector memory returns in order, so the first load a trip consumes -- the next index, gp of a self pair -- waits for every
+// prefetch issued before it; the second wave is what hides latency here, not issue order.)
+
 // marks a camera slab without any segment as complete (its rows only hold what schur_diag_fill wrote)
 __global__ void slab_flag_kernel(int32_t *flags, int s) {
     __hip_atomic_store(flags + s, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
