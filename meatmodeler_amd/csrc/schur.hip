@@ -514,7 +514,10 @@ __device__ __forceinline__ void schur_pairs_body(const mm_ba_problem pb, const d
 #pragma unroll
     for (int q = 0; q < 42; ++q) acc[q] = 0.0;
     // (the point of a pair is all the kernel gathers by: the observed coordinates are not needed)
-    auto load_xc = [&](int p, double (&x)[9]) {      // the point and its C^-1 (upper triangle)
+    // the point, its C^-1 (upper triangle) and -- diagonal segments only -- its gradient block: everything the arithmetic of
+    // a trip reads from memory, requested one trip ahead (vector memory returns in order: a load issued and consumed inside
+    // the trip would wait for the prefetches issued before it)
+    auto load_xc = [&](int p, double (&x)[12]) {
         if (p >= 0) {
             const double *Xp = pts + (size_t)p * 3, *ci = Cinv + (size_t)p * 6;
             x[0] = Xp[0];
@@ -522,9 +525,14 @@ __device__ __forceinline__ void schur_pairs_body(const mm_ba_problem pb, const d
             x[2] = Xp[2];
 #pragma unroll
             for (int q = 0; q < 6; ++q) x[3 + q] = ci[q];
+            if (d == 0) {
+                x[9] = gp[(size_t)p * 3];
+                x[10] = gp[(size_t)p * 3 + 1];
+                x[11] = gp[(size_t)p * 3 + 2];
+            }
         }
     };
-    auto pair_body = [&](int p, bool self, const double (&x)[9]) {
+    auto pair_body = [&](int p, bool self, const double (&x)[12]) {
         const double X0 = x[0], X1 = x[1], X2 = x[2];
         const double q00 = x[3], q01 = x[4], q02 = x[5], q11 = x[6], q12 = x[7], q22 = x[8];
         LeanJ a;
@@ -543,7 +551,7 @@ __device__ __forceinline__ void schur_pairs_body(const mm_ba_problem pb, const d
             // are the same whether or not o2 == o (a point observed twice in one frame) -- no second evaluation.  The
             // right-hand side takes one term per observation: the self pairs.
             if (self) {
-                const double g0 = gp[(size_t)p * 3], g1 = gp[(size_t)p * 3 + 1], g2 = gp[(size_t)p * 3 + 2];
+                const double g0 = x[9], g1 = x[10], g2 = x[11];
                 const double z0 = Z[0][0] * g0 + Z[0][1] * g1 + Z[0][2] * g2, z1 = Z[1][0] * g0 + Z[1][1] * g1 + Z[1][2] * g2;
 #pragma unroll
                 for (int q = 0; q < 6; ++q) acc[36 + q] += a.Jc[0][q] * z0 + a.Jc[1][q] * z1;
@@ -578,7 +586,7 @@ __device__ __forceinline__ void schur_pairs_body(const mm_ba_problem pb, const d
     // software pipeline over the trips of the chunk, two deep: the point index of trip t + 2 and the point / C^-1 of trip
     // t + 1 are requested before the arithmetic of trip t starts, so that a trip waits for neither of its two dependent
     // gathers (the kernel is bound by exactly those latencies at two waves per SIMD)
-    double xc[9];
+    double xc[12];
     load_xc(p_next, xc);
     int p_cur = p_next;
     bool self_cur = self_next;
@@ -589,14 +597,14 @@ __device__ __forceinline__ void schur_pairs_body(const mm_ba_problem pb, const d
     }
 #pragma clang loop unroll(disable)
     for (; e - lane < e_end; e += 64) {      // (wave-uniform trip count)
-        double xn[9];
+        double xn[12];
         load_xc(p_next, xn);
         const int p_nn_e = e + 128;
         const int p_nn = p_nn_e < e_end ? point_of(p_nn_e) : -1;
         const bool self_nn = p_nn_e < e_end && self_of(p_nn_e);
         if (p_cur >= 0) pair_body(p_cur, self_cur, xc);
 #pragma unroll
-        for (int q = 0; q < 9; ++q) xc[q] = xn[q];
+        for (int q = 0; q < 12; ++q) xc[q] = xn[q];
         p_cur = p_next;
         self_cur = self_next;
         p_next = p_nn;
