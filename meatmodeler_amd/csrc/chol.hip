@@ -148,9 +148,70 @@ __device__ __forceinline__ void dpp_column(double (&a)[16], double (&sh)[16], do
     asm volatile("s_nop 1" : "+v"(sh[Q]), "+v"(a[Q]));
     dpp_update_cols<Q, Q + 1>(a, sh, sh[Q], a[Q]);
 }
+// The LAST panel has no rows below its diagonal block: the block sits in DPP row 3, where the lane's own row IS the copy a
+// broadcast needs -- no shadow, half the FMAs (120 instead of 240; round 4).  Lanes of the rows above hold zeros throughout.
+template <int Q, int J>
+__device__ __forceinline__ void dpp_update_cols_own(double (&a)[16], double lq) {
+    if constexpr (J < 16) {
+        fmac_bcast<J>(a[J], lq, lq);
+        dpp_update_cols_own<Q, J + 1>(a, lq);
+    }
+}
+template <int Q>
+__device__ __forceinline__ void dpp_column_own(double (&a)[16], double &rvec, int t) {
+    const double piv = mov_bcast<Q>(a[Q]);
+    double r = __builtin_amdgcn_rsq(piv);
+    {
+        const double tt = piv * r;
+        const double e = fma(-tt, r, 1.0);
+        const double q = fma(0.375, e, 0.5);
+        r = fma(r * e, q, r);
+    }
+    rvec = t == Q ? r : rvec;
+    a[Q] *= r;
+    asm volatile("s_nop 1" : "+v"(a[Q]));
+    dpp_update_cols_own<Q, Q + 1>(a, a[Q]);
+}
+__device__ __forceinline__ void panel16_factor_dpp_last(double (*M)[NB + 1], double *R) {
+    constexpr int c0 = 48;
+    const int lane = lane_id(), t = lane & 15;
+    double a[16], rvec = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const double v = M[lane][c0 + q];
+        a[q] = lane >= c0 + q ? v : 0.0;
+    }
+    // (a pivot broadcast in the rows above reads 0 -> rsq = inf, 0 * inf = NaN in DEAD lanes only: they are written back
+    // as zeros below, and rvec is taken from the lanes of row 3)
+    dpp_column_own<0>(a, rvec, t);
+    dpp_column_own<1>(a, rvec, t);
+    dpp_column_own<2>(a, rvec, t);
+    dpp_column_own<3>(a, rvec, t);
+    dpp_column_own<4>(a, rvec, t);
+    dpp_column_own<5>(a, rvec, t);
+    dpp_column_own<6>(a, rvec, t);
+    dpp_column_own<7>(a, rvec, t);
+    dpp_column_own<8>(a, rvec, t);
+    dpp_column_own<9>(a, rvec, t);
+    dpp_column_own<10>(a, rvec, t);
+    dpp_column_own<11>(a, rvec, t);
+    dpp_column_own<12>(a, rvec, t);
+    dpp_column_own<13>(a, rvec, t);
+    dpp_column_own<14>(a, rvec, t);
+    dpp_column_own<15>(a, rvec, t);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        M[lane][c0 + q] = lane >= c0 + q ? a[q] : 0.0;
+    }
+    if (lane >= 48) R[lane] = rvec;
+}
 // Panel PB of the 64 x 64 block in M (columns c0 = 16 PB ..), ONE wave; R receives the reciprocal pivots.
 template <int PB>
 __device__ __forceinline__ void panel16_factor_dpp(double (*M)[NB + 1], double (*X)[NB + 1], double *R) {
+    if constexpr (PB == 3) {
+        panel16_factor_dpp_last(M, R);
+        return;
+    }
     constexpr int c0 = PB * 16;
     const int lane = lane_id(), t = lane & 15;
     double a[16], sh[16], rvec = 0.0;
