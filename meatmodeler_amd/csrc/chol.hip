@@ -18,6 +18,7 @@
 // MFMA fragment maps for f64 16x16x4 (guide section 3): A lane l -> A[l&15][l>>4], B lane l -> B[l>>4][l&15],
 // D reg i of lane l -> D[(l>>4) + 4 i][l&15].
 #include "mm_common.h"
+#include "chol_init.h"
 #include <mutex>
 #include <atomic>
 #include <type_traits>
@@ -1752,6 +1753,10 @@ __device__ __forceinline__ void chol_band_bwd_body(double *A, TwGeom g, const do
     const int ncols = side == 0 ? nrows : g.b;
     auto nat = [&](int blk) { return side == 0 ? blk : nblk - 1 - blk; };
     auto cslot = [&](int k, int d) { return contrib + (((size_t)side * nblk + k) * W + d) * NB; };
+    // x is POLLED in the d = 0 slots of side 0 (no step uses them; natural index vi -> block vi / 64), which start out as the
+    // sentinel with the rest of the buffer; `x` itself -- the caller's right-hand side, consumed by the forward
+    // substitution -- only receives plain copies, so nothing has to fill it between the two kernels
+    auto xpoll = [&](long vi) { return contrib + (size_t)(vi >> 6) * W * NB + (vi & 63); };
     // element threadIdx.x of vector block blk (natural storage); false: a virtual padding row
     auto vpos = [&](int blk, long &vi) -> bool {
         vi = vec_index(g, side, blk, threadIdx.x);
@@ -1800,7 +1805,10 @@ __device__ __forceinline__ void chol_band_bwd_body(double *A, TwGeom g, const do
             if (threadIdx.x < NB) {
                 long vi;
                 const bool ok = vpos(k, vi);
-                if (ok) st_shared<2>(x + vi, xk);
+                if (ok) {
+                    st_shared<2>(xpoll(vi), xk);
+                    x[vi] = xk;
+                }
                 vec2[threadIdx.x] = ok ? xk : 0.0;
             }
             request(k - 1);
@@ -1819,7 +1827,7 @@ __device__ __forceinline__ void chol_band_bwd_body(double *A, TwGeom g, const do
             tile_commit(T1, pt);
             if (threadIdx.x < NB) {
                 long vi;
-                vec2[threadIdx.x] = vpos(ktop + 1, vi) ? poll_value(x + vi, abort_flag, failed) : 0.0;
+                vec2[threadIdx.x] = vpos(ktop + 1, vi) ? poll_value(xpoll(vi), abort_flag, failed) : 0.0;
             }
             if (__syncthreads_or(failed)) MM_FUSED_ABANDON;
             local = tile_matvec_t(T1, vec2, part);
@@ -1846,7 +1854,7 @@ __device__ __forceinline__ void chol_band_bwd_body(double *A, TwGeom g, const do
     auto step = [&](int k, double (&pp)[16]) {
         if (threadIdx.x < NB) {
             long vi;
-            vec[threadIdx.x] = vpos(k + d, vi) ? poll_value(x + vi, abort_flag, failed) : 0.0;
+            vec[threadIdx.x] = vpos(k + d, vi) ? poll_value(xpoll(vi), abort_flag, failed) : 0.0;
         }
         if (__syncthreads_or(failed)) {
             dead = true;
@@ -1878,45 +1886,17 @@ __global__ __launch_bounds__(256) void chol_band_bwd_batch_kernel(const mm_batch
 
 
 // one launch instead of a handful of fills per solve: info = 0, flags = 0, sentinels into the backward kernel's
-// contribution buffer, the hand-over buffer of the streamed blocks and the diagonal 16 x 16 blocks of L^-1 (what the
-// consumers of the factorisation poll on)
-__device__ __forceinline__ void chol_init_body(int32_t *__restrict__ info, int32_t *__restrict__ flags, size_t nflags,
-                                                        unsigned long long *__restrict__ sentinel_buf, size_t nsent,
-                                                        unsigned long long *__restrict__ lpub, size_t nlpub,
-                                                        unsigned long long *__restrict__ Linv, size_t nblk, const unsigned bx, const unsigned gx) {
-    // (lpub covers both hand-over buffers: the streamed pieces of the diagonal blocks and the sub-diagonal blocks)
-    const size_t i = (size_t)bx * 256 + threadIdx.x, stride = (size_t)gx * 256;
-    if (i == 0) info[0] = 0;
-    for (size_t k = i; k < nflags; k += stride) flags[k] = 0;
-    for (size_t k = i; k < nsent; k += stride) sentinel_buf[k] = BWD_SENTINEL;
-    for (size_t k = i; k < nlpub; k += stride) lpub[k] = STAGE_SENTINEL;
-    for (size_t k = i; k < nblk * 1024; k += stride) {
-        const size_t b = k >> 10, d = (k >> 8) & 3, e = k & 255;
-        Linv[b * NB * NB + (16 * d + (e >> 4)) * NB + 16 * d + (e & 15)] = STAGE_SENTINEL;
-    }
-}
-__global__ __launch_bounds__(256) void chol_init_kernel(int32_t *__restrict__ info, int32_t *__restrict__ flags, size_t nflags,
-                                                        unsigned long long *__restrict__ sentinel_buf, size_t nsent,
-                                                        unsigned long long *__restrict__ lpub, size_t nlpub,
-                                                        unsigned long long *__restrict__ Linv, size_t nblk) {
-    chol_init_body(info, flags, nflags, sentinel_buf, nsent, lpub, nlpub, Linv, nblk, blockIdx.x, gridDim.x);
-}
+// contribution buffer (which also holds the words x is polled on), the hand-over buffer of the streamed blocks and the
+// diagonal 16 x 16 blocks of L^-1 (what the consumers of the factorisation poll on).  The body lives in chol_init.h:
+// schur_prepare_kernel runs it too when mm_ba_trf hands it the whole reduced solve (one launch less per solve).
+__global__ __launch_bounds__(256) void chol_init_kernel(mm_chol_init_args a) { mm_chol_init_body(a, blockIdx.x, gridDim.x); }
 constexpr unsigned CHOL_INIT_GRID = 128;
 __global__ __launch_bounds__(256) void chol_init_batch_kernel(const mm_batch_prob *__restrict__ tab, const int32_t *__restrict__ list) {
     const mm_batch_prob &bp = tab[list[blockIdx.y]];
-    chol_init_body(bp.info, bp.chol_flags, (size_t)bp.chol_nflags, (unsigned long long *)bp.chol_contrib_bwd, (size_t)bp.chol_nsent,
-                   (unsigned long long *)bp.chol_lpub, (size_t)bp.chol_nlpub, (unsigned long long *)bp.chol_Linv, (size_t)bp.chol_nblk,
-                   blockIdx.x, CHOL_INIT_GRID);
+    const mm_chol_init_args a = {bp.info, bp.chol_flags, (size_t)bp.chol_nflags, (unsigned long long *)bp.chol_contrib_bwd, (size_t)bp.chol_nsent,
+                                 (unsigned long long *)bp.chol_lpub, (size_t)bp.chol_nlpub, (unsigned long long *)bp.chol_Linv, (size_t)bp.chol_nblk};
+    mm_chol_init_body(a, blockIdx.x, CHOL_INIT_GRID);
 }
-// the right-hand side buffer becomes the output of the backward substitution: filled with the sentinel it polls on (the
-// forward substitution, inside the factorisation, has consumed it by then)
-__global__ __launch_bounds__(256) void chol_fill_x_batch_kernel(const mm_batch_prob *__restrict__ tab, const int32_t *__restrict__ list) {
-    const mm_batch_prob &bp = tab[list[blockIdx.y]];
-    unsigned long long *x = (unsigned long long *)bp.v;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < bp.chol_n; i += gridDim.x * 256) x[i] = BWD_SENTINEL;
-}
-
-
 // copy the band of the lower triangle into the upper triangle for the columns side 1 eliminates: (j, i) <- (i, j) for
 // i >= row0, 0 < i - j <= hb (callers of the two-ended path that only filled the lower triangle)
 __global__ __launch_bounds__(256) void chol_mirror_kernel(double *A, int n, int row0, int hb) {
@@ -2163,6 +2143,10 @@ int mm_chol_solve_gated(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int 
         g = TwGeom{n, nblk, bwb, nblk, 0, 0, nblk * NB - n};
     }
     ctx->chol_last_path = fused ? 1 : 0;
+    struct InitTokenReset {      // a pre-initialisation is good for exactly one solve
+        mm_ctx *c;
+        ~InitTokenReset() { c->chol_init_done = nullptr; }
+    } token_reset{ctx};
     int32_t *flags = (int32_t *)((char *)ytmp + mm_align_up((size_t)(n + NB) * sizeof(double), 256));
     double *contrib = (double *)((char *)flags + mm_align_up((2 * (2 * (size_t)nblk * (FUSED_MAX_BWB + 1) + 2 * nblk) + 64 + FUSED_MAX_BWB * FUSED_MAX_BWB) * sizeof(int32_t), 256));
     const int sides = g.b > 0 ? 2 : 1;
@@ -2183,9 +2167,14 @@ int mm_chol_solve_gated(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int 
         const size_t nflags = 1 + 2 * (2 * (size_t)nblk * (bwb + 1) + 2 * nblk) + (size_t)g.m * g.m;
         const double *b_fwd = nrhs >= 1 ? b : nullptr;  // the first right-hand side rides along
         double *spub = lpub + (size_t)nblk * LPUB_BLOCK;
-        MM_LAUNCH(ctx, "chol_init_kernel", chol_init_kernel, dim3(128), dim3(256), 0, info, flags, nflags,
-                  (unsigned long long *)contrib_bwd, (size_t)sides * nblk * (bwb + 1) * NB, (unsigned long long *)lpub,
-                  (size_t)nblk * (LPUB_BLOCK + 2 * NB * NB), (unsigned long long *)Linv, (size_t)nblk);
+        const mm_chol_init_args ia = {info, flags, nflags, (unsigned long long *)contrib_bwd, (size_t)sides * nblk * (bwb + 1) * NB,
+                                      (unsigned long long *)lpub, (size_t)nblk * (LPUB_BLOCK + 2 * NB * NB), (unsigned long long *)Linv,
+                                      (size_t)nblk};
+        if (ctx->chol_init_done == ws && ctx->chol_init_sides == sides) {
+            // (the caller's own kernel ran mm_chol_init_body with mm_chol_init_plan's arguments for this workspace)
+        } else {
+            MM_LAUNCH(ctx, "chol_init_kernel", chol_init_kernel, dim3(128), dim3(256), 0, ia);
+        }
         if (ctx->debug_abandon > 0) {      // test hook (mm_ctx_control): behave as if a workgroup had given up waiting
             --ctx->debug_abandon;
             const int32_t one = 1;
@@ -2224,14 +2213,13 @@ int mm_chol_solve_gated(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int 
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_LDS_BYTES));
                 ctx->attr_chol_bwd = true;
             }
-            // x (the output) and the contribution buffer start as the NaN sentinel the kernel polls on (the buffer of the
-            // first right-hand side was prepared by chol_init_kernel; an abort flag left by the factorisation makes the
-            // kernel leave at once -- info is -1 then anyway)
+            // the contribution buffer (and with it the words x is polled on) starts as the NaN sentinel (for the first
+            // right-hand side chol_init_kernel prepared it; an abort flag left by the factorisation makes the kernel
+            // leave at once -- info is -1 then anyway)
             if (c > 0) {
                 MM_HIP(ctx, hipMemsetAsync(flags, 0, sizeof(int32_t), ctx->stream));
                 MM_HIP(ctx, hipMemsetAsync(contrib_bwd, 0xFF, (size_t)sides * nblk * (bwb + 1) * NB * sizeof(double), ctx->stream));
             }
-            MM_HIP(ctx, hipMemsetAsync(bc, 0xFF, (size_t)n * sizeof(double), ctx->stream));
             MM_LAUNCH(ctx, "chol_band_bwd_kernel", chol_band_bwd_kernel, dim3(sides * (bwb >= 2 ? bwb : 1)), dim3(256),
                       BWD_LDS_BYTES, A, g, (const double *)Linv, (const double *)ytmp, bc, contrib_bwd, flags, info);
             continue;
@@ -2248,6 +2236,40 @@ int mm_chol_solve_gated(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int 
     }
     if (fused) chol_budget_mark(ctx);
     return MM_OK;
+}
+
+// see mm_common.h: the same geometry / layout lines as mm_chol_solve_gated(sym_mode 2, one right-hand side, not gated)
+bool mm_chol_init_plan(mm_ctx *ctx, int n, int half_bandwidth, int32_t *info, void *ws, size_t ws_bytes, mm_chol_init_args *out, int *sides_out, int *bwb_out) {
+    if (!ctx || !ws || !info || !out || n <= 0 || (n & 1) || half_bandwidth < 0 || ws_bytes < mm_chol_workspace_bytes(n)) return false;
+    const int nblk = (n + NB - 1) / NB;
+    long bwb_l = ((long)half_bandwidth + NB - 1) / NB;
+    const int bwb = bwb_l > nblk ? nblk : (int)bwb_l;
+    const bool fused = chol_fused_mode() > 0 && nblk >= 2 && bwb >= 1 && bwb <= FUSED_MAX_BWB && (long)NB * nblk * n < (1L << 31) &&
+                       !ctx->chol_avoid_fused;
+    if (!fused) return false;
+    TwGeom g = {n, nblk, bwb, nblk, 0, 0, nblk * NB - n};
+    if (chol_twisted_enabled() && nblk - bwb >= 4) {
+        g.m = bwb;
+        g.a = (nblk - g.m + 1) / 2;
+        g.b = nblk - g.m - g.a;
+    }
+    const int sides = g.b > 0 ? 2 : 1;
+    double *Linv = (double *)ws;
+    double *ytmp = (double *)((char *)ws + mm_align_up((size_t)nblk * NB * NB * sizeof(double), 256));
+    int32_t *flags = (int32_t *)((char *)ytmp + mm_align_up((size_t)(n + NB) * sizeof(double), 256));
+    double *contrib = (double *)((char *)flags + mm_align_up((2 * (2 * (size_t)nblk * (FUSED_MAX_BWB + 1) + 2 * nblk) + 64 + FUSED_MAX_BWB * FUSED_MAX_BWB) * sizeof(int32_t), 256));
+    double *contrib_bwd = (double *)((char *)contrib + mm_align_up(2 * (size_t)nblk * (FUSED_MAX_BWB + 1) * NB * sizeof(double), 256));
+    double *lpub = (double *)((char *)contrib_bwd + mm_align_up(2 * (size_t)nblk * (FUSED_MAX_BWB + 1) * NB * sizeof(double), 256));
+    *out = mm_chol_init_args{info, flags, 1 + 2 * (2 * (size_t)nblk * (bwb + 1) + 2 * nblk) + (size_t)g.m * g.m,
+                             (unsigned long long *)contrib_bwd, (size_t)sides * nblk * (bwb + 1) * NB, (unsigned long long *)lpub,
+                             (size_t)nblk * (LPUB_BLOCK + 2 * NB * NB), (unsigned long long *)Linv, (size_t)nblk};
+    if (sides_out) *sides_out = sides;
+    if (bwb_out) *bwb_out = bwb;
+    return true;
+}
+void mm_chol_init_done(mm_ctx *ctx, const void *ws, int sides) {
+    ctx->chol_init_done = ws;
+    ctx->chol_init_sides = sides;
 }
 
 // ---- batched factorisation + substitutions (mm_ba_trf_batched, trf.hip) --------------------------------------------------------
@@ -2303,7 +2325,6 @@ int mm_batch_chol(mm_ctx *ctx, const mm_batch_prob *tab, const int32_t *list, in
     const unsigned nl = (unsigned)n_list;
     MM_LAUNCH(ctx, "chol_init_kernel", chol_init_batch_kernel, dim3(CHOL_INIT_GRID, nl), dim3(256), 0, tab, list);
     MM_LAUNCH(ctx, "chol_band_fused_kernel", chol_band_fused_batch_kernel, dim3(max_g_chol, nl), dim3(256), FUSED_LDS_BYTES, tab, list);
-    MM_LAUNCH(ctx, "chol_fill_x_kernel", chol_fill_x_batch_kernel, dim3(4, nl), dim3(256), 0, tab, list);
     MM_LAUNCH(ctx, "chol_band_bwd_kernel", chol_band_bwd_batch_kernel, dim3(max_g_bwd, nl), dim3(256), BWD_LDS_BYTES, tab, list);
     ctx->chol_last_path = 1;
     return MM_OK;

@@ -58,6 +58,8 @@ struct mm_ctx {
     // mm_ba_trf_batched: device tables (batch records, per-round lists) and pinned staging + mailboxes, grown on demand
     void *batch_dev = nullptr, *batch_host = nullptr;
     size_t batch_dev_cap = 0, batch_host_cap = 0;
+    const void *chol_init_done = nullptr;      // chol workspace whose fills the caller's own kernel has done (mm_chol_init_done)
+    int chol_init_sides = 0;
     int batch_last = -1;      // problems the last mm_ba_trf_batched advanced in lock-step (0: all one by one), -1 none yet
 };
 
@@ -85,6 +87,42 @@ int mm_ba_damp_damping(mm_ctx *ctx, int F, int P, const double *B, const double 
 void mm_chol_release_budget(mm_ctx *ctx);
 // chol.hip internals used by the overlapped Schur + solve entry point (schur.hip)
 bool mm_chol_fused_eligible(int n, int half_bandwidth);
+// what chol_init_kernel fills before a single-launch factorisation (chol_init.h has the device function)
+struct mm_chol_init_args {
+    int32_t *info, *flags;
+    size_t nflags;
+    unsigned long long *sentinel_buf;
+    size_t nsent;
+    unsigned long long *lpub;
+    size_t nlpub;
+    unsigned long long *Linv;
+    size_t nblk;
+};
+// The arguments mm_chol_solve_sym(both triangles, one right-hand side) would hand to chol_init_kernel for this workspace;
+// false: that solve would not take the single-launch path.  A caller whose own kernel then runs mm_chol_init_body says so
+// with mm_chol_init_done right before the solve, which skips its launch (good for one solve on that workspace; if the
+// solve ends up on the launch-per-column path after all -- no budget -- the fills were wasted, nothing more).
+bool mm_chol_init_plan(mm_ctx *ctx, int n, int half_bandwidth, int32_t *info, void *ws, size_t ws_bytes, mm_chol_init_args *out, int *sides, int *bwb);
+void mm_chol_init_done(mm_ctx *ctx, const void *ws, int sides);
+// vec.hip / schur.hip: the damped blocks formed where they are consumed.  Bd = B + reg diag(si_c^2) is stored (the pair kernel
+// reads it), the points' C + reg diag(si_p^2) only ever exists in the registers that invert it.  gh2 != nullptr: first
+// attempt of an iteration, reg = max(trf_damping_value(gh2[0], d11[0], Delta), min_damping), recorded as {value, reg} in
+// damp_out; else reg = reg[0].
+struct mm_damp_spec {
+    const double *B, *C, *si;
+    const double *gh2, *d11;
+    double Delta, min_damping;
+    double *damp_out;
+    const double *reg;
+};
+// schur.hip: mm_ba_damp(_damping) + mm_ba_schur_solve(no slabs) with the damping, the zero fill of the band of S and the
+// factorisation's fills inside schur_prepare_kernel -- same arithmetic, three launches and a 72 MB fill less per solve at
+// the bench shape.  S must be zero outside the band tiles on entry and stays so.  Falls back to the separate calls (which
+// need Cd) when the problem has no pair list or the band is too wide for the single-launch factorisation.
+int mm_ba_schur_solve_damped(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, const double *pts, const mm_damp_spec *dmp,
+                             double *Bd, double *Cd, const double *gc, const double *gp, double *S, double *v, double *Cinv,
+                             int half_bandwidth, int32_t *info, void *ws_schur, size_t ws_schur_bytes, void *ws_chol,
+                             size_t ws_chol_bytes);
 int mm_chol_solve_gated(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int half_bandwidth, int32_t *info, void *ws,
                         size_t ws_bytes, const int32_t *slab_ready, int cams_per_slab, int n_cams, int sym_mode);
 

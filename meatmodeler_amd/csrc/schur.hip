@@ -10,6 +10,7 @@
 // evaluated from both of its rows — 2x the flops of a symmetric scheme, but the flops are free here: the kernel is bound
 // by the LDS atomic rate, and the global-atomic version it replaces ran 16x slower (profiles/r01_*).
 #include "ba_eval.h"
+#include "chol_init.h"
 
 namespace {
 
@@ -733,15 +734,54 @@ __global__ void schur_diag_fill_kernel(mm_ba_problem pb, const double *__restric
 // point_inverse + schur_diag_fill + cam_table in ONE launch (the banded build's three small preparation steps: each was a
 // launch of a few microseconds in front of every build).  Workgroup b: the points 256 b .., camera b's diagonal block if it
 // has no observation, the table rows of cameras 256 b .. (and its share of the finished-chunk counters).
+// What the prepare kernel does on behalf of its neighbours when mm_ba_trf hands the whole reduced solve to
+// mm_ba_schur_solve_damped: the damping (mm_ba_damp's arithmetic, fma(si^2, reg, .) on the diagonals), the zero fill of
+// the band tiles of S, and the fills of the single-launch factorisation.
+struct PrepExtra {
+    mm_damp_spec dmp;          // dmp.B == nullptr: Bd / Cd come damped from the caller
+    int zero_bwb;              // >= 0: zero the 64 x 64 tiles (bi, bj), |bi - bj| <= zero_bwb, of S here
+    int chol_init;             // run mm_chol_init_body(init)
+    mm_chol_init_args init;
+};
 __device__ __forceinline__ void schur_prepare_body(mm_ba_problem pb, const double *__restrict__ cams,
-                                                            const double *__restrict__ Bd, const double *__restrict__ Cd,
+                                                            double *__restrict__ Bd, const double *__restrict__ Cd,
                                                             const double *__restrict__ gc, double *__restrict__ Cinv,
                                                             double *__restrict__ S, double *__restrict__ v,
                                                             double *__restrict__ tab, int32_t *__restrict__ seg_done, bool lean,
-                                                            int32_t *__restrict__ desc /* [n_chunks][8] or NULL */, const unsigned bx, const unsigned gx) {
+                                                            int32_t *__restrict__ desc /* [n_chunks][8] or NULL */, const unsigned bx, const unsigned gx,
+                                                            const PrepExtra *ex = nullptr) {
     const int b = (int)bx, tid = threadIdx.x;
     for (int64_t k = (int64_t)b * 256 + tid; k < pb.n_seg; k += (int64_t)gx * 256) seg_done[k] = 0;
     if (desc) write_chunk_desc(pb, desc, (int64_t)b * 256 + tid, (int64_t)gx * 256);
+    const bool fold = ex && ex->dmp.B;
+    double reg = 0.0;
+    if (fold) {
+        if (ex->dmp.gh2) {
+            const double r = trf_damping_value(ex->dmp.gh2[0], ex->dmp.d11[0], ex->dmp.Delta);
+            reg = fmax(r, ex->dmp.min_damping);
+            if (b == 0 && tid == 0) {
+                ex->dmp.damp_out[0] = r;
+                ex->dmp.damp_out[1] = reg;
+            }
+        } else {
+            reg = ex->dmp.reg[0];
+        }
+    }
+    if (ex && ex->chol_init) mm_chol_init_body(ex->init, bx, gx);
+    const size_t n = (size_t)pb.F * 6;
+    if (ex && ex->zero_bwb >= 0) {
+        // row r of S: the columns of the tiles within the band, two at a time (n is even); the cameras' own 6 x 6 diagonal
+        // blocks are left to the workgroup of the camera (below), which may have to put Bd there
+        const int nblk = (int)((n + 63) / 64);
+        for (size_t r = bx; r < n; r += gx) {
+            const int bi = (int)(r >> 6);
+            const int lo = bi - ex->zero_bwb < 0 ? 0 : bi - ex->zero_bwb, hi = bi + ex->zero_bwb >= nblk ? nblk - 1 : bi + ex->zero_bwb;
+            const size_t c0 = (size_t)lo * 64, c1 = (size_t)(hi + 1) * 64 < n ? (size_t)(hi + 1) * 64 : n;
+            const size_t d0 = r / 6 * 6;
+            for (size_t c = c0 + 2 * (size_t)tid; c < c1; c += 512)
+                if (c < d0 || c >= d0 + 6) *reinterpret_cast<double2 *>(S + r * n + c) = double2{0.0, 0.0};
+        }
+    }
     const int f = b * 256 + tid;
     if (f < pb.F) {
         const double *c = cams + (size_t)f * 6;
@@ -758,15 +798,43 @@ __device__ __forceinline__ void schur_prepare_body(mm_ba_problem pb, const doubl
             t[10] = k.b1;
         }
     }
-    if (b < pb.F && pb.cam_ptr[b + 1] == pb.cam_ptr[b]) {      // camera b never appears in a segment: (Bd, gc) as they are
-        const size_t n = (size_t)pb.F * 6;
-        if (tid < 36) S[((size_t)b * 6 + tid / 6) * n + (size_t)b * 6 + tid % 6] = Bd[(size_t)b * 36 + tid];
-        if (tid < 6) v[(size_t)b * 6 + tid] = gc[(size_t)b * 6 + tid];
+    if (b < pb.F) {
+        const bool empty = pb.cam_ptr[b + 1] == pb.cam_ptr[b];      // camera b never appears in a segment: (Bd, gc) as they are
+        if (tid < 36) {
+            double bd;
+            if (fold) {
+                bd = ex->dmp.B[(size_t)b * 36 + tid];
+                if (tid % 7 == 0) {
+                    const double s = ex->dmp.si[(size_t)b * 6 + tid / 7];
+                    bd = fma(s * s, reg, bd);
+                }
+                Bd[(size_t)b * 36 + tid] = bd;
+            } else {
+                bd = Bd[(size_t)b * 36 + tid];
+            }
+            if (empty)
+                S[((size_t)b * 6 + tid / 6) * n + (size_t)b * 6 + tid % 6] = bd;
+            else if (ex && ex->zero_bwb >= 0)
+                S[((size_t)b * 6 + tid / 6) * n + (size_t)b * 6 + tid % 6] = 0.0;
+        }
+        if (empty && tid < 6) v[(size_t)b * 6 + tid] = gc[(size_t)b * 6 + tid];
     }
     const int p = b * 256 + tid;
     if (p < pb.P) {
-        const double *c = Cd + (size_t)p * 6;
-        const double a = c[0], bq = c[1], d = c[2], e = c[3], ff = c[4], g = c[5];
+        double a, bq, d, e, ff, g;
+        if (fold) {
+            const double *c = ex->dmp.C + (size_t)p * 6;
+            const double *sp = ex->dmp.si + n + (size_t)p * 3;
+            a = fma(sp[0] * sp[0], reg, c[0]);
+            bq = c[1];
+            d = c[2];
+            e = fma(sp[1] * sp[1], reg, c[3]);
+            ff = c[4];
+            g = fma(sp[2] * sp[2], reg, c[5]);
+        } else {
+            const double *c = Cd + (size_t)p * 6;
+            a = c[0], bq = c[1], d = c[2], e = c[3], ff = c[4], g = c[5];
+        }
         const double m00 = e * g - ff * ff, m01 = d * ff - bq * g, m02 = bq * ff - d * e;
         const double det = a * m00 + bq * m01 + d * m02;
         const double id = 1.0 / det;
@@ -780,12 +848,20 @@ __device__ __forceinline__ void schur_prepare_body(mm_ba_problem pb, const doubl
     }
 }
 __global__ __launch_bounds__(256) void schur_prepare_kernel(mm_ba_problem pb, const double *__restrict__ cams,
-                                                            const double *__restrict__ Bd, const double *__restrict__ Cd,
+                                                            double *__restrict__ Bd, const double *__restrict__ Cd,
                                                             const double *__restrict__ gc, double *__restrict__ Cinv,
                                                             double *__restrict__ S, double *__restrict__ v,
                                                             double *__restrict__ tab, int32_t *__restrict__ seg_done, bool lean,
                                                             int32_t *__restrict__ desc) {
     schur_prepare_body(pb, cams, Bd, Cd, gc, Cinv, S, v, tab, seg_done, lean, desc, blockIdx.x, gridDim.x);
+}
+__global__ __launch_bounds__(256) void schur_prepare_damped_kernel(mm_ba_problem pb, const double *__restrict__ cams,
+                                                                   double *__restrict__ Bd, const double *__restrict__ gc,
+                                                                   double *__restrict__ Cinv, double *__restrict__ S,
+                                                                   double *__restrict__ v, double *__restrict__ tab,
+                                                                   int32_t *__restrict__ seg_done, int32_t *__restrict__ desc,
+                                                                   PrepExtra ex) {
+    schur_prepare_body(pb, cams, Bd, nullptr, gc, Cinv, S, v, tab, seg_done, true, desc, blockIdx.x, gridDim.x, &ex);
 }
 __global__ __launch_bounds__(256) void schur_prepare_batch_kernel(const mm_batch_prob *__restrict__ tab, const int32_t *__restrict__ list) {
     const mm_batch_prob &bp = tab[list[blockIdx.y]];
@@ -924,8 +1000,8 @@ extern "C" int mm_ba_schur(mm_ctx *ctx, const mm_ba_problem *pb, const double *c
         const SchurWs w = carve_schur_ws(pb, ws);
         SlabSync none = {};
         const int prep = (pb->P + 255) / 256 > pb->F ? (pb->P + 255) / 256 : pb->F;
-        MM_LAUNCH(ctx, "schur_prepare_kernel", schur_prepare_kernel, dim3(prep), dim3(256), 0, *pb, cams, Bd, Cd, gc, Cinv, S, v,
-                  w.camtab, w.seg_done, schur_pairs_lean(), schur_pairs_lean() ? w.desc : (int32_t *)nullptr);
+        MM_LAUNCH(ctx, "schur_prepare_kernel", schur_prepare_kernel, dim3(prep), dim3(256), 0, *pb, cams, const_cast<double *>(Bd), Cd, gc,
+                  Cinv, S, v, w.camtab, w.seg_done, schur_pairs_lean(), schur_pairs_lean() ? w.desc : (int32_t *)nullptr);
         MM_LAUNCH_PAIRS(ctx, dim3((unsigned)wgs), *pb, (const double *)w.camtab, w.desc, pts, (const double *)Cinv, gp, w.partial, Bd, gc, S, v,
                         w.seg_done, none, 0u, (unsigned)wgs);
         return MM_OK;
@@ -1015,6 +1091,51 @@ extern "C" int mm_ba_schur_solve(mm_ctx *ctx, const mm_ba_problem *pb, const dou
                     w.seg_done, slabs, wg_first, wg_total);
     MM_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     return MM_OK;
+}
+
+// mm_common.h: damping + reduced system + solution for mm_ba_trf (one problem, not sharded)
+int mm_ba_schur_solve_damped(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, const double *pts, const mm_damp_spec *dmp,
+                             double *Bd, double *Cd, const double *gc, const double *gp, double *S, double *v, double *Cinv,
+                             int half_bandwidth, int32_t *info, void *ws_schur, size_t ws_schur_bytes, void *ws_chol,
+                             size_t ws_chol_bytes) {
+    if (!ctx) return MM_ERR_ARG;
+    if (!pb || !dmp || !info || !cams || !pts || !Bd || !gc || !gp || !S || !v || !Cinv || !dmp->B || !dmp->C || !dmp->si ||
+        (!dmp->gh2 && !dmp->reg) || (dmp->gh2 && (!dmp->d11 || !dmp->damp_out)))
+        return mm_fail(ctx, MM_ERR_ARG, "mm_ba_schur_solve_damped: bad argument");
+    const int n = pb->F * 6;
+    static const bool off = [] { const char *e = getenv("MM_SCHUR_FOLD"); return e && atoi(e) == 0; }();
+    mm_chol_init_args ia = {};
+    int sides = 0, bwb = 0;
+    const bool pairs_ok = pb->n_seg > 0 && pb->n_chunks > 0 && pb->seg_ids && pb->seg_chunk_ptr && pb->chunk_seg && pb->chunk_begin &&
+                          pb->chunk_end && pb->pair_o && pb->pair_o2 && pb->P > 0 && schur_pairs_lean();
+    const bool fold = !off && pairs_ok && ws_schur && ws_schur_bytes >= mm_ba_schur_workspace_bytes(pb) &&
+                      mm_chol_init_plan(ctx, n, half_bandwidth, info, ws_chol, ws_chol_bytes, &ia, &sides, &bwb);
+    if (!fold) {
+        if (!Cd) return mm_fail(ctx, MM_ERR_ARG, "mm_ba_schur_solve_damped: the separate calls need Cd");
+        int rc = dmp->gh2 ? mm_ba_damp_damping(ctx, pb->F, pb->P, dmp->B, dmp->C, dmp->si, dmp->gh2, dmp->d11, dmp->Delta, dmp->min_damping,
+                                                dmp->damp_out, Bd, Cd)
+                          : mm_ba_damp(ctx, pb->F, pb->P, dmp->B, dmp->C, dmp->si, dmp->reg, Bd, Cd);
+        if (rc) return rc;
+        return mm_ba_schur_solve(ctx, pb, cams, pts, Bd, Cd, gc, gp, S, v, Cinv, half_bandwidth, info, ws_schur, ws_schur_bytes, ws_chol,
+                                 ws_chol_bytes, 0, 0, nullptr, nullptr);
+    }
+    const SchurWs w = carve_schur_ws(pb, ws_schur);
+    PrepExtra ex = {};
+    ex.dmp = *dmp;
+    ex.zero_bwb = bwb;
+    ex.chol_init = 1;
+    ex.init = ia;
+    const int prep = (pb->P + 255) / 256 > pb->F ? (pb->P + 255) / 256 : pb->F;
+    MM_LAUNCH(ctx, "schur_prepare_kernel", schur_prepare_damped_kernel, dim3(prep), dim3(256), 0, *pb, cams, Bd, gc, Cinv, S, v, w.camtab,
+              w.seg_done, w.desc, ex);
+    const int64_t wgs = (pb->n_chunks + SP_WAVES - 1) / SP_WAVES;
+    SlabSync none = {};
+    MM_LAUNCH_PAIRS(ctx, dim3((unsigned)wgs), *pb, (const double *)w.camtab, w.desc, pts, (const double *)Cinv, gp, w.partial,
+                    (const double *)Bd, gc, S, v, w.seg_done, none, 0u, (unsigned)wgs);
+    mm_chol_init_done(ctx, ws_chol, sides);
+    const int rc = mm_chol_solve_sym(ctx, S, n, v, half_bandwidth, 1, info, ws_chol, ws_chol_bytes);
+    mm_chol_init_done(ctx, nullptr, 0);
+    return rc;
 }
 
 // ---- batched build of the reduced camera systems (mm_ba_trf_batched, trf.hip) ------------------------------------------------

@@ -458,16 +458,23 @@ static int trf_run(mm_ctx *ctx, const mm_ba_problem *pb, double *cams, double *p
         };
         bool damping_known = false;
         for (int attempt = 0; attempt < 6 && !solved; ++attempt) {
-            if (!damping_known) {
-                TRF_CALL(mm_ba_damp_damping(ctx, F, P, t.B, t.C, t.si, t.r0 + 2, t.d11 + 2, Delta, min_damping, t.damp, t.Bd, t.Cd));
-                damping_known = true;
-            } else {
-                TRF_CALL(mm_ba_damp(ctx, F, P, t.B, t.C, t.si, reg_eff, t.Bd, t.Cd));
-            }
             if (!dist) {
-                TRF_CALL(mm_ba_schur_solve(ctx, pb, cams_of(x), pts_of(x), t.Bd, t.Cd, cams_of(t.g), pts_of(t.g), t.S, t.v, t.Cinv, half_bw,
-                                           t.info, t.ws_schur, t.ws_schur_b, t.ws_chol, t.ws_chol_b, 0, 0, nullptr, nullptr));
+                // damping, reduced system, factorisation and both substitutions: four launches (schur.hip)
+                mm_damp_spec dmp = {t.B, t.C, t.si, nullptr, nullptr, Delta, min_damping, t.damp, reg_eff};
+                if (!damping_known) {
+                    dmp.gh2 = t.r0 + 2;
+                    dmp.d11 = t.d11 + 2;
+                    damping_known = true;
+                }
+                TRF_CALL(mm_ba_schur_solve_damped(ctx, pb, cams_of(x), pts_of(x), &dmp, t.Bd, t.Cd, cams_of(t.g), pts_of(t.g), t.S, t.v, t.Cinv,
+                                                  half_bw, t.info, t.ws_schur, t.ws_schur_b, t.ws_chol, t.ws_chol_b));
             } else {
+                if (!damping_known) {
+                    TRF_CALL(mm_ba_damp_damping(ctx, F, P, t.B, t.C, t.si, t.r0 + 2, t.d11 + 2, Delta, min_damping, t.damp, t.Bd, t.Cd));
+                    damping_known = true;
+                } else {
+                    TRF_CALL(mm_ba_damp(ctx, F, P, t.B, t.C, t.si, reg_eff, t.Bd, t.Cd));
+                }
                 // every rank's S / v hold its points' share plus the FULL blockdiag(Bd) / g_c: sum, then remove the
                 // duplicates.  Band exchange (decided by the caller from global quantities): n (hb + 1) + n doubles in one
                 // collective instead of the dense matrix; only the lower band then holds the sum.
