@@ -315,27 +315,7 @@ __global__ __launch_bounds__(256) void ba_jvp_dots_kernel(mm_ba_problem pb, cons
                                                           const double *__restrict__ wp, double *__restrict__ out,
                                                           const double *__restrict__ other, double *__restrict__ partial) { ba_jvp_dots_body(pb, cams, pts, ctab, wc, wp, out, other, partial, blockIdx.x, gridDim.x); }
 
-// adds the per-workgroup partials of ba_jvp_dots_kernel in index order (one workgroup; a shared arrival counter costs
-// ~11 ns per workgroup on 6 k workgroups -- more than this launch.  Round 4 re-measured it with the 2048-workgroup cap:
-// finishing the sums in the kernel's last-arriving workgroup made the product 45 us instead of 27 + 5 for this launch.)
-__device__ __forceinline__ void jvp_rows_body(const double *__restrict__ partial, unsigned n_wg, double *__restrict__ rows, const unsigned bx, const unsigned gx) {
-    __shared__ double sm[(256 / 64) * 2];
-    double acc[2] = {0.0, 0.0};
-    for (unsigned g = threadIdx.x; g < n_wg; g += 256) {
-        acc[0] += partial[2 * (size_t)g];
-        acc[1] += partial[2 * (size_t)g + 1];
-    }
-    block_sum_n<2, 256>(acc, sm);
-    if (threadIdx.x == 0) {
-        rows[0] = 0.0;
-        rows[1] = acc[0];
-        rows[2] = acc[0];
-        rows[3] = 0.0;
-        rows[4] = acc[1];
-        rows[5] = acc[1];
-    }
-}
-__global__ __launch_bounds__(256) void jvp_rows_kernel(const double *__restrict__ partial, unsigned n_wg, double *__restrict__ rows) { jvp_rows_body(partial, n_wg, rows, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(256) void jvp_rows_kernel(const double *__restrict__ partial, unsigned n_wg, double *__restrict__ rows) { (void)jvp_rows_body(partial, n_wg, rows, blockIdx.x, gridDim.x); }
 
 // ---- back-substitution: dp = Cinv (gp - sum_o Jp_o^T (Jc_o dc[f_o])) ------------------------------------------------
 __global__ __launch_bounds__(256) void ba_backsub_kernel(mm_ba_problem pb, const double *__restrict__ cams,
@@ -571,6 +551,20 @@ int mm_cam_coef_table(mm_ctx *ctx, const double *cams, int F, const void **tab_o
     *tab_out = ctx->cam_tab;
     return MM_OK;
 }
+int mm_cam_table_adopt(mm_ctx *ctx, const double *cams, int F, void **tab_out) {
+    if (F > ctx->cam_tab_cap) {
+        if (ctx->cam_tab) (void)hipFree(ctx->cam_tab);
+        ctx->cam_tab = nullptr;
+        ctx->cam_tab_cap = 0;
+        const int cap = F < 1024 ? 1024 : F + F / 2;
+        MM_HIP(ctx, hipMalloc(&ctx->cam_tab, (size_t)cap * sizeof(CamCoef)));
+        ctx->cam_tab_cap = cap;
+    }
+    ctx->cam_tab_for = cams;
+    ctx->cam_tab_F = F;
+    *tab_out = ctx->cam_tab;
+    return MM_OK;
+}
 void mm_cam_table_hold(mm_ctx *ctx, bool on) {
     ctx->cam_tab_hold = on;
     ctx->cam_tab_for = nullptr;      // (also when switching ON: an earlier, un-held call may have left the address of a
@@ -679,6 +673,11 @@ int mm_ba_jvp_dots(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, con
     MM_CAM_TABLE(ctx, pb, cams);
     MM_LAUNCH(ctx, "ba_jvp_kernel", ba_jvp_dots_kernel, dim3(n_wg), dim3(256), 0, *pb, cams, pts, ctab, wc, wp, out, other,
               (double *)((char *)ws + 256));
+    if (ctx->jvp_rows_deferred) {      // (mm_ba_trf: the consumer's own kernel adds the partials -- mm_trf_rows_step2d)
+        ctx->jvp_partial = (const double *)((char *)ws + 256);
+        ctx->jvp_n_wg = n_wg;
+        return MM_OK;
+    }
     MM_LAUNCH(ctx, "jvp_rows_kernel", jvp_rows_kernel, dim3(1), dim3(256), 0, (const double *)((char *)ws + 256), n_wg, rows);
     return MM_OK;
 }

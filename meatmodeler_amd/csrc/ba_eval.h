@@ -272,4 +272,27 @@ __device__ __forceinline__ double block_sum(double v, double *sm) {
     return t;
 }
 
+// adds the per-workgroup partials of ba_jvp_dots_kernel in index order (one workgroup; a shared arrival counter costs
+// ~11 ns per workgroup on 6 k workgroups -- more than this launch.  Round 4 re-measured it with the 2048-workgroup cap:
+// finishing the sums in the kernel's last-arriving workgroup made the product 45 us instead of 27 + 5 for this launch.)
+// (returns the two sums, valid in thread 0)
+__device__ __forceinline__ double2 jvp_rows_body(const double *__restrict__ partial, unsigned n_wg, double *__restrict__ rows, const unsigned bx, const unsigned gx) {
+    __shared__ double sm[(256 / 64) * 2];
+    double acc[2] = {0.0, 0.0};
+    for (unsigned g = threadIdx.x; g < n_wg; g += 256) {
+        acc[0] += partial[2 * (size_t)g];
+        acc[1] += partial[2 * (size_t)g + 1];
+    }
+    block_sum_n<2, 256>(acc, sm);
+    if (threadIdx.x == 0) {
+        rows[0] = 0.0;
+        rows[1] = acc[0];
+        rows[2] = acc[0];
+        rows[3] = 0.0;
+        rows[4] = acc[1];
+        rows[5] = acc[1];
+    }
+    return make_double2(acc[0], acc[1]);
+}
+
 }  // namespace

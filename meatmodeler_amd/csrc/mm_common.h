@@ -58,6 +58,9 @@ struct mm_ctx {
     // mm_ba_trf_batched: device tables (batch records, per-round lists) and pinned staging + mailboxes, grown on demand
     void *batch_dev = nullptr, *batch_host = nullptr;
     size_t batch_dev_cap = 0, batch_host_cap = 0;
+    bool jvp_rows_deferred = false;      // mm_ba_jvp_dots leaves the final sum of its partials to the caller's next kernel ...
+    const double *jvp_partial = nullptr;      // ... which finds them here
+    unsigned jvp_n_wg = 0;
     const void *chol_init_done = nullptr;      // chol workspace whose fills the caller's own kernel has done (mm_chol_init_done)
     int chol_init_sides = 0;
     int batch_last = -1;      // problems the last mm_ba_trf_batched advanced in lock-step (0: all one by one), -1 none yet
@@ -80,6 +83,20 @@ void mm_cam_table_invalidate(mm_ctx *ctx);          // ... the caller says the v
 int mm_ba_residual_publish(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, const double *pts, void *ws,
                            size_t ws_bytes, double *board, int cost_slot, int count, void *host_board, unsigned long long seq);
 
+// vec.hip: pass 0 of the loop (gh = g / si, ...) preceded by mm_ba_scale_update(first = 0) on the same elements, and pass 5
+// (x_new = x + h0 s1 + h1 s2) which also leaves the cameras' rotation coefficients at x_new in `ctab` (mm_cam_table_adopt)
+int mm_trf_fused0_scaled(mm_ctx *ctx, const double *g, double *si, const double *B, const double *C, double *gh, double *ghs, int64_t n,
+                         int64_t split, double *out, void *ws, size_t ws_bytes);
+int mm_trf_fused5_coef(mm_ctx *ctx, const double *x, const double *s1, const double *s2, double *x_new, const double *h01, int64_t n,
+                       int64_t split, void *ctab, int F);
+// vec.hip: mm_trf_step2d preceded by the final sum of the partials of the Jacobian product before it (what jvp_rows_kernel does,
+// same tree; rows receives them as mm_ba_jvp_dots would have written them)
+int mm_trf_rows_step2d(mm_ctx *ctx, const double *partial, unsigned n_wg, double *rows, const double *r0, const double *d11,
+                       const double *r1, const double *r2, const double *r3, const double *reg, const int32_t *info, double Delta,
+                       double *board);
+// ba.hip: the context's coefficient table buffer for F cameras, to be filled by the caller's own kernel for the cameras at
+// `cams` (then held like a table mm_cam_coef_table computed itself; needs mm_cam_table_hold(on))
+int mm_cam_table_adopt(mm_ctx *ctx, const double *cams, int F, void **tab_out);
 // vec.hip: mm_trf_damping + mm_ba_damp in one launch
 int mm_ba_damp_damping(mm_ctx *ctx, int F, int P, const double *B, const double *C, const double *scale_inv, const double *gh2,
                        const double *d11, double Delta, double min_damping, double *damp_out, double *Bd, double *Cd);

@@ -420,7 +420,9 @@ static int trf_run(mm_ctx *ctx, const mm_ba_problem *pb, double *cams, double *p
         ++n_log;
     };
     for (;;) {
-        {
+        if (!dist && iteration > 0) {      // (the running maximum of the Jacobian scaling rides with the pass: idempotent)
+            TRF_CALL(mm_trf_fused0_scaled(ctx, t.g, t.si, t.B, t.C, t.gh, t.ghs, n, nc, t.r0, t.ws_md, t.ws_md_b));
+        } else {
             const double *in[2] = {t.g, t.si};
             double *outv[2] = {t.gh, t.ghs};
             TRF_CALL(mm_trf_fused(ctx, 0, in, outv, nullptr, 0, 0, n, nc, t.r0, t.ws_md, t.ws_md_b));
@@ -436,14 +438,26 @@ static int trf_run(mm_ctx *ctx, const mm_ba_problem *pb, double *cams, double *p
         // (the damping of the iteration is computed by the first damped-blocks sweep itself: mm_trf_damping's formula, one
         // launch less; a retry with raised damping reads damp[1] as the host left it)
         double *reg_eff = t.damp + 1;
-        bool solved = false;
+        bool solved = false, rows_pending = false;
         auto trial = [&](double Delta_) -> int {
-            TRF_CALL(mm_trf_step2d(ctx, t.r0, t.d11, t.r1, t.r2, t.r3, t.bs, reg_eff, t.info, Delta_, t.board));
-            const double *in[3] = {x, t.s1, t.s2};
-            double *outv[1] = {x_new};
-            const double *sc[1] = {t.board};
-            TRF_CALL(mm_trf_fused(ctx, 5, in, outv, sc, 0, 0, n, nc, nullptr, t.ws_md, t.ws_md_b));
-            mm_cam_table_invalidate(ctx);      // x_new has new contents
+            if (rows_pending) {      // first trial of the attempt: the sums of J s2 are still per-workgroup partials
+                rows_pending = false;
+                TRF_CALL(mm_trf_rows_step2d(ctx, ctx->jvp_partial, ctx->jvp_n_wg, t.bs, t.r0, t.d11, t.r1, t.r2, t.r3, reg_eff, t.info, Delta_,
+                                            t.board));
+            } else {
+                TRF_CALL(mm_trf_step2d(ctx, t.r0, t.d11, t.r1, t.r2, t.r3, t.bs, reg_eff, t.info, Delta_, t.board));
+            }
+            if (F > 0 && !dist) {      // x_new and its cameras' rotation coefficients in one launch
+                void *ctab = nullptr;
+                TRF_CALL(mm_cam_table_adopt(ctx, cams_of(x_new), (int)F, &ctab));
+                TRF_CALL(mm_trf_fused5_coef(ctx, x, t.s1, t.s2, x_new, t.board, n, nc, ctab, (int)F));
+            } else {
+                const double *in[3] = {x, t.s1, t.s2};
+                double *outv[1] = {x_new};
+                const double *sc[1] = {t.board};
+                TRF_CALL(mm_trf_fused(ctx, 5, in, outv, sc, 0, 0, n, nc, nullptr, t.ws_md, t.ws_md_b));
+                mm_cam_table_invalidate(ctx);      // x_new has new contents
+            }
             if (spin && !dist) {      // the residual's final sum and the hand-over to the host mailbox are one launch
                 const unsigned long long seq = ++ctx->host_board_seq;
                 TRF_CALL(mm_ba_residual_publish(ctx, pb, cams_of(x_new), pts_of(x_new), t.ws_res, t.ws_res_b, t.board, 14, 16,
@@ -523,7 +537,13 @@ static int trf_run(mm_ctx *ctx, const mm_ba_problem *pb, double *cams, double *p
                 const double *sc[1] = {t.r2 + 2};
                 TRF_CALL(mm_trf_fused(ctx, 3, in, outv, sc, 0, 0, n, nc, t.r3, t.ws_md, t.ws_md_b));
             }
-            TRF_CALL(mm_ba_jvp_dots(ctx, pb, cams_of(x), pts_of(x), cams_of(t.s2), pts_of(t.s2), t.Jq2, t.u1, t.bs, t.ws_jvp, t.ws_jvp_b));
+            ctx->jvp_rows_deferred = !dist && P > 0 && pb->O > 0;      // (sharded: the sums are exchanged first)
+            {
+                const int rc_ = mm_ba_jvp_dots(ctx, pb, cams_of(x), pts_of(x), cams_of(t.s2), pts_of(t.s2), t.Jq2, t.u1, t.bs, t.ws_jvp, t.ws_jvp_b);
+                rows_pending = ctx->jvp_rows_deferred;
+                ctx->jvp_rows_deferred = false;
+                if (rc_) return rc_;
+            }
             // (the step inner products and the two of J s2 travel together: the Jacobian product only needs s2)
             TRF_CALL(exchange({{t.r3, 0}, {t.r3 + 3, 0}, {t.r3 + 6, 0}, {t.r3 + 9, 0}, {t.r3 + 12, 0}, {t.bs, 1}, {t.bs + 3, 1}}));
             TRF_CALL(trial(Delta));   // enqueued before the host knows whether the factorisation succeeded
@@ -583,7 +603,7 @@ static int trf_run(mm_ctx *ctx, const mm_ba_problem *pb, double *cams, double *p
             cost = cost_new;
             TRF_CALL(normal_eq(x));
             ++njev;
-            TRF_CALL(mm_ba_scale_update(ctx, F, P, t.B, t.C, t.si, 0));
+            if (dist) TRF_CALL(mm_ba_scale_update(ctx, F, P, t.B, t.C, t.si, 0));      // (else: with the next pass 0)
         } else {
             step_norm = 0;
             actual = 0;

@@ -138,6 +138,8 @@ struct FusedArgs {
     double *out[3];
     const double *scalar[2];   // device scalars
     double h0, h1;             // host scalars
+    void *ctab;                // OP 7: rotation coefficients of the F cameras at the head of out[0] (ba_eval.h's CamCoef rows)
+    int F;
 };
 
 // OP 0: gh = g / si, ghs = gh / si;                      sums: gh.gh           (+ max |g| in the extra slot)
@@ -147,8 +149,15 @@ struct FusedArgs {
 // OP 4: x_new = x + h0 * s1 + h1 * s2;                   no sums
 // OP 5: the same with (h0, h1) = scalar[0][0..1] read from device memory (mm_trf_step2d); h1 == 0 skips s2 entirely
 //       (a one-dimensional subspace leaves s2 = w / |w| with |w| = 0 undefined)
+// OP 6: OP 0 preceded by mm_ba_scale_update(first = 0) on the same elements: si = max(sqrt(diag), si) from the camera
+//       blocks in[2] [F,6,6] / packed point blocks in[3] [P,6], stored to out[2] (= in[1]) -- idempotent, so an iteration
+//       that kept its blocks (rejected step) leaves si as it is
+// OP 7: OP 5, and the cameras' rotation coefficients at x_new into `ctab` (what cam_coef_kernel would compute from out[0]:
+//       the workgroups recompute those 3 F elements with the same fma chain)
 template <int OP>
 struct FusedTraits;
+template <> struct FusedTraits<6> { static constexpr int K = 1; };
+template <> struct FusedTraits<7> { static constexpr int K = 0; };
 template <> struct FusedTraits<0> { static constexpr int K = 1; };
 template <> struct FusedTraits<1> { static constexpr int K = 2; };
 template <> struct FusedTraits<2> { static constexpr int K = 1; };
@@ -156,10 +165,32 @@ template <> struct FusedTraits<3> { static constexpr int K = 5; };
 template <> struct FusedTraits<4> { static constexpr int K = 0; };
 template <> struct FusedTraits<5> { static constexpr int K = 0; };
 
+__device__ __forceinline__ double scaled_si(const FusedArgs &a, int64_t i, int64_t split, double si_old) {
+    double d;
+    if (i < split) {
+        const int64_t f = i / 6, e = i % 6;
+        d = a.in[2][f * 36 + e * 7];
+    } else {
+        const int64_t j = i - split, q = j / 3, e = j % 3;
+        d = a.in[3][q * 6 + (e == 0 ? 0 : (e == 1 ? 3 : 5))];
+    }
+    return fmax(sqrt(d), si_old);
+}
+// x + h0 s1 (+ h1 s2): explicit fmas, the cameras' rotation coefficients (OP 7) are computed from the same chain
+__device__ __forceinline__ double step_elem(double x, double s1, double s2, double h0, double h1) {
+    double v = fma(h0, s1, x);
+    if (h1 != 0.0) v = fma(h1, s2, v);
+    return v;
+}
 template <int OP>
 __device__ __forceinline__ void fused_elem(const FusedArgs &a, int64_t i, int64_t split, double (&p)[FV_MAXK], double &mx) {
-    if constexpr (OP == 0) {
-        const double g = a.in[0][i], si = a.in[1][i];
+    if constexpr (OP == 0 || OP == 6) {
+        const double g = a.in[0][i];
+        double si = a.in[1][i];
+        if constexpr (OP == 6) {
+            si = scaled_si(a, i, split, si);
+            a.out[2][i] = si;
+        }
         const double gh = g / si;
         a.out[0][i] = gh;
         a.out[1][i] = gh / si;
@@ -194,9 +225,7 @@ __device__ __forceinline__ void fused_elem(const FusedArgs &a, int64_t i, int64_
         a.out[0][i] = a.in[0][i] + a.h0 * a.in[1][i] + a.h1 * a.in[2][i];
     } else {
         const double h0 = a.scalar[0][0], h1 = a.scalar[0][1];
-        double v = a.in[0][i] + h0 * a.in[1][i];
-        if (h1 != 0.0) v += h1 * a.in[2][i];
-        a.out[0][i] = v;
+        a.out[0][i] = step_elem(a.in[0][i], a.in[1][i], h1 != 0.0 ? a.in[2][i] : 0.0, h0, h1);
     }
 }
 
@@ -207,8 +236,14 @@ __device__ __forceinline__ double2 ld2(const double *p, int64_t i) { return *rei
 __device__ __forceinline__ void st2(double *p, int64_t i, double x, double y) { *reinterpret_cast<double2 *>(p + i) = make_double2(x, y); }
 template <int OP>
 __device__ __forceinline__ void fused_elem2(const FusedArgs &a, int64_t i, int64_t split, double (&p)[FV_MAXK], double &mx) {
-    if constexpr (OP == 0) {
-        const double2 g = ld2(a.in[0], i), si = ld2(a.in[1], i);
+    if constexpr (OP == 0 || OP == 6) {
+        const double2 g = ld2(a.in[0], i);
+        double2 si = ld2(a.in[1], i);
+        if constexpr (OP == 6) {
+            si.x = scaled_si(a, i, split, si.x);
+            si.y = scaled_si(a, i + 1, split, si.y);
+            st2(a.out[2], i, si.x, si.y);
+        }
         const double gh0 = g.x / si.x, gh1 = g.y / si.y;
         st2(a.out[0], i, gh0, gh1);
         st2(a.out[1], i, gh0 / si.x, gh1 / si.y);
@@ -253,13 +288,9 @@ __device__ __forceinline__ void fused_elem2(const FusedArgs &a, int64_t i, int64
     } else {
         const double h0 = a.scalar[0][0], h1 = a.scalar[0][1];
         const double2 x = ld2(a.in[0], i), s1 = ld2(a.in[1], i);
-        double v0 = x.x + h0 * s1.x, v1 = x.y + h0 * s1.y;
-        if (h1 != 0.0) {
-            const double2 s2 = ld2(a.in[2], i);
-            v0 += h1 * s2.x;
-            v1 += h1 * s2.y;
-        }
-        st2(a.out[0], i, v0, v1);
+        double2 s2 = make_double2(0.0, 0.0);
+        if (h1 != 0.0) s2 = ld2(a.in[2], i);
+        st2(a.out[0], i, step_elem(x.x, s1.x, s2.x, h0, h1), step_elem(x.y, s1.y, s2.y, h0, h1));
     }
 }
 
@@ -298,6 +329,16 @@ __device__ __forceinline__ void fused_vec_body(const FusedArgs &args, int64_t n,
                 fused_elem<OP>(args, j, split, p, mx);
                 add(j, p, mx);
             }
+        }
+    }
+    if constexpr (OP == 7) {
+        const double h0 = args.scalar[0][0], h1 = args.scalar[0][1];
+        for (int64_t f = (int64_t)bx * MD_THREADS + threadIdx.x; f < args.F; f += (int64_t)gx * MD_THREADS) {
+            double r[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                r[k] = step_elem(args.in[0][f * 6 + k], args.in[1][f * 6 + k], h1 != 0.0 ? args.in[2][f * 6 + k] : 0.0, h0, h1);
+            ((CamCoef *)args.ctab)[f] = cam_coef_of(r);
         }
     }
     if constexpr (K == 0) return;
@@ -463,6 +504,41 @@ extern "C" int mm_trf_fused(mm_ctx *ctx, int op, const double *const *in, double
 }
 
 
+// mm_common.h: the two passes of mm_ba_trf's loop that absorb a neighbouring small launch
+int mm_trf_fused0_scaled(mm_ctx *ctx, const double *g, double *si, const double *B, const double *C, double *gh, double *ghs, int64_t n,
+                         int64_t split, double *out, void *ws, size_t ws_bytes) {
+    if (!ws || ws_bytes < mm_multi_dot_workspace_bytes() || ((uintptr_t)ws & 255))
+        return mm_fail(ctx, MM_ERR_WORKSPACE, "mm_trf_fused: workspace too small or misaligned");
+    if (n <= 0 || (split % 6) || ((n - split) % 3)) return mm_fail(ctx, MM_ERR_ARG, "mm_trf_fused0_scaled: bad argument");
+    FusedArgs a = {};
+    a.in[0] = g; a.in[1] = si; a.in[2] = B; a.in[3] = C;
+    a.out[0] = gh; a.out[1] = ghs; a.out[2] = si;
+    FusedArgs al = a;      // (the block arrays are gathered element by element: only the vectors need the alignment)
+    al.in[2] = al.in[3] = nullptr;
+    bool vec2 = (split & 1) == 0;
+    for (int q = 0; q < 6; ++q) vec2 = vec2 && (((uintptr_t)al.in[q]) & 15) == 0;
+    for (int q = 0; q < 3; ++q) vec2 = vec2 && (((uintptr_t)al.out[q]) & 15) == 0;
+    MM_LAUNCH(ctx, "fused_vec_kernel", fused_vec_kernel<6>, dim3(fused_grid_of(n)), dim3(MD_THREADS), 0, a, n, split,
+              (double *)((char *)ws + 256), (unsigned *)ws, out, vec2);
+    return MM_OK;
+}
+int mm_trf_fused5_coef(mm_ctx *ctx, const double *x, const double *s1, const double *s2, double *x_new, const double *h01, int64_t n,
+                       int64_t split, void *ctab, int F) {
+    if (n <= 0 || !ctab || (int64_t)F * 6 > n) return mm_fail(ctx, MM_ERR_ARG, "mm_trf_fused5_coef: bad argument");
+    FusedArgs a = {};
+    a.in[0] = x; a.in[1] = s1; a.in[2] = s2;
+    a.out[0] = x_new;
+    a.scalar[0] = h01;
+    a.ctab = ctab;
+    a.F = F;
+    bool vec2 = (split & 1) == 0;
+    for (int q = 0; q < 6; ++q) vec2 = vec2 && (((uintptr_t)a.in[q]) & 15) == 0;
+    for (int q = 0; q < 3; ++q) vec2 = vec2 && (((uintptr_t)a.out[q]) & 15) == 0;
+    MM_LAUNCH(ctx, "fused_vec_kernel", fused_vec_kernel<7>, dim3(fused_grid_of(n)), dim3(MD_THREADS), 0, a, n, split, (double *)nullptr,
+              (unsigned *)nullptr, (double *)nullptr, vec2);
+    return MM_OK;
+}
+
 // ---- block glue of the trust-region driver ---------------------------------------------------------------------------------
 // scale_inv (SciPy x_scale='jac', common.py:598-610): si_i = sqrt((J^T J)_ii) from the diagonals of the camera blocks
 // B [F,6,6] and of the packed point blocks C [P,6] (xx,xy,xz,yy,yz,zz); first call: zeros become 1, later calls: running
@@ -625,13 +701,13 @@ __device__ __forceinline__ double model_2d(double b00, double b01, double b11, d
     return 0.5 * (p0 * (b00 * p0 + b01 * p1) + p1 * (b01 * p0 + b11 * p1)) + (g0 * p0 + g1 * p1);
 }
 
-__device__ __forceinline__ void trf_step2d_body(const Step2dIn &in, double Delta, double *__restrict__ board) {
+__device__ __forceinline__ void trf_step2d_body(const Step2dIn &in, double Delta, double *__restrict__ board, const double bs2, const double bs5) {
     const int lane = threadIdx.x;
     const double gh2 = in.r0[2], gmax = in.r0[5], d11 = in.d11[2], gn2 = in.r1[5], wn2 = in.r2[2];
     double n11 = in.r3[2], n12 = in.r3[5], n22 = in.r3[8], g2 = in.r3[11];
     const double xx = in.r3[14];
-    const double u1Jq2 = in.bs[2];
-    double b22 = in.bs[5];
+    const double u1Jq2 = bs2;
+    double b22 = bs5;
     const double gh_norm = sqrt(gh2);
     const double b11 = d11 / gh2;
     double b12 = u1Jq2 / gh_norm;
@@ -729,14 +805,27 @@ __device__ __forceinline__ void trf_step2d_body(const Step2dIn &in, double Delta
     }
 }
 __global__ __launch_bounds__(64) void trf_step2d_kernel(Step2dIn in, double Delta, double *__restrict__ board) {
-    trf_step2d_body(in, Delta, board);
+    trf_step2d_body(in, Delta, board, in.bs[2], in.bs[5]);
+}
+// the same behind the final sum of the second Jacobian product's partials (jvp_rows_kernel's tree: 256 threads), one launch
+// instead of two on the chain to the trial point; the sums reach the first wave through shared memory
+__global__ __launch_bounds__(256) void trf_rows_step2d_kernel(const double *__restrict__ partial, unsigned n_wg, double *__restrict__ rows,
+                                                              Step2dIn in, double Delta, double *__restrict__ board) {
+    __shared__ double s_bs[2];
+    const double2 t = jvp_rows_body(partial, n_wg, rows, 0, 1);
+    if (threadIdx.x == 0) {
+        s_bs[0] = t.x;
+        s_bs[1] = t.y;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) trf_step2d_body(in, Delta, board, s_bs[0], s_bs[1]);
 }
 __global__ __launch_bounds__(64) void trf_step2d_batch_kernel(const mm_batch_prob *__restrict__ tab, const int32_t *__restrict__ list,
                                                               const mm_batch_dyn *__restrict__ dyn) {
     const int pid = list[blockIdx.x];
     const mm_batch_prob &bp = tab[pid];
     const Step2dIn in = {bp.r0, bp.d11, bp.r1, bp.r2, bp.r3, bp.bs, bp.damp + 1, bp.info};
-    trf_step2d_body(in, dyn[pid].Delta, bp.board);
+    trf_step2d_body(in, dyn[pid].Delta, bp.board, in.bs[2], in.bs[5]);
 }
 }  // namespace
 
@@ -773,6 +862,15 @@ int mm_batch_accept(mm_ctx *ctx, const mm_batch_prob *tab, const int32_t *list, 
 int mm_batch_step2d(mm_ctx *ctx, const mm_batch_prob *tab, const int32_t *list, int n_list, const mm_batch_dyn *dyn) {
     if (n_list <= 0) return MM_OK;
     MM_LAUNCH(ctx, "trf_step2d_kernel", trf_step2d_batch_kernel, dim3((unsigned)n_list), dim3(64), 0, tab, list, dyn);
+    return MM_OK;
+}
+
+int mm_trf_rows_step2d(mm_ctx *ctx, const double *partial, unsigned n_wg, double *rows, const double *r0, const double *d11,
+                       const double *r1, const double *r2, const double *r3, const double *reg, const int32_t *info, double Delta,
+                       double *board) {
+    if (!partial || !n_wg || !rows || !(Delta >= 0.0)) return mm_fail(ctx, MM_ERR_ARG, "mm_trf_rows_step2d: bad argument");
+    Step2dIn in = {r0, d11, r1, r2, r3, rows, reg, info};
+    MM_LAUNCH(ctx, "trf_step2d_kernel", trf_rows_step2d_kernel, dim3(1), dim3(256), 0, partial, n_wg, rows, in, Delta, board);
     return MM_OK;
 }
 
