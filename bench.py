@@ -63,7 +63,11 @@ def parse():
                          "per window on --ba-streams streams (default: at the C5 window shape -- 75 k points per window -- both are "
                          "bound by the same total kernel work, 912 vs 927 ms; the lock-step solve wins on smaller problems)")
     ap.add_argument("--verbose", type=int, default=0)
-    ap.add_argument("--no-profile", action="store_true", help="no per-launch HIP events in the timed steps")
+    ap.add_argument("--no-profile", action="store_true", help="no per-launch HIP events at all (no kernel table, no roofline)")
+    ap.add_argument("--profile-timed", choices=("dominant", "big"), default="dominant",
+                    help="HIP events inside the TIMED steps: around the launches of the dominant kernel only (default; every "
+                         "bracketed launch costs the stream a bubble) or around every launch of >= 64 workgroups (rounds 1-3: "
+                         "inflates a BA iteration by ~10 %%)")
     return ap.parse_args()
 
 
@@ -215,9 +219,26 @@ def main():
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
-    # level 2: HIP events around every launch of >= 64 workgroups (the sweeps); the Cholesky's chains of 1..45-workgroup
-    # launches are left alone — bracketing all ~26k launches of a step with events inflates the step by ~25 %
-    ctx.profile(0 if a.no_profile else 2)
+    # One extra, untimed step with events on EVERY launch gives the complete per-kernel table and names the dominant kernel
+    # (largest share of device time).  Inside the timed steps only THAT kernel's launches are bracketed by events (level 3):
+    # every bracketed launch costs the stream a bubble, and bracketing all launches of >= 64 workgroups (level 2, what
+    # rounds 1-3 did; --profile-timed big) made a BA iteration 1.36 ms where it is 1.24 ms unobserved.
+    prof_full = {}
+    if not a.no_profile:
+        ctx.profile(1)
+        step()
+        prof_full = ctx.profile_report()
+        ctx.profile(0)
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+    dominant_name = max(prof_full.items(), key=lambda kv: kv[1][1])[0] if prof_full else None
+    if a.no_profile or dominant_name is None:
+        ctx.profile(0)
+    elif a.profile_timed == "big":
+        ctx.profile(2)
+    else:
+        ctx.profile(3, only=dominant_name)
     timers = {}
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -229,13 +250,6 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = ctx.profile_report()
     ctx.profile(0)
-    # one extra, untimed step with events on EVERY launch for the complete per-kernel table
-    prof_full = {}
-    if not a.no_profile:
-        ctx.profile(1)
-        step()
-        prof_full = ctx.profile_report()
-        ctx.profile(0)
     STAGES = ("detect", "match", "link", "triangulate", "ba", "ba_solve", "ba_windows")
     el = torch.tensor([elapsed] + [timers.get(k, 0.0) for k in STAGES],
                       dtype=torch.float64, device=dev)
@@ -299,10 +313,15 @@ def main():
         if fl:
             row["mfma_f64_TFLOPs"] = fl / (per * 1e-3) / 1e12
         kernels.append(row)
-    # Dominant kernel = largest share of device time.  The fully profiled extra step sees every launch; the timed steps
-    # only bracket launches of >= 64 workgroups, so a micro-launch kernel (Cholesky chain) takes its average from the
-    # extra step and says so.
+    # Dominant kernel = largest share of device time in the fully profiled extra step; its roofline figures come from the
+    # events around its launches inside the timed steps.  The other rows of "kernels" are the extra step's.
     timed = {k["kernel"]: k for k in kernels}
+    for k in kernels:
+        k["events_in_timed_region"] = True
+    for k in kernels_full:
+        if k["kernel"] not in timed:
+            kernels.append(dict(k, events_in_timed_region=False))
+    kernels.sort(key=lambda k: -k["ms_per_step"])
     dom_full = kernels_full[0] if kernels_full else (kernels[0] if kernels else None)
     roofline = None
     if dom_full is not None:

@@ -74,9 +74,12 @@ int mm_timer_elapsed_ms(mm_ctx *ctx, void *timer, float *ms_out); /* (sync) */
 void mm_timer_destroy(mm_ctx *ctx, void *timer);
 /* Per-launch profiling: on = 1 brackets every kernel launched through this context with two HIP events on the
  * context's stream (~2.5 us of device time and ~5 us of host time per launch); on = 2 only launches of >= 64
- * workgroups, leaving the micro-launch chains of the Cholesky untouched; on = 0 stops collecting.  mm_profile_report (sync) writes one line per kernel name, "name launches total_ms\n", and
- * returns the number of lines.  Enabling clears earlier records. */
+ * workgroups, leaving the micro-launch chains of the Cholesky untouched; on = 3 only launches of the kernel named by
+ * mm_profile_select (the name mm_profile_report prints; what bench.py's timed steps use: every bracketed launch costs the
+ * stream a bubble, ~10 % of a BA iteration with on = 2); on = 0 stops collecting.  mm_profile_report (sync) writes one line
+ * per kernel name, "name launches total_ms\n", and returns the number of lines.  Enabling clears earlier records. */
 int mm_profile_enable(mm_ctx *ctx, int on);
+int mm_profile_select(mm_ctx *ctx, const char *name);
 int mm_profile_report(mm_ctx *ctx, char *buf, size_t buf_len);
 
 /* ---- a-2: brute-force Hamming 2-NN + ratio test ----------------------------------------------

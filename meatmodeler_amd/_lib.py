@@ -75,6 +75,7 @@ SIGNATURES = {
     "mm_timer_destroy": (None, [vp, vp]),
     "mm_profile_enable": (C.c_int, [vp, C.c_int]),
     "mm_profile_report": (C.c_int, [vp, C.c_char_p, C.c_size_t]),
+    "mm_profile_select": (C.c_int, [vp, C.c_char_p]),
     "mm_bf_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "mm_bf_knn2_batched": (C.c_int, [vp, vp, vp, C.c_int, C.c_size_t, vp, vp, C.c_int, C.c_size_t, C.c_int, vp, vp,
                                      vp, C.c_size_t]),
@@ -203,8 +204,10 @@ class Context:
             self.check(r, "mm_ctx_control")
         return r
 
-    def profile(self, level):
-        """0 off, 1 every launch, 2 launches of >= 64 workgroups only."""
+    def profile(self, level, only=None):
+        """0 off, 1 every launch, 2 launches of >= 64 workgroups only, 3 launches of the kernel named `only`."""
+        if only is not None:
+            self.check(lib.mm_profile_select(self.h, only.encode()), "mm_profile_select")
         self.check(lib.mm_profile_enable(self.h, int(level)), "mm_profile_enable")
 
     def profile_report(self):

@@ -17,7 +17,9 @@ struct mm_ctx {
     hipStream_t stream;
     char err[512];
     // optional per-launch HIP-event profiling (mm_profile_*): bench.py's live roofline measurement
-    int prof = 0;  // 0 off, 1 every launch, 2 only launches of >= 64 workgroups (micro-launch chains stay untouched)
+    int prof = 0;  // 0 off, 1 every launch, 2 only launches of >= 64 workgroups (micro-launch chains stay untouched),
+                   // 3 only the kernel named by mm_profile_select (the timed region of bench.py: one kernel's events, not all)
+    char prof_only[64] = {0};
     std::vector<mm_prof_rec> recs;
     std::vector<hipEvent_t> pool;
     // second stream + fork/join events for overlapping the reduced-system build with its factorisation (lazily created)
@@ -225,7 +227,8 @@ static inline hipEvent_t mm_prof_event(mm_ctx *c) {
     do {                                                                                               \
         hipEvent_t ea_ = nullptr, eb_ = nullptr;                                                       \
         const dim3 g_ = (grid);                                                                        \
-        const bool p_ = (ctx)->prof == 1 || ((ctx)->prof == 2 && (size_t)g_.x * g_.y * g_.z >= 64);    \
+        const bool p_ = (ctx)->prof == 1 || ((ctx)->prof == 2 && (size_t)g_.x * g_.y * g_.z >= 64) || \
+                        ((ctx)->prof == 3 && strcmp(name, (ctx)->prof_only) == 0);                      \
         if (p_) {                                                                                      \
             ea_ = mm_prof_event(ctx);                                                                  \
             eb_ = mm_prof_event(ctx);                                                                  \

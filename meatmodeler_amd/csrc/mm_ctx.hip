@@ -55,6 +55,12 @@ int mm_profile_enable(mm_ctx *ctx, int on) {
     return MM_OK;
 }
 
+int mm_profile_select(mm_ctx *ctx, const char *name) {
+    if (!ctx || !name || strlen(name) >= sizeof(ctx->prof_only)) return MM_ERR_ARG;
+    strcpy(ctx->prof_only, name);
+    return MM_OK;
+}
+
 int mm_profile_report(mm_ctx *ctx, char *buf, size_t buf_len) {
     if (!ctx || !buf || buf_len < 64) return MM_ERR_ARG;
     MM_HIP(ctx, hipStreamSynchronize(ctx->stream));

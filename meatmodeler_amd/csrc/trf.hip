@@ -256,6 +256,7 @@ extern "C" size_t mm_ba_trf_dist_workspace_bytes(const mm_ba_problem *pb, int ha
 
 static int trf_run(mm_ctx *ctx, const mm_ba_problem *pb, double *cams, double *pts, const mm_trf_params *prm, mm_trf_report *rep,
                    mm_trf_row *log, int log_cap, void *ws, size_t ws_bytes, const mm_dist *dist) {
+    const auto t_enter = std::chrono::steady_clock::now();
     if (!ctx) return MM_ERR_ARG;
     if (!pb || !cams || !pts || !prm || !rep || pb->F <= 0 || pb->P < 0 || pb->O < 0 || !pb->K || log_cap < 0 || (log_cap > 0 && !log))
         return mm_fail(ctx, MM_ERR_ARG, "mm_ba_trf: bad argument");
@@ -419,7 +420,17 @@ static int trf_run(mm_ctx *ctx, const mm_ba_problem *pb, double *cams, double *p
         if (n_log < log_cap) log[n_log] = mm_trf_row{it, nf, c, red, stepn, opt};
         ++n_log;
     };
+    static const bool timing = getenv("MM_TRF_TIMING") && atoi(getenv("MM_TRF_TIMING")) > 0;      // wall clock per iteration on stderr
+    const auto t_loop = std::chrono::steady_clock::now();
+    auto t_iter = t_loop;
+    if (timing) fprintf(stderr, "mm_ba_trf timing: prologue %.1f us\n", std::chrono::duration<double, std::micro>(t_loop - t_enter).count());
     for (;;) {
+        if (timing && iteration > 0) {
+            const auto now = std::chrono::steady_clock::now();
+            fprintf(stderr, "mm_ba_trf timing: iteration %d %.1f us (nfev %d)\n", iteration - 1,
+                    std::chrono::duration<double, std::micro>(now - t_iter).count(), nfev);
+            t_iter = now;
+        }
         if (!dist && iteration > 0) {      // (the running maximum of the Jacobian scaling rides with the pass: idempotent)
             TRF_CALL(mm_trf_fused0_scaled(ctx, t.g, t.si, t.B, t.C, t.gh, t.ghs, n, nc, t.r0, t.ws_md, t.ws_md_b));
         } else {
@@ -614,6 +625,8 @@ static int trf_run(mm_ctx *ctx, const mm_ba_problem *pb, double *cams, double *p
     MM_HIP(ctx, hipMemcpyAsync(cams, x, (size_t)nc * sizeof(double), hipMemcpyDeviceToDevice, st));
     if (P) MM_HIP(ctx, hipMemcpyAsync(pts, x + nc, (size_t)3 * P * sizeof(double), hipMemcpyDeviceToDevice, st));
     MM_HIP(ctx, hipStreamSynchronize(st));
+    if (timing) fprintf(stderr, "mm_ba_trf timing: total %.1f us, %d iterations\n",
+                        std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_enter).count(), iteration);
     rep->cost = cost;
     rep->optimality = g_norm;
     rep->nfev = nfev;
