@@ -686,6 +686,39 @@ def test_trf_fused_passes_vs_torch():
     np.testing.assert_allclose(xn.cpu().numpy(), (x + 0.3 * s1 - 1.7 * s2).cpu().numpy(), rtol=1e-15, atol=1e-15)
 
 
+def test_profile_levels_select_what_is_bracketed():
+    """mm_profile_enable: 1 = every launch, 3 = only the kernel named by mm_profile_select (what bench.py's timed steps
+    use: one kernel's events instead of a bubble behind every launch), 0 = nothing."""
+    ctx = default_context()
+    rng = np.random.default_rng(5)
+    n = 100_000
+    a, b = dev(rng.normal(size=n)), dev(rng.uniform(0.5, 2.0, size=n))
+    pr = synth.make_ba_problem(4, 10, 3, seed=1)
+    pb = ops.BADevice(pr["K"], pr["fi"], pr["pi"], pr["obs"], 4, 10, DEV)
+    md = ops.MultiDot(DEV)
+
+    def work():
+        pb.trf_fused(0, [a, b], [torch.empty_like(a), torch.empty_like(a)], split=600)
+        md([(a, b)], 600)
+
+    try:
+        ctx.profile(1)
+        work()
+        every = ctx.profile_report()
+        assert every["fused_vec_kernel"][0] == 1 and every["multi_dot_kernel"][0] == 1
+        assert every["fused_vec_kernel"][1] > 0
+        ctx.profile(3, only="multi_dot_kernel")
+        work()
+        work()
+        only = ctx.profile_report()
+        assert list(only) == ["multi_dot_kernel"] and only["multi_dot_kernel"][0] == 2
+        ctx.profile(0)
+        work()
+        assert ctx.profile_report() == only          # nothing new is recorded while profiling is off
+    finally:
+        ctx.profile(0)
+
+
 def test_vector_kernels_on_empty_vectors():
     md = ops.MultiDot(DEV)
     e = torch.empty(0, dtype=torch.float64, device=DEV)
