@@ -29,6 +29,15 @@ constexpr int EDGE = 31;
 // products of operands below 2^23 whose result fits 32 bits: the full-rate 24-bit multiplier (v_mul_lo_u32 and
 // v_mad_u64_u32, which the compiler picks for `int * int`, issue at a quarter of the rate)
 // (as instructions: the intrinsics are widened back to 32-bit multiplies wherever the compiler cannot prove the operand range)
+// 16 bytes from a 4-byte aligned address (image rows start 64-byte aligned, tiles and patches at multiples of 4 pixels): global
+// memory takes a dwordx4 at dword alignment; the type tells the compiler so
+struct __attribute__((packed, aligned(4))) U4A4 {
+    uint32_t x, y, z, w;
+};
+__device__ __forceinline__ uint4 load16_a4(const uint8_t *p) {
+    const U4A4 v = *reinterpret_cast<const U4A4 *>(p);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ int mul24(int a, int b) {
     int d;
     asm("v_mul_u32_u24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
@@ -402,6 +411,7 @@ __global__ __launch_bounds__(PY_THREADS) void orb_pyramid_kernel(OrbGeom g, cons
         const uint8_t *src = level_ptr(g, imgs, ws, ch.src, b, ps);
         const int nw4 = (NX[0] - pax) / 4 + 1, nrow = NY[0] - ploy + 1;
         const unsigned inv20 = ((1u << 20) + nw4 - 1) / nw4;      // e / nw4 for e < 2^20 / nw4 (e < 74 * 70)
+        // (tried in round 4: 16-byte loads here, as in the FAST tile and the descriptor patch -- 2.62 vs 2.61 ms, nothing)
         for (int e = tid; e < nrow * nw4; e += PY_THREADS) {
             const int r = (int)(((unsigned)e * inv20) >> 20), c4 = e - r * nw4;
             const int x = pax + 4 * c4;
@@ -561,15 +571,28 @@ __global__ __launch_bounds__(256) void orb_fast_kernel(OrbGeom g, const uint8_t 
     const uint8_t *img = level_ptr(g, imgs, ws, l, b, pitch);
     // pixel tile: rows oy-4 .. oy+67, columns ox-7 .. ox+72 (ox-7 is a multiple of 4)
     const int bx = ox - 7, by = oy - 4;
-    for (int e = threadIdx.x; e < FP_H * (FP_W / 4); e += 256) {
-        const int r = e / (FP_W / 4), c4 = (e % (FP_W / 4)) * 4;
-        const int y = by + r, x = bx + c4;
-        uint32_t v = 0;
-        if (y < h && x + 3 < pitch) v = *reinterpret_cast<const uint32_t *>(img + (size_t)y * pitch + x);
-        *reinterpret_cast<uint32_t *>(&P[r][c4]) = v;
+    // (16 bytes per lane and access: 360 instead of 1440 loads per tile; the address is only 4-byte aligned, which global
+    // loads accept; a piece that would cross the pitch falls back to words)
+    static_assert(FP_W % 16 == 0, "pixel tile rows are whole 16-byte pieces");
+    for (int e = threadIdx.x; e < FP_H * (FP_W / 16); e += 256) {
+        const int r = e / (FP_W / 16), c16 = (e % (FP_W / 16)) * 16;
+        const int y = by + r, x = bx + c16;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (y < h) {
+            const uint8_t *src = img + (size_t)y * pitch + x;
+            if (x + 15 < pitch) {
+                v = load16_a4(src);
+            } else {
+                if (x + 3 < pitch) v.x = *reinterpret_cast<const uint32_t *>(src);
+                if (x + 7 < pitch) v.y = *reinterpret_cast<const uint32_t *>(src + 4);
+                if (x + 11 < pitch) v.z = *reinterpret_cast<const uint32_t *>(src + 8);
+            }
+        }
+        *reinterpret_cast<uint4 *>(&P[r][c16]) = v;
     }
-    static_assert(sizeof(Sc) % 4 == 0, "score tile is cleared by words");
-    for (int e = threadIdx.x; e < (int)sizeof(Sc) / 4; e += 256) reinterpret_cast<uint32_t *>(&Sc[0][0])[e] = 0;
+    static_assert(sizeof(Sc) % 4 == 0, "score tile is cleared by 16-byte pieces and a tail of words");
+    for (int e = threadIdx.x; e < (int)sizeof(Sc) / 16; e += 256) reinterpret_cast<uint4 *>(&Sc[0][0])[e] = make_uint4(0, 0, 0, 0);
+    if (threadIdx.x < (int)(sizeof(Sc) % 16) / 4) reinterpret_cast<uint32_t *>(&Sc[0][0])[(sizeof(Sc) / 16) * 4 + threadIdx.x] = 0;
     // A cascade over the score positions, each stage compacting its survivors into an LDS list so that the next one runs
     // on full waves (in one pass, a wave pays for the most expensive stage as soon as one of its 64 pixels gets there):
     //   1. every position: the exact compass pre-test (any 9 contiguous ring pixels contain two of the four compass
@@ -962,7 +985,8 @@ __global__ __launch_bounds__(64 * DESC_WAVES, 5) void orb_describe_kernel(OrbGeo
     // patch column c sits at byte c + sh), the horizontally blurred patch TRANSPOSED as u16 (so that the vertical pass
     // reads its seven taps as four words), and the blurred 33 x 33 patch, which reuses the raw patch's storage.
     constexpr int RW = 12, HT = 40, BLP = 36;
-    __shared__ uint32_t raw_w[DESC_WAVES][DP * RW];
+    __shared__ __attribute__((aligned(16))) uint32_t raw_w[DESC_WAVES][DP * RW];
+    static_assert(RW == 12 && (DP * RW * 4) % 16 == 0, "a patch row is three 16-byte pieces");
     __shared__ uint16_t hbt[DESC_WAVES][36 * HT];
     static_assert(DP * RW * 4 >= DB * BLP, "blurred patch reuses the raw patch");
     const int b = blockIdx.y;
@@ -988,8 +1012,10 @@ __global__ __launch_bounds__(64 * DESC_WAVES, 5) void orb_describe_kernel(OrbGeo
     // A wave describes every n_waves-th key point of its frame.  The patch of the NEXT key point is requested (into
     // registers) before the current one is processed: the two dependent global accesses (key point record, then 39 row
     // segments scattered over a pyramid level) were 36 % of a wave's life and more on clips that do not fit the caches.
-    constexpr int NPRE = (DP * 11 + 63) / 64;
-    uint32_t pre[NPRE];
+    // (16 bytes per lane and load: 39 rows x 3 pieces = 117 loads per patch instead of 429 words; an LDS row is 12 words, the
+    // twelfth -- bytes 44 .. 47 -- is never read but lies inside the image row: key points keep 31 pixels from the border)
+    constexpr int NPRE = (DP * 3 + 63) / 64;
+    uint4 pre[NPRE];
     int x = 0, y = 0;
     auto request = [&](int k) {
         const size_t oo = (size_t)b * g.cap_out + k;
@@ -999,11 +1025,11 @@ __global__ __launch_bounds__(64 * DESC_WAVES, 5) void orb_describe_kernel(OrbGeo
         int pitch;
         const uint8_t *img = level_ptr(g, imgs, ws, l, b, pitch);
         const int xa = (x - 19) & ~3;
-        // 11 words per row cover bytes 0 .. 43 >= 38 + 3; key points keep 31 pixels from the border: inside the row
+        // 11 words per row cover bytes 0 .. 43 >= 38 + 3
 #pragma unroll
         for (int j = 0; j < NPRE; ++j) {
-            const int e = min(lane + 64 * j, DP * 11 - 1), r = e / 11, wc = e % 11;
-            pre[j] = *reinterpret_cast<const uint32_t *>(img + (size_t)(y - 19 + r) * pitch + xa + 4 * wc);
+            const int e = min(lane + 64 * j, DP * 3 - 1), r = e / 3, pc = e % 3;
+            pre[j] = load16_a4(img + (size_t)(y - 19 + r) * pitch + xa + 16 * pc);
         }
     };
     request(kp);
@@ -1018,7 +1044,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES, 5) void orb_describe_kernel(OrbGeo
 #pragma unroll
     for (int j = 0; j < NPRE; ++j) {
         const int e = lane + 64 * j;
-        if (e < DP * 11) rw[(e / 11) * RW + e % 11] = pre[j];
+        if (e < DP * 3) *reinterpret_cast<uint4 *>(rw + (e / 3) * RW + 4 * (e % 3)) = pre[j];
     }
     wave_sync();
     const int kp_next = kp + n_waves;
