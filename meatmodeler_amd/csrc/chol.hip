@@ -342,6 +342,17 @@ __device__ unsigned long long g_chol_trace[128][32];
 #define MM_TRACE_ROW(r, e) do { } while (0)
 #endif
 
+// Delay injection (causal profiling of the chain: tools/dev/chol_delay.sh builds one variant per site): ~1 us of s_sleep at
+// ONE site; if the factorisation takes 28 x 1 us longer the site is on the critical path, if not it has slack.
+#ifdef MM_CHOL_DELAY_SITE
+#define MM_DELAY(site) do { if (MM_CHOL_DELAY_SITE == (site)) __builtin_amdgcn_s_sleep(40); } while (0)
+#define MM_DELAY_IF(site, cond) do { if (MM_CHOL_DELAY_SITE == (site) && (cond)) __builtin_amdgcn_s_sleep(40); } while (0)
+#else
+#define MM_DELAY(site) do { } while (0)
+#define MM_DELAY_IF(site, cond) do { } while (0)
+#endif
+
+
 // L (in place, lower triangle of M), the reciprocal pivots R and the four 16 x 16 diagonal blocks of X = L^-1 (the
 // rest of X zeroed); 256 threads.  The diagonal inverses ride on an idle wave while wave 0 factors the next panel.
 // `pub` streams the block out while it is being factored (the fused kernel): pub.l(k), called by wave 2 as soon as
@@ -399,6 +410,7 @@ __device__ __forceinline__ void factor_block_lds(double (*M)[NB + 1], double (*X
     __syncthreads();
     volatile int *panels = &s_panels, *xzero = &s_xzero;
     if (w == 0) {
+        MM_DELAY(7);
         panel16_factor_dpp<0>(M, X, R);
         wave_lds_sync();
         lds_counter_set(panels, 1);
@@ -419,6 +431,7 @@ __device__ __forceinline__ void factor_block_lds(double (*M)[NB + 1], double (*X
         panel16_factor_dpp<3>(M, X, R);
         wave_lds_sync();
         lds_counter_wait(xzero, 3);      // (long true: X is cleared while the first panel is factored)
+        MM_DELAY(1);
         inv_diag16(M, X, R, 3);          // the one inverse on the chain: half a microsecond
         pub.x(3);
     } else {
@@ -435,6 +448,7 @@ __device__ __forceinline__ void factor_block_lds(double (*M)[NB + 1], double (*X
         } else if (w == 2) {
             for (int k = 0; k < 3; ++k) {
                 lds_counter_wait(panels, k + 1);
+                MM_DELAY(5);
                 pub.l(k);
             }
         } else {
@@ -920,6 +934,12 @@ __device__ __forceinline__ void trsm_finish(double (*As)[LDT], const double (*Xd
 constexpr unsigned long long STAGE_SENTINEL = ~0ull;
 constexpr int LPUB_BLOCK = 6 * 256;      // doubles per diagonal block: (1,0) (2,0) (3,0) | (2,1) (3,1) | (3,2), 16 x 16 row-major
 __device__ __forceinline__ constexpr int lpub_first(int k) { return k == 0 ? 0 : (k == 1 ? 3 : 5); }
+// doubles of the polled hand-over region (what chol_init fills with the sentinel): per block row the pieces of the diagonal
+// block, the blocks (r, r - 1) and (r, r - 2), and -- per side -- the blocks of the offsets 3 .. bwb (round 4: every
+// off-diagonal block reaches the owner of its right-hand neighbour panel by panel, not through a flag and its copy in A)
+__host__ __device__ __forceinline__ size_t chol_nlpub(int nblk, int bwb) {
+    return (size_t)nblk * (LPUB_BLOCK + (size_t)(2 + 2 * (bwb > 2 ? bwb - 2 : 0)) * NB * NB);
+}
 
 // Poll one word per lane (lanes may watch different words; `watch` = lanes that count) until none is the sentinel, with FOUR
 // polls in flight: a poll that has to return before the next one is issued samples the word once per trip to memory
@@ -1049,7 +1069,7 @@ template <int MODE, bool SYRK>
 __device__ __forceinline__ bool finish_off_block_streamed(double (*As)[LDT], double (*Bs)[LDT], double (*Xd)[16][17],
                                                           const double *lpub_c, const double *Linv_c, int32_t *abort_flag,
                                                           const TileRef &t, double4_t (&acc)[2][2], double *spub_blk,
-                                                          int trace_row = -1) {
+                                                          int trace_row = -1, int delay_tag = 0) {
     const int lane = lane_id(), row0 = 16 * wave_id();
     StageRegs<0> g0;
     StageRegs<1> g1;
@@ -1073,6 +1093,15 @@ __device__ __forceinline__ bool finish_off_block_streamed(double (*As)[LDT], dou
     }
     ok = stage_wait<3>(g3, lpub_c, Linv_c, lane, abort_flag) && ok;
     MM_TRACE_ROW(trace_row, 2);
+    if constexpr (SYRK) MM_DELAY(2);
+    else MM_DELAY(4);
+    MM_DELAY_IF(41, (delay_tag & 3) == 1);      // d = 2 owners
+    MM_DELAY_IF(42, (delay_tag & 3) == 2);      // d >= 3 owners
+    MM_DELAY_IF(43, (delay_tag & 3) && (delay_tag & 4));      // d >= 2, block of M x M
+    MM_DELAY_IF(44, (delay_tag & 3) && !(delay_tag & 4));     // d >= 2, outside M x M
+#ifdef MM_CHOL_DELAY_SITE
+    MM_DELAY_IF(MM_CHOL_DELAY_SITE, MM_CHOL_DELAY_SITE >= 52 && MM_CHOL_DELAY_SITE < 70 && (delay_tag >> 4) == MM_CHOL_DELAY_SITE - 50);      // offset d = site - 50
+#endif
     stage_compute<MODE, 3>(g3, As, Bs, Xd, t, spub_blk, lane, row0);
     MM_TRACE_ROW(trace_row, 3);
     const bool all_ok = !__syncthreads_or(!ok);
@@ -1302,6 +1331,8 @@ __device__ __forceinline__ void chol_band_fused_body(double *A, TwGeom g, double
     // blocks go through A and flags only)
     auto spubp = [&](int s, int blk) { return spub + (size_t)nat(s, blk) * NB * NB; };
     auto spub2p = [&](int s, int blk) { return spub + ((size_t)nblk + nat(s, blk)) * NB * NB; };
+    // block (r, r - dd), dd = 3 .. bwb, of side s: per side (the rows of M exist on both), in that side's orientation
+    auto opubp = [&](int s, int r_, int dd) { return spub + (2 * (size_t)nblk + ((size_t)s * nblk + r_) * (bwb - 2) + (dd - 3)) * NB * NB; };
     // Entries of A (and of the right-hand side) may still be under construction by a concurrent launch on another
     // stream (the reduced camera system, built in camera slabs).  The entries (i, j) and (j, i), i >= j, are written
     // together with camera row i / 6: a tile is complete when the slabs of its LARGER natural block index are
@@ -1357,6 +1388,7 @@ __device__ __forceinline__ void chol_band_fused_body(double *A, TwGeom g, double
         __syncthreads();
         MM_ACC_FOREACH(As[row][col] = ((t.rv(row) && t.cv(col)) ? ld_shared<MODE>(t.at(row, col)) : 0.0) - acc[a][b][i];)
         __syncthreads();
+        MM_DELAY(9);
         store_tile_shared16(As, t);
         wg_publish<MODE>(pflag(i, jj));
         return;
@@ -1374,6 +1406,32 @@ __device__ __forceinline__ void chol_band_fused_body(double *A, TwGeom g, double
         period = bwb - d + 1;
     }
     if (d >= 2) {
+        // L_rc y_c for the forward substitution.  y_c leaves the head of row c at the END of its row, ~12 us after L_cc: an
+        // owner that waits for it before it turns to its next block is late for that block's solve when its blocks follow
+        // each other column by column (offset bwb: ONE workgroup, offset bwb - 1: two) -- and these are the blocks the whole
+        // anti-diagonal of owners below waits for (measured by delay injection, tools/dev/chol_delay.sh: the row heads
+        // have slack, the owners of the far offsets do not).  Those owners take the product of block (r, c) with y_c AFTER
+        // their next block is out, from its copy in A; the head of row r needs it bwb - 1 columns later at the earliest.
+#ifndef MM_CHOL_DEFER_MAXP
+#define MM_CHOL_DEFER_MAXP 2
+#endif
+        const bool defer_fwd = period <= MM_CHOL_DEFER_MAXP && d >= period + 2;
+        int pend_c = -1;
+        auto fwd_part = [&](int rr, int cc, bool reload) -> bool {
+            if (!wg_wait<MODE>(yflag(fb, cc), nullptr, abort_flag, &s_ok)) return false;
+            if (reload) load_tile_shared<MODE>(As, tile_ref(A, g, side, rr, cc));      // (the barrier of wg_wait covers the last use of As)
+            if (threadIdx.x < NB) {
+                const long vi = vec_index(g, side, cc, threadIdx.x);
+                ys[threadIdx.x] = (vi >= 0 && vi < n) ? ld_shared<MODE>(y + vi) : 0.0;
+            }
+            __syncthreads();
+            const double tv = tile_matvec<LDT>(As, ys);
+            // a row of M is finished by side 0: hand the vector over in ITS element order
+            const int row = threadIdx.x >> 2, at = (side == 1 && rr >= ncols) ? NB - 1 - row : row;
+            if ((threadIdx.x & 3) == 0) st_shared<MODE>(cslot(side, rr, d) + at, tv);
+            wg_publish<MODE>(cflag(fb, rr, d));
+            return true;
+        };
         for (int c = j; c + d < nrows && c < ncols; c += period) {
             const int r = c + d;
             const TileRef t = tile_ref(A, g, side, r, c);
@@ -1381,8 +1439,35 @@ __device__ __forceinline__ void chol_band_fused_body(double *A, TwGeom g, double
             // a block of M x M: the columns of T and of the other end have been taken care of by its pre-accumulator
             const bool in_m = tw && side == 0 && c >= g.a;
             for (int k = max(in_m ? g.a : 0, r - bwb); k < c; ++k) {
-                // (c, k): for k = c - 1 the block of row head c -- its flag is raised late, off that workgroup's critical
-                // path; the data itself is polled
+                if (k == c - 1) {
+                    // The newest column.  Its two blocks -- (r, c - 1), solved by the owner of the next offset behind the
+                    // factorisation of L_{c-1,c-1}, and L_{c,c-1} of row head c -- are taken 16 columns at a time from the
+                    // polled hand-over buffers as they appear (what the row heads do with their last column): a flag, a
+                    // drain of 32 KB of write-through stores and a tile load less on the chain  block (r, c - 1) -> block
+                    // (r, c) -> ... -> row head r, which delay injection showed to pace the factorisation.
+                    const double *pa_ = opubp(side, r, d + 1), *pb_ = spubp(side, c);
+                    const int tid = thread_id();
+                    __syncthreads();      // the previous column's products have read As / Bs
+                    PanelPair p0, p1;
+                    panels_issue<0>(p0, pa_, pb_, tid);
+                    bool col_ok = panels_wait<0>(p0, pa_, pb_, tid, abort_flag);
+                    panels_issue<1>(p1, pa_, pb_, tid);
+                    panels_commit<0>(p0, As, Bs, true, tid);
+                    gemm_slice<0>(As, Bs, acc);
+                    col_ok = panels_wait<1>(p1, pa_, pb_, tid, abort_flag) && col_ok;
+                    panels_issue<2>(p0, pa_, pb_, tid);
+                    panels_commit<1>(p1, As, Bs, true, tid);
+                    gemm_slice<1>(As, Bs, acc);
+                    col_ok = panels_wait<2>(p0, pa_, pb_, tid, abort_flag) && col_ok;
+                    panels_issue<3>(p1, pa_, pb_, tid);
+                    panels_commit<2>(p0, As, Bs, true, tid);
+                    gemm_slice<2>(As, Bs, acc);
+                    col_ok = panels_wait<3>(p1, pa_, pb_, tid, abort_flag) && col_ok;
+                    panels_commit<3>(p1, As, Bs, true, tid);
+                    gemm_slice<3>(As, Bs, acc);
+                    if (!col_ok) MM_FUSED_ABANDON;
+                    continue;
+                }
                 if (!wg_wait<MODE>(flag(fb, r, r - k), c - k > 1 ? flag(fb, c, c - k) : nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
                 load_tile_shared<MODE>(As, tile_ref(A, g, side, r, k));
                 if (c - k > 1) {
@@ -1404,25 +1489,26 @@ __device__ __forceinline__ void chol_band_fused_body(double *A, TwGeom g, double
             MM_ACC_FOREACH(As[row][col] = ((t.rv(row) && t.cv(col)) ? ld_shared<MODE>(t.at(row, col)) : 0.0) - acc[a][b][i];)
             __syncthreads();
             // (d = 2: the block also goes out panel by panel for the head of its row, whose last column it is)
+            MM_DELAY(8);      // (d >= 2 owner, products done, before its solve)
             if (!finish_off_block_streamed<MODE, false>(As, Bs, T, lpubp(side, c), linv(side, c), abort_flag, t, acc,
-                                                        d == 2 && r < ncols ? spub2p(side, r) : nullptr))
+                                                        d == 2 ? (r < ncols ? spub2p(side, r) : nullptr) : opubp(side, r, d), -1,
+                                                        (d == 2 ? 1 : 2) | (in_m ? 4 : 0) | (d << 4)))
                 MM_FUSED_ABANDON;
-            if (d == 2 && r < ncols) store_tile_shared16(As, t);      // (its copy in A: see trsm_finish)
+            if (d > 2 || r < ncols) store_tile_shared16(As, t);      // (its copy in A: see trsm_finish)
             wg_publish<MODE>(flag(fb, r, d));
-            if (b_fwd) {  // L_rc y_c for the forward substitution (the block is still in As)
-                if (!wg_wait<MODE>(yflag(fb, c), nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
-                if (threadIdx.x < NB) {
-                    const long vi = vec_index(g, side, c, threadIdx.x);
-                    ys[threadIdx.x] = (vi >= 0 && vi < n) ? ld_shared<MODE>(y + vi) : 0.0;
+            MM_DELAY(11);      // (d >= 2 owner, block published)
+            if (b_fwd) {
+                if (pend_c >= 0) {      // the previous block's product: its y has long been published
+                    if (!fwd_part(pend_c + d, pend_c, true)) MM_FUSED_ABANDON;
+                    pend_c = -1;
                 }
-                __syncthreads();
-                const double tv = tile_matvec<LDT>(As, ys);
-                // a row of M is finished by side 0: hand the vector over in ITS element order
-                const int row = threadIdx.x >> 2, at = (side == 1 && r >= ncols) ? NB - 1 - row : row;
-                if ((threadIdx.x & 3) == 0) st_shared<MODE>(cslot(side, r, d) + at, tv);
-                wg_publish<MODE>(cflag(fb, r, d));
+                if (defer_fwd)
+                    pend_c = c;
+                else if (!fwd_part(r, c, false))
+                    MM_FUSED_ABANDON;
             }
         }
+        if (pend_c >= 0 && !fwd_part(pend_c + d, pend_c, true)) MM_FUSED_ABANDON;
         return;
     }
     double4_t acc1[2][2];
@@ -1479,6 +1565,7 @@ __device__ __forceinline__ void chol_band_fused_body(double *A, TwGeom g, double
                 const double *own = spub2p(side, r), *above = do_sub ? spubp(side, r - 1) : nullptr;
                 __syncthreads();      // the previous column's products have read As / Bs
                 MM_TRACE(r, 8);
+                MM_DELAY(6);
                 // (one straight-line body per combination of the two products: accumulators updated under run-time
                 // conditions end up shuffled between register files and scratch)
                 bool col_ok = true;
@@ -1585,6 +1672,7 @@ __device__ __forceinline__ void chol_band_fused_body(double *A, TwGeom g, double
             load_tile_shared<MODE>(Ds, dt);
         }
         __syncthreads();  // As / Bs are reused as M / X from here
+        MM_DELAY(3);
         MM_ACC_FOREACH(M[row][col] = (dt.rv(row) && dt.cv(col) && col <= row) ? Ds[row][col] - acc[a][b][i]
                                                                              : ((!dt.rv(row) && row == col) ? 1.0 : 0.0);)
         __syncthreads();
@@ -1609,6 +1697,7 @@ __device__ __forceinline__ void chol_band_fused_body(double *A, TwGeom g, double
             const int rr = e / NB, cc = e % NB;
             if ((rr >> 4) != (cc >> 4)) Lr[e] = X[rr][cc];
         }
+        MM_DELAY(10);      // (row head, end of row)
         if (b_fwd) {  // y_r = L_rr^-1 (b_r - sum_d L_{r,r-d} y_{r-d})
             if (threadIdx.x < NB) {
                 const long vi = vec_index(g, side, r, threadIdx.x);
@@ -1990,7 +2079,7 @@ size_t mm_chol_workspace_bytes(int n) {
     return mm_align_up(nblk * NB * NB * sizeof(double), 256) + mm_align_up((size_t)(n + NB) * sizeof(double), 256) +
            mm_align_up((2 * (2 * nblk * (FUSED_MAX_BWB + 1) + 2 * nblk) + 64 + FUSED_MAX_BWB * FUSED_MAX_BWB) * sizeof(int32_t), 256) +
            2 * mm_align_up(2 * nblk * (FUSED_MAX_BWB + 1) * NB * sizeof(double), 256) +  // forward + backward contributions
-           mm_align_up(nblk * (LPUB_BLOCK + 2 * NB * NB) * sizeof(double), 256);          // hand-over buffers of the streamed blocks
+           mm_align_up(nblk * (LPUB_BLOCK + (size_t)(2 + 2 * (FUSED_MAX_BWB - 2)) * NB * NB) * sizeof(double), 256);   // hand-over buffers of the streamed blocks
 }
 
 int mm_chol_solve(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int half_bandwidth, int32_t *info, void *ws,
@@ -2165,10 +2254,11 @@ int mm_chol_solve_gated(mm_ctx *ctx, double *A, int n, double *b, int nrhs, int 
                       (g.a + g.m) * NB, (int)(reach < n - 1 ? reach : n - 1));
         }
         const size_t nflags = 1 + 2 * (2 * (size_t)nblk * (bwb + 1) + 2 * nblk) + (size_t)g.m * g.m;
-        const double *b_fwd = nrhs >= 1 ? b : nullptr;  // the first right-hand side rides along
+        static const bool no_fwd = getenv("MM_CHOL_NO_FWD") && atoi(getenv("MM_CHOL_NO_FWD")) > 0;      // (diagnostic: the forward substitution by the launch-per-column kernels)
+        const double *b_fwd = nrhs >= 1 && !no_fwd ? b : nullptr;  // the first right-hand side rides along
         double *spub = lpub + (size_t)nblk * LPUB_BLOCK;
         const mm_chol_init_args ia = {info, flags, nflags, (unsigned long long *)contrib_bwd, (size_t)sides * nblk * (bwb + 1) * NB,
-                                      (unsigned long long *)lpub, (size_t)nblk * (LPUB_BLOCK + 2 * NB * NB), (unsigned long long *)Linv,
+                                      (unsigned long long *)lpub, chol_nlpub(nblk, bwb), (unsigned long long *)Linv,
                                       (size_t)nblk};
         if (ctx->chol_init_done == ws && ctx->chol_init_sides == sides) {
             // (the caller's own kernel ran mm_chol_init_body with mm_chol_init_plan's arguments for this workspace)
@@ -2262,7 +2352,7 @@ bool mm_chol_init_plan(mm_ctx *ctx, int n, int half_bandwidth, int32_t *info, vo
     double *lpub = (double *)((char *)contrib_bwd + mm_align_up(2 * (size_t)nblk * (FUSED_MAX_BWB + 1) * NB * sizeof(double), 256));
     *out = mm_chol_init_args{info, flags, 1 + 2 * (2 * (size_t)nblk * (bwb + 1) + 2 * nblk) + (size_t)g.m * g.m,
                              (unsigned long long *)contrib_bwd, (size_t)sides * nblk * (bwb + 1) * NB, (unsigned long long *)lpub,
-                             (size_t)nblk * (LPUB_BLOCK + 2 * NB * NB), (unsigned long long *)Linv, (size_t)nblk};
+                             chol_nlpub(nblk, bwb), (unsigned long long *)Linv, (size_t)nblk};
     if (sides_out) *sides_out = sides;
     if (bwb_out) *bwb_out = bwb;
     return true;
@@ -2310,7 +2400,7 @@ int mm_batch_chol_setup(mm_ctx *ctx, mm_batch_prob *bp, void *ws, size_t ws_byte
     bp->chol_spub = lpub + (size_t)nblk * LPUB_BLOCK;
     bp->chol_nflags = 1 + 2 * (2 * (size_t)nblk * (bwb + 1) + 2 * nblk) + (size_t)g.m * g.m;
     bp->chol_nsent = (size_t)sides * nblk * (bwb + 1) * NB;
-    bp->chol_nlpub = (size_t)nblk * (LPUB_BLOCK + 2 * NB * NB);
+    bp->chol_nlpub = chol_nlpub(nblk, bwb);
     return MM_OK;
 }
 int mm_batch_chol(mm_ctx *ctx, const mm_batch_prob *tab, const int32_t *list, int n_list, unsigned max_g_chol, unsigned max_g_bwd) {
