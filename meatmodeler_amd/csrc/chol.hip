@@ -1432,12 +1432,20 @@ __device__ __forceinline__ void chol_band_fused_body(double *A, TwGeom g, double
             wg_publish<MODE>(cflag(fb, rr, d));
             return true;
         };
+        // The block's own entries of A: requested a whole block ahead (into registers, before the previous block's solve) and
+        // parked in Ds, so that forming V = A_rc - sum costs LDS reads on the owners' chain, not a trip to memory.  Not
+        // when the matrix is still being produced by a concurrent launch (slab gating), nor for the blocks of M x M, whose
+        // entries come out of a pre-accumulator at the last moment.
+        double own[16];
+        auto own_early = [&](int c_) { return !slab_ready && !(tw && side == 0 && c_ >= g.a) && c_ + d < nrows && c_ < ncols; };
+        if (own_early(j)) tile_prefetch_shared<MODE>(own, tile_ref(A, g, side, j + d, j));
         for (int c = j; c + d < nrows && c < ncols; c += period) {
             const int r = c + d;
             const TileRef t = tile_ref(A, g, side, r, c);
             zero_acc(acc);
             // a block of M x M: the columns of T and of the other end have been taken care of by its pre-accumulator
             const bool in_m = tw && side == 0 && c >= g.a;
+            const bool early = own_early(c);
             for (int k = max(in_m ? g.a : 0, r - bwb); k < c; ++k) {
                 if (k == c - 1) {
                     // The newest column.  Its two blocks -- (r, c - 1), solved by the owner of the next offset behind the
@@ -1485,9 +1493,15 @@ __device__ __forceinline__ void chol_band_fused_body(double *A, TwGeom g, double
             } else if (!rows_ready(side == 0 ? r : nat(1, c))) {
                 MM_FUSED_ABANDON;
             }
+            if (early) tile_commit(Ds, own);
             __syncthreads();   // the last tile product has read As / Bs
-            MM_ACC_FOREACH(As[row][col] = ((t.rv(row) && t.cv(col)) ? ld_shared<MODE>(t.at(row, col)) : 0.0) - acc[a][b][i];)
+            if (early) {
+                MM_ACC_FOREACH(As[row][col] = Ds[row][col] - acc[a][b][i];)
+            } else {
+                MM_ACC_FOREACH(As[row][col] = ((t.rv(row) && t.cv(col)) ? ld_shared<MODE>(t.at(row, col)) : 0.0) - acc[a][b][i];)
+            }
             __syncthreads();
+            if (own_early(c + period)) tile_prefetch_shared<MODE>(own, tile_ref(A, g, side, c + period + d, c + period));
             // (d = 2: the block also goes out panel by panel for the head of its row, whose last column it is)
             MM_DELAY(8);      // (d >= 2 owner, products done, before its solve)
             if (!finish_off_block_streamed<MODE, false>(As, Bs, T, lpubp(side, c), linv(side, c), abort_flag, t, acc,
@@ -1673,8 +1687,21 @@ __device__ __forceinline__ void chol_band_fused_body(double *A, TwGeom g, double
         }
         __syncthreads();  // As / Bs are reused as M / X from here
         MM_DELAY(3);
-        MM_ACC_FOREACH(M[row][col] = (dt.rv(row) && dt.cv(col) && col <= row) ? Ds[row][col] - acc[a][b][i]
-                                                                             : ((!dt.rv(row) && row == col) ? 1.0 : 0.0);)
+        if (dt.r_lo == 0 && dt.c_lo == 0 && dt.r_hi == NB && dt.c_hi == NB) {
+            // a whole tile (all but the first / last block row): the waves' 32 x 32 quadrants are entirely below the diagonal
+            // (wave 2), entirely above it (wave 1: zeros) or on it -- no range tests, a third of the instructions on the chain
+            const int wq = wave_id();
+            if (wq == 2) {
+                MM_ACC_FOREACH(M[row][col] = Ds[row][col] - acc[a][b][i];)
+            } else if (wq == 1) {
+                MM_ACC_FOREACH(M[row][col] = 0.0;)
+            } else {
+                MM_ACC_FOREACH(M[row][col] = col <= row ? Ds[row][col] - acc[a][b][i] : 0.0;)
+            }
+        } else {
+            MM_ACC_FOREACH(M[row][col] = (dt.rv(row) && dt.cv(col) && col <= row) ? Ds[row][col] - acc[a][b][i]
+                                                                                 : ((!dt.rv(row) && row == col) ? 1.0 : 0.0);)
+        }
         __syncthreads();
         int bad = 0;
         double *Lr = linv(side, r);
