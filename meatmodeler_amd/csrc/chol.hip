@@ -1020,6 +1020,36 @@ __device__ __forceinline__ bool stage_wait(StageRegs<K> &g, const double *lpub_c
     __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return false;
 }
+// The row head's LAST stage sits on the chain  factorisation of L_{r-1,r-1} -> this solve -> factorisation of L_rr: it may
+// poll the stage's own words (four per lane, two attempts in flight) instead of a canary followed by the load -- one trip
+// to memory less per block column (only this one consumer per diagonal block: see stage_wait on flooding).
+#ifndef MM_CHOL_DIRECT_LAST
+#define MM_CHOL_DIRECT_LAST 1
+#endif
+template <int K>
+__device__ __forceinline__ bool stage_wait_direct(StageRegs<K> &g, const double *lpub_c, const double *Linv_c, int lane,
+                                                  int32_t *abort_flag) {
+    if (stage_complete<K>(g)) return true;
+    StageRegs<K> ga, gb;
+    stage_issue<K>(ga, lpub_c, Linv_c, lane);
+    __builtin_amdgcn_s_sleep(2);
+    stage_issue<K>(gb, lpub_c, Linv_c, lane);
+    for (long it = 0; it < SPIN_LIMIT; ++it) {
+        if (stage_complete<K>(ga)) {
+            g = ga;
+            return true;
+        }
+        stage_issue<K>(ga, lpub_c, Linv_c, lane);
+        if (stage_complete<K>(gb)) {
+            g = gb;
+            return true;
+        }
+        stage_issue<K>(gb, lpub_c, Linv_c, lane);
+        if ((it & 63) == 63 && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+    }
+    __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return false;
+}
 // stage K of the solve on this wave's 16 rows, its operands in registers
 template <int MODE, int K>
 __device__ __forceinline__ void stage_compute(const StageRegs<K> &g, double (*As)[LDT], double (*Bs)[LDT], double (*Xd)[16][17],
@@ -1091,7 +1121,10 @@ __device__ __forceinline__ bool finish_off_block_streamed(double (*As)[LDT], dou
         syrk_slice<1>(As, acc);
         syrk_slice<2>(As, acc);
     }
-    ok = stage_wait<3>(g3, lpub_c, Linv_c, lane, abort_flag) && ok;
+    if constexpr (SYRK && MM_CHOL_DIRECT_LAST != 0)
+        ok = stage_wait_direct<3>(g3, lpub_c, Linv_c, lane, abort_flag) && ok;
+    else
+        ok = stage_wait<3>(g3, lpub_c, Linv_c, lane, abort_flag) && ok;
     MM_TRACE_ROW(trace_row, 2);
     if constexpr (SYRK) MM_DELAY(2);
     else MM_DELAY(4);
