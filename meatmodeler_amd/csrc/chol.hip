@@ -415,6 +415,7 @@ __device__ __forceinline__ void factor_block_lds(double (*M)[NB + 1], double (*X
         wave_lds_sync();
         lds_counter_set(panels, 1);
         MM_TRACE_ROW(trace_row, 10);
+        MM_DELAY(15);
         panel16_update_own<1>(M);
         MM_TRACE_ROW(trace_row, 11);
         panel16_factor_dpp<1>(M, X, R);
@@ -426,6 +427,7 @@ __device__ __forceinline__ void factor_block_lds(double (*M)[NB + 1], double (*X
         wave_lds_sync();
         lds_counter_set(panels, 3);
         MM_TRACE_ROW(trace_row, 13);
+        MM_DELAY(16);
         panel16_update_own<3>(M);
         MM_TRACE_ROW(trace_row, 14);
         panel16_factor_dpp<3>(M, X, R);
@@ -1024,7 +1026,7 @@ __device__ __forceinline__ bool stage_wait(StageRegs<K> &g, const double *lpub_c
 // poll the stage's own words (four per lane, two attempts in flight) instead of a canary followed by the load -- one trip
 // to memory less per block column (only this one consumer per diagonal block: see stage_wait on flooding).
 #ifndef MM_CHOL_DIRECT_LAST
-#define MM_CHOL_DIRECT_LAST 1
+#define MM_CHOL_DIRECT_LAST 2
 #endif
 template <int K>
 __device__ __forceinline__ bool stage_wait_direct(StageRegs<K> &g, const double *lpub_c, const double *Linv_c, int lane,
@@ -1105,15 +1107,28 @@ __device__ __forceinline__ bool finish_off_block_streamed(double (*As)[LDT], dou
     StageRegs<1> g1;
     StageRegs<2> g2;
     StageRegs<3> g3;
+    // (MM_CHOL_DIRECT_LAST: 1 = the row head polls the words of its LAST stage directly, 2 = of every stage -- its early
+    // loads usually come back as the sentinel, and canary + reload is two trips to memory per stage on a consumer that delay
+    // injection shows running BEHIND the producer's panels)
+    auto wait_stage = [&](auto &gk, auto ktag) __attribute__((always_inline)) -> bool {
+        constexpr int K = decltype(ktag)::value;
+        if constexpr (SYRK && (MM_CHOL_DIRECT_LAST >= 2 || (MM_CHOL_DIRECT_LAST == 1 && K == 3)))
+            return stage_wait_direct<K>(gk, lpub_c, Linv_c, lane, abort_flag);
+        else
+            return stage_wait<K>(gk, lpub_c, Linv_c, lane, abort_flag);
+    };
     stage_issue<0>(g0, lpub_c, Linv_c, lane);
-    bool ok = stage_wait<0>(g0, lpub_c, Linv_c, lane, abort_flag);
+    bool ok = wait_stage(g0, std::integral_constant<int, 0>{});
     stage_issue<1>(g1, lpub_c, Linv_c, lane);
+    if constexpr (SYRK) MM_DELAY(12);
     stage_compute<MODE, 0>(g0, As, Bs, Xd, t, spub_blk, lane, row0);
-    ok = stage_wait<1>(g1, lpub_c, Linv_c, lane, abort_flag) && ok;
+    ok = wait_stage(g1, std::integral_constant<int, 1>{}) && ok;
     stage_issue<2>(g2, lpub_c, Linv_c, lane);
+    if constexpr (SYRK) MM_DELAY(13);
     stage_compute<MODE, 1>(g1, As, Bs, Xd, t, spub_blk, lane, row0);
-    ok = stage_wait<2>(g2, lpub_c, Linv_c, lane, abort_flag) && ok;
+    ok = wait_stage(g2, std::integral_constant<int, 2>{}) && ok;
     stage_issue<3>(g3, lpub_c, Linv_c, lane);
+    if constexpr (SYRK) MM_DELAY(14);
     stage_compute<MODE, 2>(g2, As, Bs, Xd, t, spub_blk, lane, row0);
     if constexpr (SYRK) {
         __syncthreads();      // P_0 .. P_2 of all four waves
@@ -1121,10 +1136,7 @@ __device__ __forceinline__ bool finish_off_block_streamed(double (*As)[LDT], dou
         syrk_slice<1>(As, acc);
         syrk_slice<2>(As, acc);
     }
-    if constexpr (SYRK && MM_CHOL_DIRECT_LAST != 0)
-        ok = stage_wait_direct<3>(g3, lpub_c, Linv_c, lane, abort_flag) && ok;
-    else
-        ok = stage_wait<3>(g3, lpub_c, Linv_c, lane, abort_flag) && ok;
+    ok = wait_stage(g3, std::integral_constant<int, 3>{}) && ok;
     MM_TRACE_ROW(trace_row, 2);
     if constexpr (SYRK) MM_DELAY(2);
     else MM_DELAY(4);
@@ -1679,6 +1691,7 @@ __device__ __forceinline__ void chol_band_fused_body(double *A, TwGeom g, double
             // The solve runs IN the parked tile Ss (V = A_{r,r-1} - sum, in place): L_{r,r-1} then outlives the diagonal
             // block's factorisation, which takes As / Bs -- it is copied to A beside that factorisation by the idle waves
             // (StagePub::bulk) and multiplies y_{r-1} at the end of the row without being read back.
+            MM_DELAY(17);
             MM_ACC_FOREACH(Ss[row][col] -= acc1[a][b][i];)
             __syncthreads();
             // the solve streams behind the factorisation of L_{r-1,r-1}; acc += L_{r,r-1} L_{r,r-1}^T rides along
