@@ -1404,9 +1404,19 @@ __device__ __forceinline__ void chol_band_fused_body(double *A, TwGeom g, double
         const int r = g.a + i, c = g.a + jj;
         const TileRef t = tile_ref(A, g, 0, r, c);
         zero_acc(acc);
-        for (int k = max(0, r - bwb); k < g.a; ++k) {
-            if (r == c && k == r - 1) continue;  // (the head of row r adds L_{r,r-1} L_{r,r-1}^T itself, from its LDS copy)
-            if (!wg_wait<MODE>(flag(fb0(), r, r - k), r != c ? flag(fb0(), c, c - k) : nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
+        // its own entries: requested now, parked in Ds before they are needed (not when the matrix is still being produced)
+        double own[16];
+        const bool early = !slab_ready;
+        if (early) tile_prefetch_shared<MODE>(own, t);
+        // the other end's blocks sit at their natural positions (upper triangle): read with side 0's addressing
+        const int rr = nblk - 1 - r, rc = nblk - 1 - c;  // the two rows in side 1's numbering (rr <= rc)
+        bool ok_ = true;
+        auto product0 = [&](int k) __attribute__((always_inline)) {      // with column k of T
+            if (r == c && k == r - 1) return;  // (the head of row r adds L_{r,r-1} L_{r,r-1}^T itself, from its LDS copy)
+            if (!wg_wait<MODE>(flag(fb0(), r, r - k), r != c ? flag(fb0(), c, c - k) : nullptr, abort_flag, &s_ok)) {
+                ok_ = false;
+                return;
+            }
             load_tile_shared<MODE>(As, tile_ref(A, g, 0, r, k));
             if (r != c) load_tile_shared<MODE>(Bs, tile_ref(A, g, 0, c, k));
             __syncthreads();
@@ -1414,11 +1424,12 @@ __device__ __forceinline__ void chol_band_fused_body(double *A, TwGeom g, double
                 tile_gemm_nt(As, Bs, acc);
             else
                 tile_gemm_nt(As, As, acc);
-        }
-        // the other end's blocks sit at their natural positions (upper triangle): read with side 0's addressing
-        const int rr = nblk - 1 - r, rc = nblk - 1 - c;  // the two rows in side 1's numbering (rr <= rc)
-        for (int kt = max(0, rc - bwb); kt < g.b; ++kt) {
-            if (!wg_wait<MODE>(flag(fb1(), rr, rr - kt), r != c ? flag(fb1(), rc, rc - kt) : nullptr, abort_flag, &s_ok)) MM_FUSED_ABANDON;
+        };
+        auto product1 = [&](int kt) __attribute__((always_inline)) {     // with column kt of the other end
+            if (!wg_wait<MODE>(flag(fb1(), rr, rr - kt), r != c ? flag(fb1(), rc, rc - kt) : nullptr, abort_flag, &s_ok)) {
+                ok_ = false;
+                return;
+            }
             load_tile_shared<MODE>(As, tile_ref(A, g, 0, r, nblk - 1 - kt));
             if (r != c) load_tile_shared<MODE>(Bs, tile_ref(A, g, 0, c, nblk - 1 - kt));
             __syncthreads();
@@ -1426,12 +1437,26 @@ __device__ __forceinline__ void chol_band_fused_body(double *A, TwGeom g, double
                 tile_gemm_nt(As, Bs, acc);
             else
                 tile_gemm_nt(As, As, acc);
-        }
+        };
+        // Every block of M x M takes a product with the LAST column of either end, and those two appear at about the same
+        // time, last of all: everything older goes first (both ends), so that two products are left when they are there --
+        // walking one end to its last column first left up to bwb products of the other end behind it, and the first rows
+        // of M waited for them (the phase trace showed row a + 1 starting 12 us late).
+        for (int k = max(0, r - bwb); k < g.a - 1 && ok_; ++k) product0(k);
+        for (int kt = max(0, rc - bwb); kt < g.b - 1 && ok_; ++kt) product1(kt);
+        if (ok_ && g.b - 1 >= max(0, rc - bwb)) product1(g.b - 1);
+        if (ok_ && g.a - 1 >= max(0, r - bwb)) product0(g.a - 1);
+        if (!ok_) MM_FUSED_ABANDON;
         if (!rows_ready(r)) MM_FUSED_ABANDON;
         // A_rc - sum goes back through LDS: 16-byte write-through stores (an 8-byte one is a fabric write per lane, and the
         // first rows of M wait for exactly this publication)
+        if (early) tile_commit(Ds, own);
         __syncthreads();
-        MM_ACC_FOREACH(As[row][col] = ((t.rv(row) && t.cv(col)) ? ld_shared<MODE>(t.at(row, col)) : 0.0) - acc[a][b][i];)
+        if (early) {
+            MM_ACC_FOREACH(As[row][col] = Ds[row][col] - acc[a][b][i];)
+        } else {
+            MM_ACC_FOREACH(As[row][col] = ((t.rv(row) && t.cv(col)) ? ld_shared<MODE>(t.at(row, col)) : 0.0) - acc[a][b][i];)
+        }
         __syncthreads();
         MM_DELAY(9);
         store_tile_shared16(As, t);
