@@ -1876,7 +1876,7 @@ extern "C" int mm_debug_chol_trace(unsigned long long *host /*[128*32]*/) {
 // Two-ended: side 0 walks M then T upwards; side 1 starts from the x of M (polled like any other) and walks its own
 // columns in its reversed numbering -- the two chains of a + m and b steps run side by side.
 constexpr unsigned long long BWD_SENTINEL = ~0ull;
-constexpr size_t BWD_LDS_BYTES = (size_t)(2 * NB * LDT + 4 * NB + 2 * NB) * sizeof(double);
+constexpr size_t BWD_LDS_BYTES = (size_t)(4 * NB * LDT + 4 * NB + 2 * NB) * sizeof(double);      // four tiles: two steps' L_kk^-1 and L_{k,k-1}
 
 __device__ __forceinline__ void tile_prefetch(double (&pre)[16], const TileRef &t) {
 #pragma unroll
@@ -1950,6 +1950,143 @@ __device__ __forceinline__ void chol_band_bwd_body(double *A, TwGeom g, const do
         return vi >= 0 && vi < n;
     };
     int failed = 0;
+#ifndef MM_CHOL_BWD_CHAIN_WAVE
+#define MM_CHOL_BWD_CHAIN_WAVE 1
+#endif
+    if (lid == 0 && MM_CHOL_BWD_CHAIN_WAVE) {
+        // The chain  x_k = L_kk^-T (y_k - L_{k+1,k}^T x_{k+1} - contributions)  on ONE wave (round 4).  Delay injection showed
+        // the chain workgroup itself pacing this kernel (its helpers have slack): four waves sharing each product paid five
+        // workgroup barriers and as many LDS round trips per step (3.1 us).  Here wave 0 walks the chain alone -- lane c owns
+        // element c of every vector, a product is 64 multiply-adds per lane with the tile and the vector read from LDS, wave
+        // barriers only -- and waves 1 .. 3 keep the tiles of the next step coming into the other half of a double buffer.
+        double (*TA)[NB][LDT] = reinterpret_cast<double (*)[NB][LDT]>(smem);                      // TA[b]: L_kk^-1 of a step with parity b
+        double (*TB)[NB][LDT] = reinterpret_cast<double (*)[NB][LDT]>(smem + 2 * NB * LDT);       // TB[b]: L_{k,k-1}
+        double *cvec = smem + 4 * NB * LDT, *cvec2 = cvec + NB;
+        __shared__ int s_loaded[3], s_done, s_dead;      // steps each loader wave has delivered | steps the chain has left
+        const int ktop = ncols - 1;  // first block this chain solves for
+        if (ktop < 0) return;
+        double local = 0.0;  // L_{k+1,k}^T x_{k+1}, element lane (wave 0)
+        if (threadIdx.x == 0) {
+            s_loaded[0] = s_loaded[1] = s_loaded[2] = 0;
+            s_done = 0;
+            s_dead = 0;
+        }
+        if (side == 1 && ktop + 1 < nrows && bwb >= 1) {
+            // the row above the chain's first block belongs to M: x of that row comes from side 0, the block
+            // (ktop + 1, ktop) is this side's -> `local` for the first step (all four waves, once)
+            double (*T1_)[LDT] = TB[1];
+            double (*part_)[NB] = reinterpret_cast<double (*)[NB]>(&TA[1][0][0]);
+            double pt[16];
+            tile_prefetch(pt, tile_ref(A, g, side, ktop + 1, ktop));
+            tile_commit(T1_, pt);
+            if (threadIdx.x < NB) {
+                long vi;
+                cvec2[threadIdx.x] = vpos(ktop + 1, vi) ? poll_value(xpoll(vi), abort_flag, failed) : 0.0;
+            }
+            if (__syncthreads_or(failed)) MM_FUSED_ABANDON;
+            local = tile_matvec_t(T1_, cvec2, part_);      // (valid in the first 64 threads = wave 0)
+        }
+        __syncthreads();
+        const int wv = wave_id();
+        volatile int *loaded = s_loaded, *done = &s_done, *deadp = &s_dead;
+        if (wv != 0) {
+            // loaders: the two tiles of step j (k = ktop - j) into buffer j & 1, once the chain has left step j - 2
+            const int lt = (int)threadIdx.x - 64;
+            // (all loads of a step in flight at once: three dependent batches per step made the loaders the chain's pace.  Tried:
+            // requesting step j + 1 before waiting for the buffer, registers as a third buffer -- 0.604 instead of 0.566 ms.)
+            constexpr int NLD = (NB * NB + 191) / 192;
+            for (int j = 0; j <= ktop; ++j) {
+                const int k = ktop - j, b = j & 1;
+                while (*done < j - 1 && !*deadp) __builtin_amdgcn_s_sleep(1);
+                if (*deadp) return;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                MM_DELAY(24);      // (backward loaders, buffer free)
+                const double *li = Linv + (size_t)nat(k) * NB * NB;
+                const TileRef tr = tile_ref(A, g, side, k, k > 0 ? k - 1 : 0);
+                double va[NLD], vb[NLD];
+#pragma unroll
+                for (int q = 0; q < NLD; ++q) {
+                    const int e = lt + 192 * q, r_ = e / NB, c_ = e % NB;
+                    va[q] = e < NB * NB ? li[e] : 0.0;
+                    vb[q] = (k > 0 && e < NB * NB && tr.rv(r_) && tr.cv(c_)) ? *tr.at(r_, c_) : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < NLD; ++q) {
+                    const int e = lt + 192 * q;
+                    if (e < NB * NB) {
+                        TA[b][e / NB][e % NB] = va[q];
+                        TB[b][e / NB][e % NB] = vb[q];
+                    }
+                }
+                lds_counter_set(loaded + (wv - 1), j + 1);
+            }
+            return;
+        }
+        // ---- wave 0: the chain ----
+        const int lane = lane_id();
+        double cv[FUSED_MAX_BWB + 1], yk = 0.0;
+        auto vposl = [&](int blk, long &vi) -> bool {
+            vi = vec_index(g, side, blk, lane);
+            return vi >= 0 && vi < n;
+        };
+        auto request = [&](int k) {
+            if (k < 0) return;
+            long vi;
+            yk = vposl(k, vi) ? y[vi] : 0.0;
+#pragma unroll
+            for (int dd = 2; dd <= FUSED_MAX_BWB; ++dd)
+                if (dd <= bwb && k + dd < nrows) cv[dd] = __hip_atomic_load(cslot(k, dd) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        // out[lane] = sum_r T[r][lane] v[r]: four independent partial sums (the FMAs of one chain would wait for each other)
+        auto col_product = [&](const double (*T)[LDT], const double *v) {
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll 4
+            for (int r_ = 0; r_ < NB; r_ += 4) {
+                s0 = fma(T[r_][lane], v[r_], s0);
+                s1 = fma(T[r_ + 1][lane], v[r_ + 1], s1);
+                s2 = fma(T[r_ + 2][lane], v[r_ + 2], s2);
+                s3 = fma(T[r_ + 3][lane], v[r_ + 3], s3);
+            }
+            return (s0 + s1) + (s2 + s3);
+        };
+        request(ktop);
+        for (int j = 0; j <= ktop; ++j) {
+            const int k = ktop - j, b = j & 1;
+            MM_DELAY(21);      // (backward chain, top of a step)
+            double rhs = yk - local;
+#pragma unroll
+            for (int dd = 2; dd <= FUSED_MAX_BWB; ++dd)  // fixed summation order
+                if (dd <= bwb && k + dd < nrows) {
+                    if ((unsigned long long)__double_as_longlong(cv[dd]) == BWD_SENTINEL)
+                        cv[dd] = poll_value(cslot(k, dd) + lane, abort_flag, failed);
+                    rhs -= cv[dd];
+                }
+            if (__builtin_amdgcn_ballot_w64(failed != 0)) {
+                if (lane == 0) *deadp = 1;
+                MM_FUSED_ABANDON;
+            }
+            cvec[lane] = rhs;
+            lds_counter_wait(loaded, j + 1);
+            lds_counter_wait(loaded + 1, j + 1);
+            lds_counter_wait(loaded + 2, j + 1);
+            wave_lds_sync();
+            MM_DELAY(25);      // (backward chain, tiles there, before the first product)
+            const double xk = col_product(TA[b], cvec);
+            long vi;
+            const bool okv = vposl(k, vi);
+            if (okv) {
+                st_shared<2>(xpoll(vi), xk);
+                x[vi] = xk;
+            }
+            cvec2[lane] = okv ? xk : 0.0;
+            request(k - 1);
+            MM_DELAY(22);      // (backward chain, x_k is out)
+            wave_lds_sync();
+            if (k > 0) local = col_product(TB[b], cvec2);
+            lds_counter_set(done, j + 1);
+        }
+        return;
+    }
     // tiles are fetched two steps ahead (a step is shorter than a trip to memory): two register slots, loop unrolled by 2
     if (lid == 0) {
         double p0a[16], p1a[16], p0b[16], p1b[16];
@@ -1973,6 +2110,7 @@ __device__ __forceinline__ void chol_band_bwd_body(double *A, TwGeom g, const do
                     cv[dd] = __hip_atomic_load(cslot(k, dd) + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
         auto step = [&](int k, double (&p0)[16], double (&p1)[16]) {
+            MM_DELAY(21);      // (backward chain, top of a step)
             if (threadIdx.x < NB) {
                 double rhs = yk - local;
 #pragma unroll
@@ -1999,6 +2137,7 @@ __device__ __forceinline__ void chol_band_bwd_body(double *A, TwGeom g, const do
                 vec2[threadIdx.x] = ok ? xk : 0.0;
             }
             request(k - 1);
+            MM_DELAY(22);      // (backward chain, x_k is out)
             __syncthreads();
             if (k > 0) local = reg_matvec_t(p1, vec2, part);
             fetch(k - 2, p0, p1);      // (both register sets of this step are spent)
@@ -2047,6 +2186,7 @@ __device__ __forceinline__ void chol_band_bwd_body(double *A, TwGeom g, const do
             dead = true;
             return;
         }
+        MM_DELAY(23);      // (backward helpers, x_{k+d} seen)
         const double t = reg_matvec_t(pp, vec, part);
         if (threadIdx.x < NB) st_shared<2>(cslot(k, d) + threadIdx.x, t);
         fetch(k - 2, pp);
