@@ -1330,7 +1330,11 @@ __device__ __forceinline__ size_t tw_side_flags(int nblk, int W) { return 2 * (s
 // Forward substitution L y = b rides along (b_fwd != nullptr): the owner of block (r, c) multiplies it with y_c as
 // soon as that exists and hands the 64-vector to the owner of the diagonal block r, which adds the contributions in
 // a fixed order (deterministic), applies L_rr^-1 and publishes y_r.  The y chain trails the factorisation by a hop or
-// two, so the forward solve costs no extra time.  (Two-ended: the rows of M receive contributions from both sides.)
+// two.  NOT for free, as this comment claimed until round 4: y_c leaves its row head ~12 us after L_cc, and an owner that
+// waits for it between two blocks is late for the next one -- with MM_CHOL_NO_FWD=1 the kernel took 506 instead of 531 us.
+// The owners of the two farthest offsets therefore take the product after their next block (defer_fwd below); what is
+// left of the difference is the tail of the y chain behind the last column.  (Two-ended: the rows of M receive
+// contributions from both sides.)
 
 template <int MODE>
 __device__ __forceinline__ void chol_band_fused_body(double *A, TwGeom g, double *Linv,
