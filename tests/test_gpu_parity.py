@@ -1041,6 +1041,35 @@ def test_library_trf_driver_equals_python_driver_bitwise(golden_dir, case, monke
         assert a.status == 0 and a.nfev == 7
 
 
+def test_trf_folded_launches_equal_the_separate_ones(golden_dir):
+    """Inside mm_ba_trf the damping, the band zero fill of S and the factorisation's fills ride in schur_prepare_kernel
+    (mm_ba_schur_solve_damped); MM_SCHUR_FOLD=0 keeps mm_ba_damp + fill + mm_ba_schur_solve + chol_init_kernel as separate
+    launches (what the Python-sequenced loop and the sharded loop issue).  Same arithmetic: identical iterates, bit for bit.
+    (The switch is read once per process: the unfolded run is a fresh interpreter.)"""
+    import subprocess
+    import sys
+    d = np.load(os.path.join(golden_dir, "g5_adjust_points_d.npz"))       # 120 cameras: pair list + single-launch factorisation
+    F, P, L, seed = (int(d[k]) for k in ("F", "P", "L", "seed"))
+    pr = synth.make_ba_problem(F, P, L, seed=seed)
+    res = bundleAdjuster.solvePoints(pr["ext"], pr["K"], pr["pts0"], pr["obs"], pr["fi"], pr["pi"], verbose=0)
+    assert "library" in res.host_segments_ms
+    code = (
+        "import numpy as np\n"
+        "from meatmodeler_amd import synth, bundleAdjuster\n"
+        f"pr = synth.make_ba_problem({F}, {P}, {L}, seed={seed})\n"
+        "r = bundleAdjuster.solvePoints(pr['ext'], pr['K'], pr['pts0'], pr['obs'], pr['fi'], pr['pi'], verbose=0)\n"
+        "assert 'library' in r.host_segments_ms\n"
+        "print('RESULT', r.nfev, r.status, repr(float(r.cost)), repr(float(np.asarray(r.x, dtype=np.float64).sum())))\n")
+    env = dict(os.environ, MM_SCHUR_FOLD="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1].split()
+    assert (int(line[1]), int(line[2])) == (res.nfev, res.status)
+    assert float(line[3]) == float(res.cost)
+    assert float(line[4]) == float(np.asarray(res.x, dtype=np.float64).sum())
+
+
 @pytest.mark.parametrize("driver", ["library", "python"])
 def test_trf_survives_an_abandoned_factorisation(golden_dir, driver, monkeypatch):
     """info = -1 (the single-launch banded factorisation gave up waiting: its workgroups were not co-resident) is not an
