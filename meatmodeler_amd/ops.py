@@ -303,8 +303,9 @@ class BADevice:
                 seg_ids, counts = torch.unique_consecutive(key_s, return_counts=True)
                 seg_hi = torch.cumsum(counts, 0)
                 seg_lo = seg_hi - counts
-                # pairs per chunk = per wave of the pair kernel (a multiple of 64: whole lane strides)
-                CH = max(64, int(os.environ.get("MM_SCHUR_CHUNK", "256")) // 64 * 64)
+                # pairs per chunk = per wave of the pair kernel (a multiple of 64: whole lane strides).  512 since the second
+                # half of round 4: 230 us per build at the bench shape against 249 with 256 (384: 230; 1024: slower)
+                CH = max(64, int(os.environ.get("MM_SCHUR_CHUNK", "512")) // 64 * 64)
                 cntc = (counts + (CH - 1)) // CH
                 first_hi = torch.cumsum(cntc, 0)
                 first = first_hi - cntc
