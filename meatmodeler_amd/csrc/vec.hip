@@ -16,7 +16,7 @@ constexpr int MD_GRID = 2048;      // capacity of the per-workgroup partials (wo
 inline int md_grid_cap() {
     static const int cap = [] {
         const char *e = getenv("MM_VEC_GRID");
-        const int v = e ? atoi(e) : 512;
+        const int v = e ? atoi(e) : 256;      // (17.9 us per pass at the bench shape; 384: 17.9, 512: 19.0, 768: 21.4, 128: 22.0 -- round 4)
         return v < 1 ? 1 : (v > MD_GRID ? MD_GRID : v);
     }();
     return cap;
