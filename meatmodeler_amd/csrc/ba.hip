@@ -440,6 +440,23 @@ int check_pb(mm_ctx *ctx, const mm_ba_problem *pb, const char *who) {
 
 constexpr int RES_BLOCKS = 2048;
 constexpr int JVP_MAX_WG = 2048;      // workgroups of the Jacobian product with fused inner products (grid-stride beyond)
+// (the caps actually used: MM_RES_WG / MM_JVP_WG, at most the compile-time capacities above -- for sweeps)
+inline int res_wg_cap() {
+    static const int cap = [] {
+        const char *e = getenv("MM_RES_WG");
+        const int v = e ? atoi(e) : RES_BLOCKS;
+        return v < 1 ? 1 : (v > RES_BLOCKS ? RES_BLOCKS : v);
+    }();
+    return cap;
+}
+inline int jvp_wg_cap() {
+    static const int cap = [] {
+        const char *e = getenv("MM_JVP_WG");
+        const int v = e ? atoi(e) : 1024;      // (25.0 us per product at the bench shape; 2048: 26.5, 512: 31.9 -- round 4)
+        return v < 1 ? 1 : (v > JVP_MAX_WG ? JVP_MAX_WG : v);
+    }();
+    return cap;
+}
 
 // Regulariser of the 2-D subspace trust-region step, on the device so that the host does not have to wait for the
 // three scalars before the reduced system can be built (SciPy trf.py:473-477 via least_squares(method='trf',
@@ -593,7 +610,7 @@ int mm_ba_residual(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, con
     if (!cams || !pts || !cost2) return mm_fail(ctx, MM_ERR_ARG, "mm_ba_residual: null pointer");
     if (!ws || ws_bytes < RES_BLOCKS * sizeof(double)) return mm_fail(ctx, MM_ERR_WORKSPACE, "mm_ba_residual: workspace < 16 KiB");
     int64_t nb = (pb->O + 255) / 256;
-    int blocks = (int)(nb < 1 ? 1 : (nb > RES_BLOCKS ? RES_BLOCKS : nb));
+    int blocks = (int)(nb < 1 ? 1 : (nb > res_wg_cap() ? res_wg_cap() : nb));
     MM_CAM_TABLE(ctx, pb, cams);
     MM_LAUNCH(ctx, "ba_residual_kernel", ba_residual_kernel, dim3(blocks), dim3(256), 0, *pb, cams, pts, ctab, res, (double *)ws);
     MM_LAUNCH(ctx, "sum_partials_kernel", sum_partials_kernel, dim3(1), dim3(256), 0, (const double *)ws, blocks, cost2);
@@ -669,7 +686,7 @@ int mm_ba_jvp_dots(mm_ctx *ctx, const mm_ba_problem *pb, const double *cams, con
         return MM_OK;
     }
     const int64_t n_all = (pb->O + 255) / 256;
-    const unsigned n_wg = (unsigned)(n_all < JVP_MAX_WG ? n_all : JVP_MAX_WG);
+    const unsigned n_wg = (unsigned)(n_all < jvp_wg_cap() ? n_all : jvp_wg_cap());
     MM_CAM_TABLE(ctx, pb, cams);
     MM_LAUNCH(ctx, "ba_jvp_kernel", ba_jvp_dots_kernel, dim3(n_wg), dim3(256), 0, *pb, cams, pts, ctab, wc, wp, out, other,
               (double *)((char *)ws + 256));
@@ -723,7 +740,7 @@ int mm_ba_residual_publish(mm_ctx *ctx, const mm_ba_problem *pb, const double *c
     if (!cams || !pts || !board || !host_board || count > 16 || cost_slot >= count) return mm_fail(ctx, MM_ERR_ARG, "mm_ba_residual_publish: bad argument");
     if (!ws || ws_bytes < RES_BLOCKS * sizeof(double)) return mm_fail(ctx, MM_ERR_WORKSPACE, "mm_ba_residual: workspace < 16 KiB");
     int64_t nb = (pb->O + 255) / 256;
-    int blocks = (int)(nb < 1 ? 1 : (nb > RES_BLOCKS ? RES_BLOCKS : nb));
+    int blocks = (int)(nb < 1 ? 1 : (nb > res_wg_cap() ? res_wg_cap() : nb));
     MM_CAM_TABLE(ctx, pb, cams);
     MM_LAUNCH(ctx, "ba_residual_kernel", ba_residual_kernel, dim3(blocks), dim3(256), 0, *pb, cams, pts, ctab, (double *)nullptr, (double *)ws);
     MM_LAUNCH(ctx, "sum_partials_kernel", sum_partials_publish_kernel, dim3(1), dim3(256), 0, (const double *)ws, blocks, board,
@@ -736,8 +753,8 @@ int mm_ba_residual_publish(mm_ctx *ctx, const mm_ba_problem *pb, const double *c
 void mm_batch_ba_setup(mm_batch_prob *bp) {
     const mm_ba_problem &pb = bp->pb;
     const int64_t nb = (pb.O + 255) / 256;
-    bp->g_res = (uint32_t)(nb < 1 ? 1 : (nb > RES_BLOCKS ? RES_BLOCKS : nb));
-    bp->g_jvp = (uint32_t)(nb < JVP_MAX_WG ? (nb < 1 ? 1 : nb) : JVP_MAX_WG);
+    bp->g_res = (uint32_t)(nb < 1 ? 1 : (nb > res_wg_cap() ? res_wg_cap() : nb));
+    bp->g_jvp = (uint32_t)(nb < jvp_wg_cap() ? (nb < 1 ? 1 : nb) : jvp_wg_cap());
     bp->g_pblk = (uint32_t)((pb.P + 256 / PB_LANES - 1) / (256 / PB_LANES));
     bp->g_obs = (uint32_t)(nb < 1 ? 1 : nb);
     bp->g_pts = (uint32_t)((pb.P + 256 / PB_LANES - 1) / (256 / PB_LANES));
