@@ -118,7 +118,10 @@ __global__ __launch_bounds__(256) void ba_jacobian_kernel(mm_ba_problem pb, cons
 // (One thread per point waits for the waves that own the longest tracks -- 4 observations on average, up to the band width
 // (88 at C3): 68 us against 24 us for the Jacobian product over the same observations.  Four lanes stride over a point's
 // observations and add up in a fixed butterfly: deterministic, tracks of <= 4 observations in one trip.)
-constexpr int PB_LANES = 4;
+#ifndef MM_PB_LANES
+#define MM_PB_LANES 4
+#endif
+constexpr int PB_LANES = MM_PB_LANES;      // lanes per point in the point-block sweeps (normal equations 84.3 / 81.6 / 98.0 us with 2 / 4 / 8: round 4)
 __device__ __forceinline__ void ba_point_blocks_body(mm_ba_problem pb, const double *__restrict__ cams,
                                                               const double *__restrict__ pts, const CamCoef *__restrict__ ctab, double *__restrict__ C,
                                                               double *__restrict__ gp, const unsigned bx, const unsigned gx) {
