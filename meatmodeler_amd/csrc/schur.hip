@@ -117,7 +117,13 @@ __global__ __launch_bounds__(256) void schur_rows_kernel(mm_ba_problem pb, const
 // S is summed in the same order on every run — the trust-region iteration, which is chaotic on outlier-laden matches,
 // then repeats bit for bit.  No atomics; every block is written together with its mirror image, so both triangles of the
 // band are filled (S is zero-filled first).
-constexpr int SP_WAVES = 4;
+// waves (= chunks) per workgroup of the pair kernel.  ONE since the second half of round 4: the workgroup barrier behind the
+// descriptor / camera-table loads made every wave wait for the slowest of its workgroup -- 259.7 / 230.7 / 205.6 / 198.4 us
+// with 8 / 4 / 2 / 1 waves at the bench shape (512 pairs per chunk)
+#ifndef MM_SP_WAVES
+#define MM_SP_WAVES 1
+#endif
+constexpr int SP_WAVES = MM_SP_WAVES;
 constexpr int MAX_SLABS = 64;
 // slab bookkeeping of the overlapped build + solve (all null / 0 when nobody consumes S concurrently)
 struct SlabSync {
