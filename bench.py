@@ -56,6 +56,10 @@ def parse():
     ap.add_argument("--ba-order", default=None, choices=("sequential", "wavefront"),
                     help="window schedule (default: wavefront -- the independent windows of a pass spread over the ranks and "
                          "over --ba-streams streams per GPU; sequential = every window starts from its predecessor's result)")
+    ap.add_argument("--ba-window-max-nfev", type=int, default=0,
+                    help="evaluation budget per window of the sliding-window adjustment (0: SciPy's default, 100 n).  The window "
+                         "trajectories on this outlier-laden synthetic clip are chaotic: the occasional window crawls for thousands of "
+                         "evaluations and then IS the stage (it runs alone at the end of its pass)")
     ap.add_argument("--ba-streams", type=int, default=8,
                     help="wavefront schedule: windows in flight per GPU (one HIP stream + host thread each)")
     ap.add_argument("--ba-batched", type=int, default=0,
@@ -210,7 +214,8 @@ def main():
             o["windows"] = pipe.adjust_windows(o, K, ext, window=a.ba_window, stride=a.ba_stride or max(1, a.ba_window // 2),
                                                ftol=1e-4, timers=timers, dist=d,
                                                order=a.ba_order or "wavefront",
-                                               streams=a.ba_streams, batched=bool(a.ba_batched))["windows"]
+                                               streams=a.ba_streams, batched=bool(a.ba_batched),
+                                               max_nfev=a.ba_window_max_nfev or None)["windows"]
             return o
         return pipe.run(frames, K, ext, ba=not a.no_ba, ftol=1e-4, verbose=a.verbose, dist=d, timers=timers)
 
@@ -424,7 +429,7 @@ def main():
                         "schur_pairs": out.get("n_pairs"), "render_s": t_render},
             "sliding_window_ba": None if "windows" not in out else {
                 "window": a.ba_window, "stride": a.ba_stride or max(1, a.ba_window // 2), "windows": len(out["windows"]),
-                "order": a.ba_order or "wavefront", "streams": a.ba_streams,
+                "order": a.ba_order or "wavefront", "streams": a.ba_streams, "max_nfev_per_window": a.ba_window_max_nfev or None,
                 "batched": bool(a.ba_batched) and (a.ba_order or "wavefront") == "wavefront",
                 "ms": stage_ms["ba_windows"], "nfev_total": int(sum(w["nfev"] for w in out["windows"])),
                 "observations_total": int(sum(w["observations"] for w in out["windows"])),

@@ -134,7 +134,7 @@ class ClipPipeline:
         return inside & (last_frame <= hi - 2)
 
     def adjust_windows(self, out, K, extrinsics, window=50, stride=25, ftol=1e-4, verbose=0, timers=None, dist=None,
-                       order="sequential", streams=1, batched=False):
+                       order="sequential", streams=1, batched=False, max_nfev=None):
         """Incremental bundle adjustment over a sliding window of keyframes: the reference keeps this step as a
         commented hook (processor.py:395-408: after a keyframe whose tracks were popped, `managePoints(popped_tracks)`
         + `adjustPoints` over everything so far); bounding it to the last `window` keyframes is what makes the
@@ -157,6 +157,10 @@ class ClipPipeline:
         same un-sharded code on the same inputs).  It is a different -- equally valid -- schedule than "sequential".
         streams > 1 (wavefront only): that many windows of a pass are in flight on this GPU at once, one HIP stream and
         one host thread each; the result does not depend on it either.
+        max_nfev: evaluation budget PER WINDOW (None: SciPy's default of 100 n, as adjustPoints).  A window is adjusted again
+        by its successor, so a budget is a reasonable guard against the occasional outlier-laden window that crawls
+        (observed: one window of 79 taking 3466 evaluations where the others take 30 - 340); a window that exhausts it
+        reports status 0 and its last accepted iterate is used.
         batched = True (wavefront only; supersedes `streams`): ALL windows of a pass that this rank owns advance in
         lock-step through mm_ba_trf_batched -- every kernel of the trust-region loop is launched once per round for all of
         them, so a pass costs about as many evaluations as its slowest window needs instead of the sum over its windows.
@@ -171,7 +175,7 @@ class ClipPipeline:
             raise ValueError("order must be 'sequential' or 'wavefront'")
         if order == "wavefront":
             return self._adjust_windows_wavefront(out, K, extrinsics, window, stride, ftol, verbose, timers, allreduce,
-                                                  world, rank, streams, batched)
+                                                  world, rank, streams, batched, max_nfev)
         F = int(np.asarray(extrinsics).shape[0])
         tp, of_, ok = out["track_ptr_dev"], out["obs_frame_dev"], out["obs_kp_dev"]
         xy = out["xy_dev"]
@@ -211,7 +215,7 @@ class ClipPipeline:
             O = int(fi.numel())
             pb = ops.BADevice(K, fi, pi, coords, hi - lo, P, d, self.ctx)
             res = SchurTRF(pb, allreduce=allreduce if sharded else None).solve(
-                cams[lo:hi].contiguous(), pts[sel].contiguous(), ftol=ftol, verbose=verbose if rank == 0 else 0)
+                cams[lo:hi].contiguous(), pts[sel].contiguous(), ftol=ftol, max_nfev=max_nfev, verbose=verbose if rank == 0 else 0)
             cams[lo:hi] = res.cams
             if sharded:
                 buf = torch.zeros((P_all, 3), dtype=torch.float64, device=d)
@@ -243,7 +247,7 @@ class ClipPipeline:
         return sel, fi, pi, coords, P, int(fi.numel())
 
     def _adjust_windows_wavefront(self, out, K, extrinsics, window, stride, ftol, verbose, timers, allreduce, world, rank,
-                                  streams=1, batched=False):
+                                  streams=1, batched=False, max_nfev=None):
         d = self.device
         F = int(np.asarray(extrinsics).shape[0])
         tp, of_ = out["track_ptr_dev"], out["obs_frame_dev"]
@@ -287,7 +291,7 @@ class ClipPipeline:
             if P == 0:
                 return
             pb = ops.BADevice(K, fi, pi, coords, hi - lo, P, d, ctx)
-            res = SchurTRF(pb).solve(cams[lo:hi].contiguous(), pts[sel].contiguous(), ftol=ftol,
+            res = SchurTRF(pb).solve(cams[lo:hi].contiguous(), pts[sel].contiguous(), ftol=ftol, max_nfev=max_nfev,
                                      verbose=verbose if rank == 0 and n_streams == 1 else 0)
             cams_upd[lo:hi] = res.cams
             cam_mask[lo:hi] = 1.0
@@ -321,7 +325,7 @@ class ClipPipeline:
                     pb = ops.BADevice(K, fi, pi, coords, hi - lo, P, d, self.ctx)
                     items.append((k, sel, pb, cams[lo:hi].contiguous(), pts[sel].contiguous(), P, O))
                 reps, _ = ops.trf_solve_batched([it[2] for it in items], [it[3] for it in items], [it[4] for it in items],
-                                                ftol, 1e-8, 1e-8, ctx=self.ctx)
+                                                ftol, 1e-8, 1e-8, max_nfev=max_nfev, ctx=self.ctx)
                 rows, ks = [], []
                 for (k, sel, pb, cw, pw, P, O), rep in zip(items, reps):
                     lo, hi = wins[k]

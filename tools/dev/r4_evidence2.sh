@@ -4,7 +4,7 @@
 c5() {
   name=$1; shift
   timeout -k 10 500 python bench.py --frames 2000 --height 2160 --width 3840 --nfeatures 8000 --ba-window 50 --ba-stride 25 \
-      --steps 1 --warmup 1 --no-cpu-baseline "$@" > gpurun_out/c5_$name.log 2> gpurun_out/c5_$name.err
+      --ba-window-max-nfev 500 --steps 1 --warmup 1 --no-cpu-baseline "$@" > gpurun_out/c5_$name.log 2> gpurun_out/c5_$name.err
   grep "^{" gpurun_out/c5_$name.log | tail -1 > gpurun_out/bench_c5_$name.json
   python - <<PY
 import json
