@@ -54,7 +54,10 @@ __device__ __forceinline__ int mad24(int a, int b, int c) {
 // the owned ranges are intervals that partition every level); the few columns / rows beyond, needed as right / lower taps
 // further down, are recomputed (bit-identical) rather than exchanged.  Bounds per tile boundary, as int32 in the workspace:
 //   X: lo[j][0..ntx] (j = 0..n: first owned column at run level j), nh[j][0..ntx-1] (last needed column); then Y likewise.
-constexpr int PY_MAXN = 4, PY_TW = 192, PY_TH = 64, PY_THREADS = 512;
+#ifndef MM_PY_THREADS
+#define MM_PY_THREADS 512
+#endif
+constexpr int PY_MAXN = 4, PY_TW = 192, PY_TH = 64, PY_THREADS = MM_PY_THREADS;
 constexpr int PY_PITCH_A = 216, PY_PITCH_B = 184;      // LDS pitches of the two rectangles (compile-time: row steps are immediates)
 constexpr int PY_BUF_A = 15984, PY_BUF_B = 11960, PY_TABX = 224, PY_TABY = 96;      // 74 rows x 216, 65 rows x 184: 34 KB with the tables, 4 workgroups per CU
 struct PyrChain {
@@ -971,10 +974,21 @@ __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9
 
 constexpr int DP = 39;  // raw patch side (31 + 2*(1 rotation slack) + 2*3 blur) -> offsets -19..19
 constexpr int DB = 33;  // blurred patch side, offsets -16..16
-constexpr int DESC_WAVES = 4;
-constexpr int DESC_KP_PER_WAVE = 8;  // key points a wave describes one after the other (the next patch prefetched)
+// (waves per workgroup / key points per wave / waves per SIMD the register allocation aims at: 1 / 8 / 8 since the sweeps of
+// round 4 -- 3.22 -> 3.05 ms; 4 / 8 / 5 before)
+#ifndef MM_DESC_WAVES
+#define MM_DESC_WAVES 1
+#endif
+#ifndef MM_DESC_KP
+#define MM_DESC_KP 8
+#endif
+#ifndef MM_DESC_OCC
+#define MM_DESC_OCC 8
+#endif
+constexpr int DESC_WAVES = MM_DESC_WAVES;
+constexpr int DESC_KP_PER_WAVE = MM_DESC_KP;  // key points a wave describes one after the other (the next patch prefetched)
 
-__global__ __launch_bounds__(64 * DESC_WAVES, 5) void orb_describe_kernel(OrbGeom g, const uint8_t *__restrict__ imgs,
+__global__ __launch_bounds__(64 * DESC_WAVES, MM_DESC_OCC) void orb_describe_kernel(OrbGeom g, const uint8_t *__restrict__ imgs,
                                                                        const uint8_t *__restrict__ ws,
                                                                        const int8_t *__restrict__ pattern,
                                                                        const int32_t *__restrict__ kp_meta,
