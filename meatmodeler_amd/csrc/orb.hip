@@ -493,7 +493,10 @@ __global__ __launch_bounds__(PY_THREADS) void orb_pyramid_kernel(OrbGeom g, cons
 }
 
 // ---- FAST-9/16 + NMS ----------------------------------------------------------------------------------------------------
-constexpr int FT_W = 64, FT_H = 64;        // keypoint tile
+#ifndef MM_FT_H
+#define MM_FT_H 64
+#endif
+constexpr int FT_W = 64, FT_H = MM_FT_H;        // keypoint tile (the width is the wave: lane = column)
 constexpr int FP_W = 80, FP_H = FT_H + 8;  // pixel tile in LDS (80 = 72 needed + alignment slack)
 constexpr int FS_W = FT_W + 2, FS_H = FT_H + 2;
 

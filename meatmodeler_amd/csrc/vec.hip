@@ -11,7 +11,10 @@
 namespace {
 
 constexpr int MD_MAX = 8;
-constexpr int MD_THREADS = 256;
+#ifndef MM_MD_THREADS
+#define MM_MD_THREADS 512      // (17.2 us per pass with 256 workgroups of 512 threads; 256 threads: 17.8, 128: 21.5, 1024: 19.4 -- round 4)
+#endif
+constexpr int MD_THREADS = MM_MD_THREADS;
 constexpr int MD_GRID = 2048;      // capacity of the per-workgroup partials (workspace size); the launch uses md_grid_cap() of them
 inline int md_grid_cap() {
     static const int cap = [] {
