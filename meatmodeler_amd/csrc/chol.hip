@@ -951,22 +951,38 @@ __device__ __forceinline__ bool poll_words_pipelined(const double *p, unsigned l
     auto there = [&](double v) {
         return !(__builtin_amdgcn_ballot_w64((unsigned long long)__double_as_longlong(v) == STAGE_SENTINEL) & watch);
     };
+#ifndef MM_CHOL_POLL_DEPTH
+#define MM_CHOL_POLL_DEPTH 4
+#endif
     double c0 = ld();
-    __builtin_amdgcn_s_sleep(2);
-    double c1 = ld();
-    __builtin_amdgcn_s_sleep(2);
-    double c2 = ld();
-    __builtin_amdgcn_s_sleep(2);
-    double c3 = ld();
+    double c1 = 0.0, c2 = 0.0, c3 = 0.0;
+    if (MM_CHOL_POLL_DEPTH >= 2) {
+        __builtin_amdgcn_s_sleep(2);
+        c1 = ld();
+    }
+    if (MM_CHOL_POLL_DEPTH >= 3) {
+        __builtin_amdgcn_s_sleep(2);
+        c2 = ld();
+    }
+    if (MM_CHOL_POLL_DEPTH >= 4) {
+        __builtin_amdgcn_s_sleep(2);
+        c3 = ld();
+    }
     for (long it = 0; it < SPIN_LIMIT; ++it) {
         if (there(c0)) return true;
         c0 = ld();
-        if (there(c1)) return true;
-        c1 = ld();
-        if (there(c2)) return true;
-        c2 = ld();
-        if (there(c3)) return true;
-        c3 = ld();
+        if (MM_CHOL_POLL_DEPTH >= 2) {
+            if (there(c1)) return true;
+            c1 = ld();
+        }
+        if (MM_CHOL_POLL_DEPTH >= 3) {
+            if (there(c2)) return true;
+            c2 = ld();
+        }
+        if (MM_CHOL_POLL_DEPTH >= 4) {
+            if (there(c3)) return true;
+            c3 = ld();
+        }
         if ((it & 63) == 63 && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
     }
     __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1023,7 +1039,7 @@ __device__ __forceinline__ bool stage_wait(StageRegs<K> &g, const double *lpub_c
     return false;
 }
 // The row head's LAST stage sits on the chain  factorisation of L_{r-1,r-1} -> this solve -> factorisation of L_rr: it may
-// poll the stage's own words (four per lane, two attempts in flight) instead of a canary followed by the load -- one trip
+// poll the stage's own words (four per lane) instead of a canary followed by the load -- one trip
 // to memory less per block column (only this one consumer per diagonal block: see stage_wait on flooding).
 #ifndef MM_CHOL_DIRECT_LAST
 #define MM_CHOL_DIRECT_LAST 2
@@ -1031,22 +1047,11 @@ __device__ __forceinline__ bool stage_wait(StageRegs<K> &g, const double *lpub_c
 template <int K>
 __device__ __forceinline__ bool stage_wait_direct(StageRegs<K> &g, const double *lpub_c, const double *Linv_c, int lane,
                                                   int32_t *abort_flag) {
-    if (stage_complete<K>(g)) return true;
-    StageRegs<K> ga, gb;
-    stage_issue<K>(ga, lpub_c, Linv_c, lane);
-    __builtin_amdgcn_s_sleep(2);
-    stage_issue<K>(gb, lpub_c, Linv_c, lane);
+    // ONE attempt in flight: two (0.566 ms per factor + solve) or more flood the queues the producer's stores travel through
+    // and are slower than this (0.560)
     for (long it = 0; it < SPIN_LIMIT; ++it) {
-        if (stage_complete<K>(ga)) {
-            g = ga;
-            return true;
-        }
-        stage_issue<K>(ga, lpub_c, Linv_c, lane);
-        if (stage_complete<K>(gb)) {
-            g = gb;
-            return true;
-        }
-        stage_issue<K>(gb, lpub_c, Linv_c, lane);
+        if (stage_complete<K>(g)) return true;
+        stage_issue<K>(g, lpub_c, Linv_c, lane);
         if ((it & 63) == 63 && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
     }
     __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
